@@ -1,0 +1,720 @@
+"""Generate golden input/output vectors by IMPORTING the reference (read-only at
+/root/reference) on CPU in the build container.  Run:  python tests/golden/make_golden.py
+
+Only data leaves this script: inputs and the reference's outputs, written as small .npz
+fixtures next to it.  The reference's source never travels.  Every fixture
+records the reference file:line that produced it in the README table of tests/golden/.
+"""
+import os
+import random
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _refshim  # noqa: E402
+
+_refshim.install()
+
+from qdiff.quant_layer import UniformAffineQuantizer, QuantModule, lp_loss  # noqa: E402
+from qdiff.adaptive_rounding import AdaRoundQuantizer  # noqa: E402
+from qdiff.block_recon import LinearTempDecay, LossFunction, block_reconstruction  # noqa: E402
+from qdiff.layer_recon import layer_reconstruction  # noqa: E402
+from qdiff.quant_model import QuantModel  # noqa: E402
+from qdiff.quant_block import (QuantResnetBlock, QuantAttnBlock, QuantResBlock,  # noqa: E402
+                               QuantBasicTransformerBlock, BaseQuantBlock, QuantAttentionBlock)
+from qdiff.set_quantize_params import set_weight_quantize_params, set_act_quantize_params  # noqa: E402
+from qdiff.data_utils import save_inp_oup_data  # noqa: E402
+from qdiff.recon_block_Qmodel import recon_block_Qmodel, Change_LDM_model_attnblock  # noqa: E402
+from qdiff.utils import seed_everything  # noqa: E402
+from ddim.models.diffusion import Model as DDPMModel, ResnetBlock, AttnBlock  # noqa: E402
+from ddim.functions.denoising import compute_alpha, generalized_steps  # noqa: E402
+from ldm.modules.diffusionmodules.openaimodel import UNetModel, ResBlock, AttentionBlock  # noqa: E402
+from ldm.modules.attention import BasicTransformerBlock  # noqa: E402
+from ldm.modules.diffusionmodules.util import (make_ddim_timesteps, make_ddim_sampling_parameters,  # noqa: E402
+                                               make_beta_schedule, timestep_embedding)
+
+
+def A(t):
+    if isinstance(t, torch.Tensor):
+        return t.detach().cpu().numpy()
+    return np.asarray(t)
+
+
+def save(name, d):
+    flat = {}
+    for k, v in d.items():
+        flat[k] = A(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **flat)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+def reinit_zero_modules(model, gen):
+    """zero_module() convs are all-zero at init (openaimodel.py:229-231,315,721); give them
+    small random values so the fixtures exercise them."""
+    for p in model.parameters():
+        if p.numel() > 0 and float(p.detach().abs().max()) == 0.0:
+            with torch.no_grad():
+                p.copy_(torch.randn(p.shape, generator=gen) * 0.05)
+
+
+def qparams_of(qnn):
+    """Collect (delta, zero_point, n_bits) of every quantizer, keyed by module path."""
+    out = {}
+    for name, m in qnn.named_modules():
+        if isinstance(m, (UniformAffineQuantizer, AdaRoundQuantizer)):
+            if m.delta is None:
+                continue
+            out["qp/%s/delta" % name] = A(m.delta).astype(np.float32)
+            out["qp/%s/zero_point" % name] = A(m.zero_point).astype(np.float32)
+            out["qp/%s/n_bits" % name] = np.int64(m.n_bits)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+def g1_weight_init():
+    """G1: weight UAQ init, per-channel (quant_layer.py:95-105,120-147,150-213,215-226)."""
+    g = torch.Generator().manual_seed(101)
+    d = {}
+    cases = []
+    w = torch.randn(8, 6, 3, 3, generator=g) * 0.2
+    cases.append(("conv_two", w))
+    cases.append(("lin_two", torch.randn(12, 20, generator=g) * 0.5))
+    cases.append(("conv_pos", (torch.rand(8, 4, 3, 3, generator=g) * 0.3)))
+    cases.append(("conv_neg", -(torch.rand(8, 4, 1, 1, generator=g) * 0.7)))
+    wz = torch.randn(6, 5, 3, 3, generator=g) * 0.1
+    wz[2] = 0.0  # an all-zero channel -> eps clamp path
+    cases.append(("conv_zero_ch", wz))
+    for cname, w in cases:
+        d["w/%s" % cname] = w
+        for bits in (4, 8):
+            for sym in (True, False):
+                if not sym and bits == 8 and cname not in ("conv_pos", "conv_neg"):
+                    # 2-D search at 8 bit is 100x256 candidates: keep one small case only
+                    if cname != "lin_two":
+                        continue
+                q = UniformAffineQuantizer(n_bits=bits, symmetric=sym, channel_wise=True, scale_method="mse")
+                out = q(w)
+                key = "%s/b%d/%s" % (cname, bits, "sym" if sym else "asym")
+                d[key + "/delta"] = q.delta
+                d[key + "/zero_point"] = q.zero_point
+                d[key + "/one_side"] = np.array({"pos": 1, "neg": -1, "no": 0}[q.one_side_dist])
+                d[key + "/out"] = out
+    save("g1_weight_init", d)
+
+
+def g2_act_init():
+    """G2: act UAQ init with EMA over batches (quant_layer.py:79-85,150-199,246-264)."""
+    g = torch.Generator().manual_seed(202)
+    d = {}
+    for cname, gen in (("two", lambda: torch.randn(4, 8, 6, 6, generator=g) * 1.5),
+                       ("pos", lambda: torch.rand(4, 8, 6, 6, generator=g) * 2.0),
+                       ("softmax", lambda: torch.softmax(torch.randn(4, 16, 16, generator=g) * 2, -1))):
+        for bits in (8, 4):
+            for sym in (True, False):
+                if not sym and bits == 8:
+                    continue  # per-tensor 2-D search at 8 bit: 25600 passes, skip
+                q = UniformAffineQuantizer(n_bits=bits, symmetric=sym, channel_wise=False, scale_method="mse",
+                                           leaf_param=True, prob=0.5)
+                g.manual_seed(202 + bits)
+                for k in range(4):
+                    x = gen()
+                    out = q(x)
+                    key = "%s/b%d/%s/step%d" % (cname, bits, "sym" if sym else "asym", k)
+                    d[key + "/x"] = x
+                    d[key + "/delta"] = q.delta
+                    d[key + "/zero_point"] = q.zero_point
+                    d[key + "/running_min"] = q.running_min
+                    d[key + "/running_max"] = q.running_max
+                    d[key + "/out"] = out
+    save("g2_act_init", d)
+
+
+def g3_uaq_forward():
+    """G3: inited UAQ forward/backward incl. injected prob mask (quant_layer.py:266-276)."""
+    g = torch.Generator().manual_seed(303)
+    d = {}
+    x = (torch.randn(4, 8, 6, 6, generator=g) * 1.3)
+    gy = torch.randn(4, 8, 6, 6, generator=g)
+    mask_u = torch.rand(4, 8, 6, 6, generator=g)
+    d["x"], d["gy"], d["mask_u"] = x, gy, mask_u
+    for bits, delta, zp in ((8, 0.021, 128.0), (8, 0.013, 127.0), (4, 0.31, 7.0), (8, 0.009, 0.0)):
+        q = UniformAffineQuantizer(n_bits=bits, symmetric=True, channel_wise=False, scale_method="mse",
+                                   leaf_param=True, prob=0.5)
+        q.delta = nn.Parameter(torch.tensor(delta))
+        q.zero_point = torch.tensor(zp)
+        q.inited = True
+        key = "b%d_d%g_z%g" % (bits, delta, zp)
+        xr = x.clone().requires_grad_(True)
+        out = q(xr)
+        (out * gy).sum().backward()
+        codes = torch.clamp(torch.round(x / delta) + zp, 0, 2 ** bits - 1)
+        d[key + "/out"], d[key + "/codes"] = out, codes
+        d[key + "/gx"], d[key + "/gdelta"] = xr.grad, q.delta.grad
+        # training mode with the mask injected through a patched rand_like
+        q.delta.grad = None
+        q.is_training = True
+        orig = torch.rand_like
+        torch.rand_like = lambda t, **k: mask_u
+        try:
+            xr = x.clone().requires_grad_(True)
+            out = q(xr)
+            (out * gy).sum().backward()
+        finally:
+            torch.rand_like = orig
+        d[key + "/train_out"], d[key + "/train_gx"], d[key + "/train_gdelta"] = out, xr.grad, q.delta.grad
+    save("g3_uaq_forward", d)
+
+
+def g4_adaround():
+    """G4: AdaRound alpha init / soft / hard / grad (adaptive_rounding.py:39-72)."""
+    g = torch.Generator().manual_seed(404)
+    d = {}
+    for cname, w, bits in (("conv", torch.randn(8, 6, 3, 3, generator=g) * 0.2, 4),
+                           ("lin", torch.randn(10, 16, generator=g) * 0.4, 8)):
+        uaq = UniformAffineQuantizer(n_bits=bits, symmetric=True, channel_wise=True, scale_method="mse")
+        uaq(w)
+        aq = AdaRoundQuantizer(uaq=uaq, round_mode="learned_hard_sigmoid", weight_tensor=w.clone())
+        d[cname + "/w"], d[cname + "/delta"], d[cname + "/zero_point"] = w, aq.delta, aq.zero_point
+        d[cname + "/alpha0"] = aq.alpha
+        aq.soft_targets = True
+        gy = torch.randn(w.shape, generator=g)
+        out = aq(w)
+        (out * gy).sum().backward()
+        d[cname + "/gy"], d[cname + "/soft_out"], d[cname + "/galpha"] = gy, out, aq.alpha.grad
+        # perturb alpha so hard rounding differs from nearest
+        with torch.no_grad():
+            aq.alpha.add_(torch.randn(w.shape, generator=g) * 2.0)
+        d[cname + "/alpha1"] = aq.alpha
+        aq.alpha.grad = None
+        out = aq(w)
+        (out * gy).sum().backward()
+        d[cname + "/soft_out1"], d[cname + "/galpha1"] = out, aq.alpha.grad
+        aq.soft_targets = False
+        d[cname + "/hard_out1"] = aq(w)
+    save("g4_adaround", d)
+
+
+def g5_loss():
+    """G5: lp_loss fwd/bwd, LinearTempDecay, dead round-loss branch (quant_layer.py:26-33,
+    block_recon.py:235-323)."""
+    g = torch.Generator().manual_seed(505)
+    d = {}
+    for cname, shape in (("4d", (4, 8, 6, 6)), ("2d", (4, 24)), ("3d", (4, 9, 16))):
+        p = torch.randn(shape, generator=g).requires_grad_(True)
+        t = torch.randn(shape, generator=g)
+        l = lp_loss(p, t, p=2.0)
+        l.backward()
+        d[cname + "/pred"], d[cname + "/tgt"], d[cname + "/loss"], d[cname + "/gpred"] = p, t, l, p.grad
+        d[cname + "/loss_all"] = lp_loss(p, t, p=2.4, reduction="all")
+    td = LinearTempDecay(100, rel_start_decay=0.2, start_b=20, end_b=2)
+    d["temp/t"] = np.arange(0, 101)
+    d["temp/b"] = np.array([td(t) for t in range(0, 101)], dtype=np.float64)
+    save("g5_loss", d)
+
+
+def _mk_qmodule(org, wbits=4, abits=8):
+    wq = {"n_bits": wbits, "symmetric": True, "channel_wise": True, "scale_method": "mse"}
+    aq = {"n_bits": abits, "symmetric": True, "channel_wise": False, "scale_method": "mse",
+          "leaf_param": True, "prob": 0.5}
+    return QuantModule(org, wq, aq), wq, aq
+
+
+def g6_quant_module():
+    """G6: QuantModule forward variants (quant_layer.py:406-437)."""
+    torch.manual_seed(606)
+    g = torch.Generator().manual_seed(606)
+    d = {}
+    cases = [
+        ("conv3", nn.Conv2d(32, 48, 3, padding=1), torch.randn(4, 32, 8, 8, generator=g), 0, None),
+        ("conv3s2", nn.Conv2d(32, 32, 3, stride=2, padding=0),
+         torch.nn.functional.pad(torch.randn(4, 32, 8, 8, generator=g), (0, 1, 0, 1)), 0, None),
+        ("conv1split", nn.Conv2d(64, 32, 1), torch.randn(4, 64, 8, 8, generator=g) *
+         torch.cat([torch.ones(32), 3 * torch.ones(32)]).view(1, 64, 1, 1), 32, None),
+        ("conv1d", nn.Conv1d(32, 96, 1), torch.randn(4, 32, 16, generator=g), 0, None),
+        ("linear", nn.Linear(32, 64), torch.randn(4, 32, generator=g), 0, None),
+        ("linear3d", nn.Linear(32, 64, bias=False), torch.randn(4, 16, 32, generator=g), 0, None),
+    ]
+    for cname, org, x, split, _ in cases:
+        qm, _, _ = _mk_qmodule(org)
+        d[cname + "/weight"] = org.weight
+        if org.bias is not None:
+            d[cname + "/bias"] = org.bias
+        d[cname + "/x"] = x
+        d[cname + "/out_fp"] = qm(x, split) if split else qm(x)
+        qm.set_quant_state(True, False)
+        d[cname + "/out_w"] = qm(x)
+        qm.weight_quantizer.set_inited(True)
+        if split:
+            qm.weight_quantizer_0.set_inited(True)
+        qm.set_quant_state(True, True)
+        d[cname + "/out_wa"] = qm(x)
+        qm.act_quantizer.set_inited(True)
+        d[cname + "/w_delta"], d[cname + "/w_zp"] = qm.weight_quantizer.delta, qm.weight_quantizer.zero_point
+        d[cname + "/a_delta"], d[cname + "/a_zp"] = qm.act_quantizer.delta, qm.act_quantizer.zero_point
+        if split:
+            qm.act_quantizer_0.set_inited(True)
+            d[cname + "/w_delta_0"], d[cname + "/w_zp_0"] = qm.weight_quantizer_0.delta, qm.weight_quantizer_0.zero_point
+            d[cname + "/a_delta_0"], d[cname + "/a_zp_0"] = qm.act_quantizer_0.delta, qm.act_quantizer_0.zero_point
+        d[cname + "/split"] = np.int64(split)
+    save("g6_quant_module", d)
+
+
+# --------------------------------------------------------------------------------------
+def cifar_cfg(ch=32, ch_mult=(1, 2, 2), nres=2, attn=(8,), res=16):
+    return SimpleNamespace(
+        model=SimpleNamespace(type="simple", in_channels=3, out_ch=3, ch=ch, ch_mult=list(ch_mult),
+                              num_res_blocks=nres, attn_resolutions=list(attn), dropout=0.0,
+                              resamp_with_conv=True),
+        data=SimpleNamespace(image_size=res),
+        diffusion=SimpleNamespace(num_diffusion_timesteps=1000))
+
+
+WQ4 = {"n_bits": 4, "symmetric": True, "channel_wise": True, "scale_method": "mse"}
+AQ8 = {"n_bits": 8, "symmetric": True, "channel_wise": False, "scale_method": "mse", "leaf_param": True,
+       "prob": 0.5}
+
+
+def sd_of(model):
+    return {"sd/" + k: v for k, v in model.state_dict().items()}
+
+
+def g13_cifar_unet():
+    """G13a: tiny DDPM UNet (ddim/models/diffusion.py:199-392) FP and fake-quant forward after
+    the reference's own scale-init drivers (set_quantize_params.py:9-71), split shortcut on."""
+    seed_everything(1301)
+    g = torch.Generator().manual_seed(1301)
+    cfg = cifar_cfg()
+    model = DDPMModel(cfg).eval()
+    d = sd_of(model)
+    d["cfg/ch"], d["cfg/ch_mult"], d["cfg/nres"], d["cfg/attn"], d["cfg/res"] = 32, [1, 2, 2], 2, [8], 16
+    x = torch.randn(8, 3, 16, 16, generator=g)
+    t = torch.tensor([999., 870., 640., 500., 333., 120., 40., 0.])
+    d["x"], d["t"] = x, t
+    with torch.no_grad():
+        d["out_fp"] = model(x, t)
+    qnn = QuantModel(model, WQ4, AQ8, sm_abit=8)
+    qnn.eval()
+    qnn.set_quant_state(False, False)
+    qnn.set_first_last_layer_to_8bit()
+    qnn.disable_network_output_quantization()
+    qnn.model.config.split_shortcut = True
+    cali = (x, t)
+    set_weight_quantize_params(qnn, cali)
+    set_act_quantize_params(qnn, cali, batch_size=4)   # 2 batches -> EMA exercised
+    qnn.set_quant_state(True, True)
+    with torch.no_grad():
+        d["out_q"] = qnn(x, t)
+        qnn.set_quant_state(True, False)
+        d["out_wq"] = qnn(x, t)
+    d.update(qparams_of(qnn))
+    # G11 structure: unit order as the reference walks it
+    units = []
+
+    class Spy(recon_block_Qmodel):
+        pass
+
+    rb = sys.modules['qdiff.recon_block_Qmodel']
+    rec = []
+    ob, ol = rb.block_reconstruction, rb.layer_reconstruction
+    rb.block_reconstruction = lambda m, blk, **k: rec.append(("block", blk))
+    rb.layer_reconstruction = lambda m, lay, **k: rec.append(("layer", lay))
+    try:
+        qnn.set_quant_state(True, True)
+        recon_block_Qmodel(None, qnn, cali, {}).recon()
+    finally:
+        rb.block_reconstruction, rb.layer_reconstruction = ob, ol
+    names = {m: n for n, m in qnn.named_modules()}
+    d["units"] = np.array(["%s:%s:%s" % (k, names[m], type(m).__name__) for k, m in rec])
+    save("g13_cifar_unet", d)
+    return model, qnn, cali
+
+
+def ldm_kwargs(kind):
+    if kind == "imagenet":   # cin256-v2.yaml shape family, shrunk
+        return dict(image_size=8, in_channels=3, out_channels=3, model_channels=32,
+                    attention_resolutions=[2, 1], num_res_blocks=1, channel_mult=[1, 2],
+                    num_heads=1, use_spatial_transformer=True, transformer_depth=1, context_dim=16)
+    if kind == "church":     # lsun_churches256 shape family, shrunk
+        return dict(image_size=8, in_channels=4, out_channels=4, model_channels=32,
+                    attention_resolutions=[2, 1], num_res_blocks=1, channel_mult=[1, 2],
+                    num_heads=2, use_scale_shift_norm=True, resblock_updown=True)
+    raise ValueError(kind)
+
+
+def g13_ldm_unet(kind):
+    """G13b/c: tiny LDM UNetModel (openaimodel.py:447-783) FP and fake-quant forward."""
+    seed_everything(1302)
+    g = torch.Generator().manual_seed(1302 + len(kind))
+    kw = ldm_kwargs(kind)
+    model = UNetModel(**kw).eval()
+    reinit_zero_modules(model, g)
+    d = sd_of(model)
+    for k, v in kw.items():
+        d["cfg/" + k] = np.asarray(v)
+    cin = kw["in_channels"]
+    x = torch.randn(8, cin, 8, 8, generator=g)
+    t = torch.tensor([981, 800, 640, 500, 333, 120, 40, 1]).long()
+    ctx = torch.randn(8, 1, 16, generator=g) if kind == "imagenet" else None
+    d["x"], d["t"] = x, t
+    if ctx is not None:
+        d["ctx"] = ctx
+    with torch.no_grad():
+        d["out_fp"] = model(x, t, ctx)
+    aq = dict(AQ8)
+    qnn = QuantModel(model, WQ4, aq, sm_abit=8, act_quant_mode="qdiff")
+    qnn.eval()
+    qnn.set_quant_state(False, False)
+    qnn.set_first_last_layer_to_8bit()
+    qnn.disable_network_output_quantization()
+    qnn.set_grad_ckpt(False)
+    qnn.model.split_shortcut = True
+    cali = (x, t, ctx) if ctx is not None else (x, t)
+    set_weight_quantize_params(qnn, cali)
+    # the generic driver only flips QuantModule/QuantAttnBlock quantizers (set_quantize_params.py:17-27);
+    # the LDM/conditional drivers also flip q/k/v/w of the attention wrappers
+    # (set_quantize_params_Conditional.py:31-46).  Quantizers start with inited=False, so one
+    # pass initialises every one of them either way.
+    set_act_quantize_params(qnn, cali, batch_size=4)
+    for m in qnn.modules():
+        if isinstance(m, UniformAffineQuantizer):
+            m.set_inited(True)
+    qnn.set_quant_state(True, True)
+    with torch.no_grad():
+        d["out_q"] = qnn(x, t, ctx)
+        qnn.set_quant_state(True, False)
+        d["out_wq"] = qnn(x, t, ctx)
+    d.update(qparams_of(qnn))
+    rb = sys.modules['qdiff.recon_block_Qmodel']
+    rec = []
+    ob, ol = rb.block_reconstruction, rb.layer_reconstruction
+    rb.block_reconstruction = lambda m, blk, **k: rec.append(("block", blk))
+    rb.layer_reconstruction = lambda m, lay, **k: rec.append(("layer", lay))
+    try:
+        recon_block_Qmodel(None, qnn, cali, {}).recon()
+    finally:
+        rb.block_reconstruction, rb.layer_reconstruction = ob, ol
+    names = {m: n for n, m in qnn.named_modules()}
+    d["units"] = np.array(["%s:%s:%s" % (k, names[m], type(m).__name__) for k, m in rec])
+    save("g13_ldm_%s" % kind, d)
+
+
+def g7_blocks():
+    """G7: block forwards FP vs fake-quant with the reference's own initialised qparams
+    (quant_block.py:46-116,168-192,204-235,238-285,300-348,398-451)."""
+    seed_everything(707)
+    g = torch.Generator().manual_seed(707)
+    d = {}
+    # --- CIFAR blocks
+    rb = ResnetBlock(in_channels=64, out_channels=32, dropout=0.0, temb_channels=64).eval()
+    at = AttnBlock(32).eval()
+    holder = nn.Module()
+    holder.in_channels = 3
+    holder.rb, holder.at = rb, at
+    for k, v in holder.state_dict().items():
+        d["cifar/sd/" + k] = v
+    qh = QuantModel(holder, WQ4, AQ8, sm_abit=8)
+    x = torch.randn(4, 64, 8, 8, generator=g) * torch.cat([torch.ones(32), 2.5 * torch.ones(32)]).view(1, 64, 1, 1)
+    temb = torch.randn(4, 64, generator=g)
+    xa = torch.randn(4, 32, 8, 8, generator=g)
+    d["cifar/x"], d["cifar/temb"], d["cifar/xa"] = x, temb, xa
+    qrb, qat = qh.model.rb, qh.model.at
+    assert isinstance(qrb, QuantResnetBlock) and isinstance(qat, QuantAttnBlock)
+    with torch.no_grad():
+        d["cifar/rb_fp"] = qrb(x, temb, split=32)
+        d["cifar/at_fp"] = qat(xa)
+        qh.set_quant_state(True, True)
+        d["cifar/rb_q0"] = qrb(x, temb, split=32)   # first call initialises every quantizer
+        d["cifar/at_q0"] = qat(xa)
+        for m in qh.modules():
+            if isinstance(m, UniformAffineQuantizer):
+                m.set_inited(True)
+        d["cifar/rb_q"] = qrb(x, temb, split=32)
+        d["cifar/at_q"] = qat(xa)
+    for k, v in qparams_of(qh).items():
+        d["cifar/" + k] = v
+    # --- LDM blocks
+    res = ResBlock(32, 64, 0.0, out_channels=64).eval()
+    res_ss = ResBlock(32, 64, 0.0, out_channels=32, use_scale_shift_norm=True, down=True).eval()
+    res_up = ResBlock(32, 64, 0.0, out_channels=32, up=True).eval()
+    tr = BasicTransformerBlock(32, 2, 16, context_dim=24, checkpoint=False).eval()
+    ab = AttentionBlock(32, num_heads=2).eval()
+    holder = nn.Module()
+    holder.in_channels = 3
+    holder.res, holder.res_ss, holder.res_up, holder.tr, holder.ab = res, res_ss, res_up, tr, ab
+    reinit_zero_modules(holder, g)
+    for k, v in holder.state_dict().items():
+        d["ldm/sd/" + k] = v
+    qh = QuantModel(holder, WQ4, AQ8, sm_abit=8)
+    x = torch.randn(4, 32, 8, 8, generator=g)
+    emb = torch.randn(4, 64, generator=g)
+    xs = torch.randn(4, 16, 32, generator=g)
+    ctx1 = torch.randn(4, 1, 24, generator=g)
+    ctx7 = torch.randn(4, 7, 24, generator=g)
+    d["ldm/x"], d["ldm/emb"], d["ldm/xs"], d["ldm/ctx1"], d["ldm/ctx7"] = x, emb, xs, ctx1, ctx7
+    m = qh.model
+    assert isinstance(m.res, QuantResBlock) and isinstance(m.tr, QuantBasicTransformerBlock)
+    with torch.no_grad():
+        d["ldm/res_fp"] = m.res(x, emb)
+        d["ldm/res_ss_fp"] = m.res_ss(x, emb)
+        d["ldm/res_up_fp"] = m.res_up(x, emb)
+        d["ldm/tr_fp7"] = m.tr(xs, ctx7)
+        d["ldm/tr_fp1"] = m.tr(xs, ctx1)
+        d["ldm/ab_fp"] = m.ab(x)
+        qh.set_quant_state(True, True)
+        m.res(x, emb), m.res_ss(x, emb), m.res_up(x, emb), m.tr(xs, ctx7), m.ab(x)
+        for mm in qh.modules():
+            if isinstance(mm, UniformAffineQuantizer):
+                mm.set_inited(True)
+        d["ldm/res_q"] = m.res(x, emb)
+        d["ldm/res_ss_q"] = m.res_ss(x, emb)
+        d["ldm/res_up_q"] = m.res_up(x, emb)
+        d["ldm/tr_q7"] = m.tr(xs, ctx7)
+        d["ldm/tr_q1"] = m.tr(xs, ctx1)
+        d["ldm/ab_q"] = m.ab(x)
+    for k, v in qparams_of(qh).items():
+        d["ldm/" + k] = v
+    save("g7_blocks", d)
+
+
+class _ToyNet(nn.Module):
+    """2-block toy model for G8/G12: conv_in -> ResnetBlock -> AttnBlock -> conv_out."""
+
+    def __init__(self):
+        super().__init__()
+        self.in_channels = 3
+        self.conv_in = nn.Conv2d(3, 32, 3, padding=1)
+        self.temb_lin = nn.Linear(8, 64)
+        self.rb = ResnetBlock(in_channels=32, out_channels=32, dropout=0.0, temb_channels=64)
+        self.at = AttnBlock(32)
+        self.conv_out = nn.Conv2d(32, 3, 3, padding=1)
+
+    def forward(self, x, t, context=None):
+        temb = self.temb_lin(torch.stack([torch.sin(t * (i + 1) * 0.01) for i in range(8)], 1))
+        h = self.conv_in(x)
+        h = self.rb(h, temb)
+        h = self.at(h)
+        return self.conv_out(h)
+
+
+def g8_g12_recon():
+    """G12: save_inp_oup_data nesting/values (data_utils.py:7-75,107-171).
+    G8: layer_reconstruction / block_reconstruction trajectories with prob=1, input_prob=1
+    (no device RNG; python `random` fixes idx) (layer_recon.py:13-129, block_recon.py:13-232)."""
+    seed_everything(808)
+    g = torch.Generator().manual_seed(808)
+    net = _ToyNet().eval()
+    d = {"sd/" + k: v for k, v in net.state_dict().items()}
+    aq = dict(AQ8)
+    aq["prob"] = 1.0
+    qnn = QuantModel(net, WQ4, aq, sm_abit=8)
+    qnn.eval()
+    N = 64
+    x = torch.randn(N, 3, 8, 8, generator=g)
+    t = torch.randint(0, 1000, (N,), generator=g).float()
+    d["x"], d["t"] = x, t
+    cali = (x, t)
+    set_weight_quantize_params(qnn, cali)
+    set_act_quantize_params(qnn, cali, batch_size=32)
+    for k, v in qparams_of(qnn).items():
+        d["init/" + k] = v
+    # G12
+    qnn.set_quant_state(True, True)
+    res, ci, co = save_inp_oup_data(qnn, qnn.model.rb, cali, True, True, batch_size=32, input_prob=True, keep_gpu=False)
+    d["g12/rb/resblock"] = np.int64(res)
+    d["g12/rb/inp_q"], d["g12/rb/temb_q"] = ci[0][0], ci[0][1]
+    d["g12/rb/inp_fp"], d["g12/rb/temb_fp"] = ci[1][0], ci[1][1]
+    d["g12/rb/out_fp"] = co
+    res, ci, co = save_inp_oup_data(qnn, qnn.model.conv_in, cali, True, True, batch_size=32, input_prob=True, keep_gpu=False)
+    d["g12/conv_in/resblock"] = np.int64(res)
+    d["g12/conv_in/inp_q"], d["g12/conv_in/inp_fp"], d["g12/conv_in/out_fp"] = ci[0], ci[1], co
+
+    # G8: walk the units like recon_block_Qmodel, recording per-iteration state through a
+    # patched Adam.step (alpha / delta after every iteration)
+    kwargs = dict(cali_data=cali, iters=12, act_quant=True, asym=True, opt_mode="mse", lr_a=1e-3, lr_w=5e-2,
+                  p=2.0, weight=0.0001, b_range=(20, 2), warmup=0.2, batch_size=16, input_prob=1.0,
+                  add_loss=0.8, recon_w=True, recon_a=True, keep_gpu=True)
+    traj = {}
+    cur = {"name": None}
+    orig_step = torch.optim.Adam.step
+
+    def step(self, *a, **k):
+        r = orig_step(self, *a, **k)
+        ps = [p for gr in self.param_groups for p in gr["params"]]
+        key = "%s/%s" % (cur["name"], "a" if ps[0].numel() == 1 else "w")
+        traj.setdefault(key, []).append(torch.cat([p.detach().flatten() for p in ps]).clone())
+        return r
+
+    torch.optim.Adam.step = step
+    idx_log = {}
+    orig_sample = random.sample
+
+    def sample(pop, k):
+        r = orig_sample(pop, k)
+        idx_log.setdefault(cur["name"], []).append(list(r))
+        return r
+
+    random.sample = sample
+    try:
+        random.seed(8080)
+        cur["name"] = "conv_in"
+        layer_reconstruction(qnn, qnn.model.conv_in, **kwargs)
+        cur["name"] = "temb_lin"
+        layer_reconstruction(qnn, qnn.model.temb_lin, **kwargs)
+        cur["name"] = "rb"
+        block_reconstruction(qnn, qnn.model.rb, **kwargs)
+        cur["name"] = "at"
+        block_reconstruction(qnn, qnn.model.at, **kwargs)
+        cur["name"] = "conv_out"
+        layer_reconstruction(qnn, qnn.model.conv_out, **kwargs)
+    finally:
+        torch.optim.Adam.step = orig_step
+        random.sample = orig_sample
+    for k, v in traj.items():
+        d["g8/traj/" + k] = torch.stack(v)
+    for k, v in idx_log.items():
+        d["g8/idx/" + k] = np.array(v)
+    for k, v in qparams_of(qnn).items():
+        d["g8/final/" + k] = v
+    for name, m in qnn.named_modules():
+        if isinstance(m, AdaRoundQuantizer):
+            d["g8/final/alpha/" + name] = m.alpha
+    qnn.set_quant_state(True, True)
+    with torch.no_grad():
+        d["g8/final/out_q"] = qnn(x[:8], t[:8])
+    d["g8/block_count"] = np.int64(qnn.block_count)
+    save("g8_recon", d)
+
+
+def g9_tdac():
+    """G9: TDAC scoring / allocation maths on synthetic feature maps (calibration.py:45-92;
+    Church `>= 0` fix-up variant :332)."""
+    g = torch.Generator().manual_seed(909)
+    d = {}
+    for T, N, lam, r in ((10, 64, 1.2, 3.0), (20, 256, 1.2, 3.0), (20, 100, 0.5, 2.0)):
+        base = torch.randn(4, 32, 4, 4, generator=g)
+        fm = [base * (0.3 + 0.2 * i) + torch.randn(4, 32, 4, 4, generator=g) * (0.2 + 0.25 * i) for i in range(T)]
+        dense_num = torch.zeros(T, dtype=torch.int16)
+        for i in range(T):
+            for j in range(T):
+                if i != j:
+                    mse = torch.mean((fm[i] - fm[j]) ** 2)
+                    if mse <= r:
+                        dense_num[i] = dense_num[i] + 1
+        dn = (dense_num - dense_num.min()) / (dense_num.max() - dense_num.min())
+        cs = nn.CosineSimilarity(dim=1, eps=1e-6)
+        cd = torch.zeros(T)
+        for i in range(T):
+            for j in range(T):
+                if i != j:
+                    cd[i] = cd[i] + torch.sum(1 - cs(fm[i], fm[j]))
+        cdn = (cd - cd.min()) / (cd.max() - cd.min())
+        w = dn + lam * cdn
+        prob = w / torch.sum(w)
+        key = "T%d_N%d" % (T, N)
+        for variant in ("gt", "ge"):
+            t_num = torch.tensor((prob * N).round(), dtype=int)
+            t_error = N - torch.sum(t_num)
+            _, t_num_sort = torch.sort(t_num, descending=True)
+            if t_error >= 0:
+                t_num[t_num_sort[:t_error]] += 1
+            else:
+                for i in reversed(range(len(t_num))):
+                    if t_error == 0:
+                        break
+                    ok = (t_num[i] > 0) if variant == "gt" else (t_num[i] >= 0)
+                    if ok:
+                        t_num[i] -= 1
+                        t_error = t_error + 1
+            d[key + "/t_num_" + variant] = t_num
+        d[key + "/fm"] = torch.stack(fm)
+        d[key + "/lam"], d[key + "/r"], d[key + "/N"] = lam, r, N
+        d[key + "/dense_num"], d[key + "/cos_dis"], d[key + "/w"] = dense_num, cd, w
+    save("g9_tdac", d)
+
+
+def g10_steps():
+    """G10: stepping maths (denoising.py:4-59; util.py:21-74; ddim_control.py:198-254)."""
+    g = torch.Generator().manual_seed(1010)
+    d = {}
+    betas = torch.linspace(1e-4, 0.02, 1000)
+    tt = torch.tensor([0, 5, 500, 999])
+    d["betas"], d["compute_alpha/t"], d["compute_alpha/a"] = betas, tt, compute_alpha(betas, tt)
+    # one full generalized_steps run with a fixed linear "model"
+    seq = [int(s) for s in (np.linspace(0, np.sqrt(1000 * 0.8), 10) ** 2)]
+    x = torch.randn(4, 3, 8, 8, generator=g)
+    Wm = torch.randn(3, 3, generator=g) * 0.3
+
+    def model(xt, t):
+        return torch.einsum("oc,bchw->bohw", Wm, xt) + (t.view(-1, 1, 1, 1) / 1000.0)
+
+    xs, x0s = generalized_steps(x, seq, model, betas, eta=0.0)
+    d["gs/seq"], d["gs/x"], d["gs/Wm"] = np.array(seq), x, Wm
+    d["gs/xs"], d["gs/x0"] = torch.stack(xs), torch.stack(x0s)
+    # eta=1 with injected noise
+    noise = torch.randn(4, 3, 8, 8, generator=g)
+    orig = torch.randn_like
+    torch.randn_like = lambda t_, **k: noise
+    try:
+        xs1, _ = generalized_steps(x, seq[:3], model, betas, eta=1.0)
+    finally:
+        torch.randn_like = orig
+    d["gs/noise"], d["gs/xs_eta1"] = noise, torch.stack(xs1)
+    # LDM schedule helpers
+    b = make_beta_schedule("linear", 1000, linear_start=0.0015, linear_end=0.0195)
+    ac = np.cumprod(1.0 - b, axis=0)
+    d["ldm/betas"], d["ldm/alphas_cumprod"] = b, ac
+    for S in (20, 50):
+        ts = make_ddim_timesteps("uniform", S, 1000, verbose=False)
+        sig, al, alp = make_ddim_sampling_parameters(ac, ts, 0.0, verbose=False)
+        d["ldm/S%d/ts" % S], d["ldm/S%d/sigmas" % S] = ts, sig
+        d["ldm/S%d/alphas" % S], d["ldm/S%d/alphas_prev" % S] = al, alp
+    d["temb/t"] = torch.tensor([0., 1., 250., 999.])
+    d["temb/ldm64"] = timestep_embedding(d["temb/t"], 64)
+    from ddim.models.diffusion import get_timestep_embedding
+    d["temb/ddpm64"] = get_timestep_embedding(d["temb/t"], 64)
+    # p_sample_ddim through the real sampler with a stand-in LatentDiffusion (ddpm.py:895 contract)
+    from ldm.models.diffusion.ddim_control import DDIMSampler_control
+
+    class FakeLD:
+        def __init__(self):
+            self.num_timesteps = 1000
+            self.betas = torch.tensor(b, dtype=torch.float32)
+            self.alphas_cumprod = torch.tensor(ac, dtype=torch.float32)
+            self.alphas_cumprod_prev = torch.tensor(np.append(1.0, ac[:-1]), dtype=torch.float32)
+            self.device = torch.device("cpu")
+
+        def apply_model(self, x_, t_, c_):
+            return torch.einsum("oc,bchw->bohw", Wm, x_) * 0.5 + c_.mean(dim=(1, 2)).view(-1, 1, 1, 1) \
+                + t_.float().view(-1, 1, 1, 1) / 1000.0
+
+    ld = FakeLD()
+    s = DDIMSampler_control(ld)
+    s.make_schedule(20, ddim_eta=0.0, verbose=False)
+    c = torch.randn(4, 1, 16, generator=g)
+    uc = torch.randn(4, 1, 16, generator=g)
+    ts = torch.full((4,), int(s.ddim_timesteps[7]), dtype=torch.long)
+    xp, px0 = s.p_sample_ddim(x, c, ts, index=7, unconditional_guidance_scale=3.0, unconditional_conditioning=uc)
+    d["ps/c"], d["ps/uc"], d["ps/x_prev"], d["ps/pred_x0"], d["ps/t"] = c, uc, xp, px0, ts
+    idx = torch.tensor([0, 5, 11, 19])
+    tq = torch.tensor(s.ddim_timesteps[idx.numpy()]).long()
+    xp, px0 = s.p_sample_ddim(x, c, tq, index=idx, unconditional_guidance_scale=3.0, unconditional_conditioning=uc,
+                              quant_unet=True)
+    d["psq/index"], d["psq/t"], d["psq/x_prev"], d["psq/pred_x0"] = idx, tq, xp, px0
+    save("g10_steps", d)
+
+
+if __name__ == "__main__":
+    only = sys.argv[1:]
+    jobs = dict(g1=g1_weight_init, g2=g2_act_init, g3=g3_uaq_forward, g4=g4_adaround, g5=g5_loss,
+                g6=g6_quant_module, g7=g7_blocks, g8=g8_g12_recon, g9=g9_tdac, g10=g10_steps,
+                g13c=g13_cifar_unet, g13i=lambda: g13_ldm_unet("imagenet"), g13h=lambda: g13_ldm_unet("church"))
+    for k, fn in jobs.items():
+        if not only or k in only:
+            print("==", k)
+            fn()
