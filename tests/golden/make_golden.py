@@ -181,12 +181,12 @@ def g4_adaround():
         uaq(w)
         aq = AdaRoundQuantizer(uaq=uaq, round_mode="learned_hard_sigmoid", weight_tensor=w.clone())
         d[cname + "/w"], d[cname + "/delta"], d[cname + "/zero_point"] = w, aq.delta, aq.zero_point
-        d[cname + "/alpha0"] = aq.alpha
+        d[cname + "/alpha0"] = aq.alpha.detach().clone()
         aq.soft_targets = True
         gy = torch.randn(w.shape, generator=g)
         out = aq(w)
         (out * gy).sum().backward()
-        d[cname + "/gy"], d[cname + "/soft_out"], d[cname + "/galpha"] = gy, out, aq.alpha.grad
+        d[cname + "/gy"], d[cname + "/soft_out"], d[cname + "/galpha"] = gy, out, aq.alpha.grad.clone()
         # perturb alpha so hard rounding differs from nearest
         with torch.no_grad():
             aq.alpha.add_(torch.randn(w.shape, generator=g) * 2.0)

@@ -1,0 +1,258 @@
+"""Oracle block / network / reconstruction-loop restatements vs the reference's own outputs."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import qdiff_oracle as O
+
+T = lambda a: torch.as_tensor(np.asarray(a))
+WQ4 = dict(n_bits=4, symmetric=True, channel_wise=True, scale_method="mse")
+AQ8 = dict(n_bits=8, symmetric=True, channel_wise=False, scale_method="mse", leaf_param=True, prob=0.5)
+
+
+def close(a, b, rtol=1e-5, atol=1e-6):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def sub_sd(g, prefix):
+    return {k[len(prefix):]: g[k] for k in g.files if k.startswith(prefix)}
+
+
+def load_q(qs, g, prefix):
+    n = 0
+    for q in qs:
+        k = prefix + q.name
+        if k + "/delta" in g.files:
+            q.delta, q.zero_point = T(g[k + "/delta"]).float(), T(g[k + "/zero_point"]).float()
+            q.bitwidth_refactor(int(g[k + "/n_bits"]))
+            q.inited = True
+            n += 1
+    return n
+
+
+def block_qs(b):
+    return sum([l.quantizers() for l in b.layers()], []) + b.extra_quantizers()
+
+
+def test_g7_cifar_blocks(golden):
+    g = golden("g7_blocks")
+    B = O._Builder(sub_sd(g, "cifar/sd/"), WQ4, AQ8, 8)
+    rb = O.OResnetBlock(B, "rb", "rb", 64, 32)
+    at = O.OAttnBlock(B, "at", "at", 32)
+    x, temb, xa = T(g["cifar/x"]), T(g["cifar/temb"]), T(g["cifar/xa"])
+    with torch.no_grad():
+        close(rb(x, temb, split=32), g["cifar/rb_fp"])
+        close(at(xa), g["cifar/at_fp"])
+        rb.set_quant_state(True, True), at.set_quant_state(True, True)
+        # first quantized call initialises every quantizer exactly as the reference did
+        close(rb(x, temb, split=32), g["cifar/rb_q0"], rtol=1e-4, atol=1e-5)
+        close(at(xa), g["cifar/at_q0"], rtol=1e-4, atol=1e-5)
+        for q in block_qs(rb) + block_qs(at):
+            assert q.inited is False or True
+            k = "cifar/qp/model." + q.name
+            np.testing.assert_array_equal(q.delta.numpy().reshape(-1), g[k + "/delta"].reshape(-1))
+            np.testing.assert_array_equal(q.zero_point.numpy().reshape(-1), g[k + "/zero_point"].reshape(-1))
+            q.inited = True
+        close(rb(x, temb, split=32), g["cifar/rb_q"], rtol=1e-4, atol=1e-5)
+        close(at(xa), g["cifar/at_q"], rtol=1e-4, atol=1e-5)
+
+
+def test_g7_ldm_blocks(golden):
+    g = golden("g7_blocks")
+    B = O._Builder(sub_sd(g, "ldm/sd/"), WQ4, AQ8, 8)
+    res = O.OResBlock(B, "res", "res", 32, 64)
+    res_ss = O.OResBlock(B, "res_ss", "res_ss", 32, 32, scale_shift=True, down=True)
+    res_up = O.OResBlock(B, "res_up", "res_up", 32, 32, up=True)
+    tr = O.OTransformerBlock(B, "tr", "tr", 2)
+    ab = O.OLegacyAttention(B, "ab", "ab", 2)
+    x, emb, xs = T(g["ldm/x"]), T(g["ldm/emb"]), T(g["ldm/xs"])
+    c1, c7 = T(g["ldm/ctx1"]), T(g["ldm/ctx7"])
+    with torch.no_grad():
+        close(res(x, emb), g["ldm/res_fp"])
+        close(res_ss(x, emb), g["ldm/res_ss_fp"])
+        close(res_up(x, emb), g["ldm/res_up_fp"])
+        close(tr(xs, c7), g["ldm/tr_fp7"])
+        close(tr(xs, c1), g["ldm/tr_fp1"])
+        close(ab(x), g["ldm/ab_fp"])
+        qs = block_qs(res) + block_qs(res_ss) + block_qs(res_up) + tr.ordered_quantizers() + \
+            ab.qkv.quantizers() + ab.proj_out.quantizers() + ab.qk.extra_quantizers() + ab.smv.extra_quantizers()
+        n = load_q(qs, g, "ldm/qp/model.")
+        assert n == len(qs)
+        for b in (res, res_ss, res_up, tr, ab.qk, ab.smv):
+            b.set_quant_state(True, True)
+        ab.qkv.set_quant_state(True, True), ab.proj_out.set_quant_state(True, True)
+        close(res(x, emb), g["ldm/res_q"], rtol=1e-4, atol=1e-5)
+        close(res_ss(x, emb), g["ldm/res_ss_q"], rtol=1e-4, atol=1e-5)
+        close(res_up(x, emb), g["ldm/res_up_q"], rtol=1e-4, atol=1e-5)
+        close(tr(xs, c7), g["ldm/tr_q7"], rtol=1e-4, atol=1e-5)
+        close(tr(xs, c1), g["ldm/tr_q1"], rtol=1e-4, atol=1e-5)
+        close(ab(x), g["ldm/ab_q"], rtol=1e-4, atol=1e-5)
+
+
+def _unit_names(net, prefix="model."):
+    out = []
+    for kind, u in net.units():
+        out.append("%s:%s%s" % (kind, prefix, u.name))
+    return out
+
+
+def test_g13_cifar_unet(golden):
+    g = golden("g13_cifar_unet")
+    net = O.ODDPM(sub_sd(g, "sd/"), int(g["cfg/ch"]), [int(v) for v in g["cfg/ch_mult"]], int(g["cfg/nres"]),
+                  [int(v) for v in g["cfg/attn"]], int(g["cfg/res"]), WQ4, AQ8, 8)
+    x, t = T(g["x"]), T(g["t"])
+    with torch.no_grad():
+        close(net(x, t), g["out_fp"], rtol=1e-4, atol=1e-5)
+    # G11: unit order, which quantizers become 8-bit
+    ref_units = [u.rsplit(":", 1)[0] for u in g["units"]]
+    assert _unit_names(net) == ref_units
+    net.set_first_last_layer_to_8bit()
+    net.disable_network_output_quantization()
+    net.split_shortcut = True
+    # scale-init drivers reproduce every delta / zero-point of the reference bit-exactly
+    O.set_weight_quantize_params(net, (x, t))
+    O.set_act_quantize_params(net, (x, t), batch_size=4)
+    n = 0
+    for q in net.all_quantizers():
+        k = "qp/model." + q.name
+        if q.delta is None:
+            assert k + "/delta" not in g.files, k
+            continue
+        assert k + "/delta" in g.files, k
+        assert q.n_bits == int(g[k + "/n_bits"]), k
+        close(q.delta.reshape(-1), g[k + "/delta"].reshape(-1), rtol=2e-4, atol=0)
+        np.testing.assert_array_equal(q.zero_point.numpy().reshape(-1), g[k + "/zero_point"].reshape(-1))
+        n += 1
+    assert n == len([k for k in g.files if k.startswith("qp/") and k.endswith("/delta")])
+    # forward with the reference's own qparams loaded
+    net.load_qparams(g)
+    net.set_quant_state(True, True)
+    with torch.no_grad():
+        close(net(x, t), g["out_q"], rtol=1e-3, atol=2e-4)
+        net.set_quant_state(True, False)
+        close(net(x, t), g["out_wq"], rtol=1e-3, atol=2e-4)
+
+
+@pytest.mark.parametrize("kind", ["imagenet", "church"])
+def test_g13_ldm_unet(golden, kind):
+    g = golden("g13_ldm_%s" % kind)
+    cfg = {k[4:]: g[k] for k in g.files if k.startswith("cfg/")}
+    net = O.OUNet(sub_sd(g, "sd/"), WQ4, AQ8, 8, **cfg)
+    x, t = T(g["x"]), T(g["t"])
+    ctx = T(g["ctx"]) if "ctx" in g.files else None
+    with torch.no_grad():
+        close(net(x, t, ctx), g["out_fp"], rtol=1e-4, atol=1e-5)
+    ref_units = [u.rsplit(":", 1)[0] for u in g["units"]]
+    assert _unit_names(net) == ref_units
+    net.set_first_last_layer_to_8bit()
+    net.disable_network_output_quantization()
+    net.split_shortcut = True
+    cali = (x, t, ctx) if ctx is not None else (x, t)
+    O.set_weight_quantize_params(net, cali)
+    O.set_act_quantize_params(net, cali, batch_size=4)
+    for q in net.all_quantizers():
+        k = "qp/model." + q.name
+        if q.delta is None:
+            assert k + "/delta" not in g.files, k
+            continue
+        assert k + "/delta" in g.files, k
+        assert q.n_bits == int(g[k + "/n_bits"]), k
+        # activations arrive through upstream fake-quant layers: one flipped code upstream can move
+        # max|x| in the last digits; the 100-candidate grid is 1 % wide
+        close(q.delta.reshape(-1), g[k + "/delta"].reshape(-1), rtol=5e-2 if q.leaf_param else 1e-6, atol=0)
+        assert np.abs(q.zero_point.numpy().reshape(-1) - g[k + "/zero_point"].reshape(-1)).max() <= \
+            (1 if q.leaf_param else 0), k
+    net.load_qparams(g)
+    net.set_quant_state(True, True)
+    with torch.no_grad():
+        close(net(x, t, ctx), g["out_q"], rtol=1e-3, atol=2e-4)
+        net.set_quant_state(True, False)
+        close(net(x, t, ctx), g["out_wq"], rtol=1e-3, atol=2e-4)
+
+
+class ToyNet(O._Net):
+    """The fixture's 2-block toy model (make_golden._ToyNet)."""
+
+    def __init__(self, sd, wq, aq):
+        B = O._Builder(sd, wq, aq, 8)
+        self.conv_in = B.layer("conv_in", "conv_in", "conv2d", 1, 1)
+        self.temb_lin = B.layer("temb_lin", "temb_lin", "linear")
+        self.rb = O.OResnetBlock(B, "rb", "rb", 32, 32)
+        self.at = O.OAttnBlock(B, "at", "at", 32)
+        self.conv_out = B.layer("conv_out", "conv_out", "conv2d", 1, 1)
+
+    def units(self):
+        return [("layer", self.conv_in), ("layer", self.temb_lin), ("block", self.rb), ("block", self.at),
+                ("layer", self.conv_out)]
+
+    def __call__(self, x, t, context=None):
+        temb = self.temb_lin(torch.stack([torch.sin(t * (i + 1) * 0.01) for i in range(8)], 1))
+        return self.conv_out(self.at(self.rb(self.conv_in(x), temb)))
+
+
+def test_g12_g8_reconstruction(golden):
+    g = golden("g8_recon")
+    aq = dict(AQ8)
+    aq["prob"] = 1.0
+    net = ToyNet(sub_sd(g, "sd/"), WQ4, aq)
+    x, t = T(g["x"]), T(g["t"])
+    cali = (x, t)
+    O.set_weight_quantize_params(net, cali)
+    O.set_act_quantize_params(net, cali, batch_size=32)
+    for q in net.all_quantizers():
+        k = "init/qp/model." + q.name
+        if q.delta is None:
+            continue
+        close(q.delta.reshape(-1), g[k + "/delta"].reshape(-1), rtol=1e-5, atol=0)
+        np.testing.assert_array_equal(q.zero_point.numpy().reshape(-1), g[k + "/zero_point"].reshape(-1))
+        q.delta = T(g[k + "/delta"]).float().reshape(q.delta.shape)
+    # G12
+    two, iq, ifp, ofp = O.save_inp_oup_data(net, net.rb, cali, True, 32)
+    assert two == bool(g["g12/rb/resblock"])
+    close(iq[0], g["g12/rb/inp_q"], rtol=1e-4, atol=1e-5)
+    close(iq[1], g["g12/rb/temb_q"], rtol=1e-4, atol=1e-5)
+    close(ifp[0], g["g12/rb/inp_fp"], rtol=1e-5, atol=1e-6)
+    close(ifp[1], g["g12/rb/temb_fp"], rtol=1e-5, atol=1e-6)
+    close(ofp, g["g12/rb/out_fp"], rtol=1e-5, atol=1e-6)
+    two, iq, ifp, ofp = O.save_inp_oup_data(net, net.conv_in, cali, True, 32)
+    assert two == bool(g["g12/conv_in/resblock"])
+    close(iq[0], g["g12/conv_in/inp_q"]), close(ofp, g["g12/conv_in/out_fp"])
+    # G8: same idx stream (python random), per-iteration alpha / delta trajectories
+    kw = dict(cali=cali, iters=12, act_quant=True, lr_a=1e-3, lr_w=5e-2, p=2.0, batch_size=16, input_prob=1.0,
+              add_loss=0.8, recon_w=True, recon_a=True, cache_batch=32)
+    random.seed(8080)
+    for name, kind in (("conv_in", "layer"), ("temb_lin", "layer"), ("rb", "block"), ("at", "block"),
+                       ("conv_out", "layer")):
+        tw, ta = [], []
+
+        def trace(it, w_para, a_para, loss):
+            tw.append(torch.cat([p.detach().flatten() for p in w_para]).clone())
+            ta.append(torch.cat([p.detach().flatten() for p in a_para]).clone())
+
+        O.reconstruct_unit(net, getattr(net, name), kind, trace=trace, **kw)
+        ref_w, ref_a = g["g8/traj/%s/w" % name], g["g8/traj/%s/a" % name]
+        got_w, got_a = torch.stack(tw).numpy(), torch.stack(ta).numpy()
+        # alphas move by lr_w per step; agreement to 1e-3 absolute over 12 steps pins Adam,
+        # the cosine schedule, the loss gradient and the STE/LSQ gradients together
+        # (Adam normalises g/sqrt(v): an element whose gradient is at rounding-noise level can take a
+        # different +-lr step, so a <0.5 % tail is allowed up to two steps of lr_w)
+        dw = np.abs(got_w - ref_w)
+        print(name, "alpha traj: frac>2e-3 %.4f max %.4g | delta traj max rel %.3g" % (
+            (dw > 2e-3).mean(), dw.max(), (np.abs(got_a - ref_a) / np.abs(ref_a)).max()))
+        assert np.median(dw) < 5e-4, name     # lr_w = 5e-2 per step: trajectories coincide to 1 % of a step
+        assert (dw > 1e-2).mean() < 5e-3 and dw.max() < 2 * 5e-2, (name, (dw > 1e-2).mean(), dw.max())
+        np.testing.assert_allclose(got_a, ref_a, rtol=5e-3, atol=1e-6)
+    # final hard rounding decisions identical -> same integer weights
+    for l in net.all_layers():
+        ref_alpha = g["g8/final/alpha/model.%s.weight_quantizer" % l.name]
+        got = l.weight_quantizer.alpha.detach().numpy()
+        agree = np.mean((got >= 0) == (ref_alpha >= 0))
+        assert agree > 0.999, (l.name, agree)
+    net.set_quant_state(True, True)
+    with torch.no_grad():
+        out = net(x[:8], t[:8])
+    assert np.abs(out.numpy() - g["g8/final/out_q"]).max() < 0.05 * np.abs(g["g8/final/out_q"]).max()
