@@ -1,0 +1,62 @@
+// Internal helpers shared by the gfx950 kernels of libedadm.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define EDADM_EINVAL (-22)
+#define EDADM_EIO (-5)
+
+static inline int edadm_launch_status() { return hipGetLastError() == hipSuccess ? 0 : EDADM_EIO; }
+
+// memory-bound launches: cap the grid at 256 CUs x 8 blocks and grid-stride the rest
+static inline int edadm_grid(int64_t work_items, int block) {
+    int64_t g = (work_items + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > 2048) g = 2048;
+    return (int)g;
+}
+#define EDADM_RED_BLOCKS 1024  // partial-sum slots used by two-stage reductions
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// block-wide sum for 256-thread blocks (4 waves); result valid in thread 0
+__device__ __forceinline__ float block_sum_256(float v, float* sm4) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sm4[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x == 0) r = sm4[0] + sm4[1] + sm4[2] + sm4[3];
+    __syncthreads();
+    return r;
+}
+
+// counter RNG: uniform in [0,1) from (seed, index) — splitmix64 finaliser
+__device__ __forceinline__ float rng_uniform(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+// x * sigmoid(x) in the reference's operation order (ddim/models/diffusion.py:27-29)
+__device__ __forceinline__ float silu_f(float x) { return x * (1.0f / (1.0f + expf(-x))); }

@@ -1,0 +1,474 @@
+// HBM-bound elementwise / reduction kernels of the calibration loop (K1, K2, K3, K7, K8, K9, K10).
+// One pass over each operand, float4 accesses where the layout allows, two-stage deterministic
+// reductions (per-block partials in a caller workspace, then one block in double).
+#include "common.h"
+#include "../../include/edadm.h"
+
+extern "C" int edadm_abi_version(void) { return 1; }
+extern "C" int64_t edadm_reduce_ws_floats(void) { return 4 * EDADM_RED_BLOCKS + 256; }
+
+// ------------------------------------------------------------------------------------------ K1
+__device__ __forceinline__ float fq_one(float x, float d, float z, float qmax, float* code) {
+    float c = fminf(fmaxf(rintf(x / d) + z, 0.f), qmax);
+    if (code) *code = c;
+    return (c - z) * d;
+}
+
+__global__ void __launch_bounds__(256) k_fq_fwd(const float* __restrict__ x, float* __restrict__ out,
+                                                float* __restrict__ codes, int64_t n,
+                                                const float* __restrict__ delta, const float* __restrict__ zp,
+                                                int64_t nq, int64_t inner, float qmax,
+                                                const float* __restrict__ u, float prob, uint64_t seed) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const bool vec = ((n & 3) == 0) && (nq == 1 || (inner & 3) == 0);
+    const bool mix = prob < 1.0f;
+    if (vec) {
+        const int64_t n4 = n >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+            float4 v = reinterpret_cast<const float4*>(x)[i];
+            const int64_t q = nq == 1 ? 0 : ((i * 4) / inner) % nq;
+            const float d = delta[q], z = zp[q];
+            float c[4];
+            float4 o;
+            o.x = fq_one(v.x, d, z, qmax, &c[0]);
+            o.y = fq_one(v.y, d, z, qmax, &c[1]);
+            o.z = fq_one(v.z, d, z, qmax, &c[2]);
+            o.w = fq_one(v.w, d, z, qmax, &c[3]);
+            if (mix) {
+                float r[4];
+                if (u) {
+                    float4 uu = reinterpret_cast<const float4*>(u)[i];
+                    r[0] = uu.x; r[1] = uu.y; r[2] = uu.z; r[3] = uu.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) r[j] = rng_uniform(seed, (uint64_t)(i * 4 + j));
+                }
+                o.x = r[0] < prob ? o.x : v.x;
+                o.y = r[1] < prob ? o.y : v.y;
+                o.z = r[2] < prob ? o.z : v.z;
+                o.w = r[3] < prob ? o.w : v.w;
+            }
+            reinterpret_cast<float4*>(out)[i] = o;
+            if (codes) reinterpret_cast<float4*>(codes)[i] = make_float4(c[0], c[1], c[2], c[3]);
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+            const int64_t q = nq == 1 ? 0 : (i / inner) % nq;
+            float c;
+            const float v = x[i];
+            float o = fq_one(v, delta[q], zp[q], qmax, &c);
+            if (mix) {
+                const float r = u ? u[i] : rng_uniform(seed, (uint64_t)i);
+                o = r < prob ? o : v;
+            }
+            out[i] = o;
+            if (codes) codes[i] = c;
+        }
+    }
+}
+
+extern "C" int edadm_fake_quant_fwd(const float* x, float* out, float* codes, int64_t n, const float* delta,
+                                    const float* zp, int64_t nq, int64_t inner, float qmax, const float* u,
+                                    float prob, uint64_t seed, void* stream) {
+    if (!x || !out || !delta || !zp || n < 0 || nq < 1 || inner < 1) return EDADM_EINVAL;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_fq_fwd, dim3(edadm_grid((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, out,
+                       codes, n, delta, zp, nq, inner, qmax, u, prob, seed);
+    return edadm_launch_status();
+}
+
+// final stage of every two-stage sum: `cols` independent sums over `rows` partials, in double
+__global__ void __launch_bounds__(256) k_reduce_final(const float* __restrict__ part, int rows, int cols,
+                                                      float* __restrict__ out, float mul) {
+    __shared__ double sm[4];
+    for (int c = 0; c < cols; ++c) {
+        double s = 0.0;
+        for (int r = threadIdx.x; r < rows; r += 256) s += (double)part[(int64_t)r * cols + c];
+        s = wave_sum_d(s);
+        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) out[c] = (float)((sm[0] + sm[1] + sm[2] + sm[3]) * (double)mul);
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) k_fq_bwd(const float* __restrict__ gy, const float* __restrict__ x,
+                                                float* __restrict__ gx, float* __restrict__ part, int64_t n,
+                                                const float* __restrict__ delta, const float* __restrict__ zp,
+                                                float qmax, const float* __restrict__ u, float prob,
+                                                uint64_t seed) {
+    __shared__ float sm[4];
+    const float d = delta[0], z = zp[0];
+    const bool mix = prob < 1.0f;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float g = gy[i], v = x[i];
+        const float xs = v / d;
+        const float xi = rintf(xs) + z;
+        const float inr = (xi >= 0.f && xi <= qmax) ? 1.f : 0.f;
+        const float c = fminf(fmaxf(xi, 0.f), qmax);
+        const float gq = g * d * inr;
+        float gd = g * (c - z) - gq * (xs / d);
+        float gxi = gq / d;
+        if (mix) {
+            const float r = u ? u[i] : rng_uniform(seed, (uint64_t)i);
+            if (!(r < prob)) { gxi = g; gd = 0.f; }
+        }
+        if (gx) gx[i] = gxi;
+        acc += gd;
+    }
+    const float s = block_sum_256(acc, sm);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+extern "C" int edadm_fake_quant_bwd(const float* gy, const float* x, float* gx, float* gdelta, int64_t n,
+                                    const float* delta, const float* zp, float qmax, const float* u, float prob,
+                                    uint64_t seed, float* ws, void* stream) {
+    if (!gy || !x || !gdelta || !delta || !zp || !ws || n <= 0) return EDADM_EINVAL;
+    int g = edadm_grid(n, 256);
+    if (g > EDADM_RED_BLOCKS) g = EDADM_RED_BLOCKS;
+    hipLaunchKernelGGL(k_fq_bwd, dim3(g), dim3(256), 0, (hipStream_t)stream, gy, x, gx, ws, n, delta, zp, qmax, u,
+                       prob, seed);
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, (hipStream_t)stream, ws, g, 1, gdelta, 1.0f);
+    return edadm_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------ K2
+#define AR_GAMMA (-0.1f)
+#define AR_ZETA (1.1f)
+
+__global__ void __launch_bounds__(256) k_ar_init(const float* __restrict__ w, int64_t ldw,
+                                                 float* __restrict__ alpha, int64_t rows, int64_t cols,
+                                                 const float* __restrict__ delta) {
+    const int64_t n = rows * cols, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t r = i / cols, c = i - r * cols;
+        const float d = delta[r];
+        const float q = w[r * ldw + c] / d;
+        const float rest = q - floorf(q);
+        alpha[i] = -logf((AR_ZETA - AR_GAMMA) / (rest - AR_GAMMA) - 1.0f);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_ar_fwd(const float* __restrict__ w, int64_t ldw,
+                                                const float* __restrict__ alpha, float* __restrict__ out,
+                                                int64_t ldo, int64_t rows, int64_t cols,
+                                                const float* __restrict__ delta, const float* __restrict__ zp,
+                                                float qmax, int soft) {
+    const int64_t n = rows * cols, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t r = i / cols, c = i - r * cols;
+        const float d = delta[r], z = zp[r];
+        const float a = alpha[i];
+        float h;
+        if (soft) {
+            const float sg = 1.0f / (1.0f + expf(-a));
+            h = fminf(fmaxf(sg * (AR_ZETA - AR_GAMMA) + AR_GAMMA, 0.f), 1.f);
+        } else {
+            h = a >= 0.f ? 1.f : 0.f;
+        }
+        const float xi = floorf(w[r * ldw + c] / d) + h;
+        const float q = fminf(fmaxf(xi + z, 0.f), qmax);
+        out[r * ldo + c] = (q - z) * d;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_ar_bwd(const float* __restrict__ gy, int64_t ldg,
+                                                const float* __restrict__ w, int64_t ldw,
+                                                const float* __restrict__ alpha, float* __restrict__ galpha,
+                                                int64_t rows, int64_t cols, const float* __restrict__ delta,
+                                                const float* __restrict__ zp, float qmax) {
+    const int64_t n = rows * cols, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t r = i / cols, c = i - r * cols;
+        const float d = delta[r], z = zp[r];
+        const float a = alpha[i];
+        const float sg = 1.0f / (1.0f + expf(-a));
+        const float s = sg * (AR_ZETA - AR_GAMMA) + AR_GAMMA;
+        const float h = fminf(fmaxf(s, 0.f), 1.f);
+        const float v = floorf(w[r * ldw + c] / d) + h + z;
+        const float inr = (v >= 0.f && v <= qmax) ? 1.f : 0.f;
+        const float ins = (s >= 0.f && s <= 1.f) ? 1.f : 0.f;
+        galpha[i] = gy[r * ldg + c] * d * inr * ins * (AR_ZETA - AR_GAMMA) * sg * (1.0f - sg);
+    }
+}
+
+extern "C" int edadm_adaround_init_alpha(const float* w, int64_t ldw, float* alpha, int64_t rows, int64_t cols,
+                                         const float* delta, void* stream) {
+    if (!w || !alpha || !delta || rows <= 0 || cols <= 0 || ldw < cols) return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_ar_init, dim3(edadm_grid(rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, w, ldw,
+                       alpha, rows, cols, delta);
+    return edadm_launch_status();
+}
+extern "C" int edadm_adaround_fwd(const float* w, int64_t ldw, const float* alpha, float* out, int64_t ldo,
+                                  int64_t rows, int64_t cols, const float* delta, const float* zp, float qmax,
+                                  int soft, void* stream) {
+    if (!w || !alpha || !out || !delta || !zp || rows <= 0 || cols <= 0 || ldw < cols || ldo < cols)
+        return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_ar_fwd, dim3(edadm_grid(rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, w, ldw,
+                       alpha, out, ldo, rows, cols, delta, zp, qmax, soft);
+    return edadm_launch_status();
+}
+extern "C" int edadm_adaround_bwd(const float* gy, int64_t ldg, const float* w, int64_t ldw, const float* alpha,
+                                  float* galpha, int64_t rows, int64_t cols, const float* delta, const float* zp,
+                                  float qmax, void* stream) {
+    if (!gy || !w || !alpha || !galpha || !delta || !zp || rows <= 0 || cols <= 0) return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_ar_bwd, dim3(edadm_grid(rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, gy, ldg, w,
+                       ldw, alpha, galpha, rows, cols, delta, zp, qmax);
+    return edadm_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------ K3
+// One pass over x, all candidates kept in registers.  |e|^2.4 through powf: the argmin over
+// candidates must land on the reference's index, so no fast-math pow here.
+#define MSE_MAXC 128
+template <int NC>
+__device__ __forceinline__ void mse_accum(float v, const float* sc, const float* lo, const float* hi, float* acc) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        float q = rintf(v / sc[c]);
+        q = fminf(fmaxf(q, lo[c]), hi[c]);
+        acc[c] += powf(fabsf(q * sc[c] - v), 2.4f);
+    }
+}
+
+// per-tensor: candidates processed in chunks of 16 to bound registers; grid-stride over x
+__global__ void __launch_bounds__(256) k_mse_tensor(const float* __restrict__ x, int64_t n,
+                                                    const float* __restrict__ scale,
+                                                    const float* __restrict__ zp, int nc, float qmax,
+                                                    float* __restrict__ part) {
+    __shared__ float s_sc[MSE_MAXC], s_lo[MSE_MAXC], s_hi[MSE_MAXC];
+    __shared__ float sm[4];
+    for (int c = threadIdx.x; c < nc; c += 256) {
+        s_sc[c] = scale[c];
+        s_lo[c] = -zp[c];
+        s_hi[c] = qmax - zp[c];
+    }
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int c0 = 0; c0 < nc; c0 += 16) {
+        float acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+        const int m = nc - c0 < 16 ? nc - c0 : 16;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+            const float v = x[i];
+            if (m == 16) {
+                mse_accum<16>(v, s_sc + c0, s_lo + c0, s_hi + c0, acc);
+            } else {
+                for (int j = 0; j < m; ++j) {
+                    float q = fminf(fmaxf(rintf(v / s_sc[c0 + j]), s_lo[c0 + j]), s_hi[c0 + j]);
+                    acc[j] += powf(fabsf(q * s_sc[c0 + j] - v), 2.4f);
+                }
+            }
+        }
+        for (int j = 0; j < m; ++j) {
+            const float s = block_sum_256(acc[j], sm);
+            if (threadIdx.x == 0) part[(int64_t)blockIdx.x * nc + c0 + j] = s;
+        }
+    }
+}
+
+extern "C" int edadm_mse_scores_tensor(const float* x, int64_t n, const float* scale, const float* zp, int nc,
+                                       float qmax, float* score, float* ws, void* stream) {
+    if (!x || !scale || !zp || !score || !ws || n <= 0 || nc < 1 || nc > MSE_MAXC) return EDADM_EINVAL;
+    int g = edadm_grid(n, 256);
+    const int maxg = (int)(4 * EDADM_RED_BLOCKS / nc);
+    if (g > maxg) g = maxg;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(k_mse_tensor, dim3(g), dim3(256), 0, (hipStream_t)stream, x, n, scale, zp, nc, qmax, ws);
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, (hipStream_t)stream, ws, g, nc, score,
+                       (float)(1.0 / (double)n));
+    return edadm_launch_status();
+}
+
+// per-channel: one block per (row, candidate chunk); scores laid out [nc][rows]
+__global__ void __launch_bounds__(256) k_mse_channel(const float* __restrict__ x, int64_t rows, int64_t cols,
+                                                     const float* __restrict__ scale,
+                                                     const float* __restrict__ zp, int nc, float qmax,
+                                                     float* __restrict__ score) {
+    __shared__ float sm[4];
+    const int64_t r = blockIdx.x;
+    const int c0 = blockIdx.y * 16;
+    const int m = nc - c0 < 16 ? nc - c0 : 16;
+    float sc[16], lo[16], hi[16], acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int c = c0 + (j < m ? j : 0);
+        sc[j] = scale[(int64_t)c * rows + r];
+        const float z = zp[(int64_t)c * rows + r];
+        lo[j] = -z;
+        hi[j] = qmax - z;
+        acc[j] = 0.f;
+    }
+    for (int64_t i = threadIdx.x; i < cols; i += 256) mse_accum<16>(x[r * cols + i], sc, lo, hi, acc);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const float s = block_sum_256(acc[j], sm);
+        if (threadIdx.x == 0 && j < m) score[(int64_t)(c0 + j) * rows + r] = s / (float)cols;
+    }
+}
+
+extern "C" int edadm_mse_scores_channel(const float* x, int64_t rows, int64_t cols, const float* scale,
+                                        const float* zp, int nc, float qmax, float* score, void* stream) {
+    if (!x || !scale || !zp || !score || rows <= 0 || cols <= 0 || nc < 1 || nc > 4096) return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_mse_channel, dim3((unsigned)rows, (unsigned)((nc + 15) / 16)), dim3(256), 0,
+                       (hipStream_t)stream, x, rows, cols, scale, zp, nc, qmax, score);
+    return edadm_launch_status();
+}
+
+__global__ void __launch_bounds__(256) k_minmax(const float* __restrict__ x, int64_t n, float* __restrict__ part) {
+    __shared__ float smn[4], smx[4];
+    float mn = INFINITY, mx = -INFINITY;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float v = x[i];
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+    }
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+        part[2 * blockIdx.x + 1] = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+    }
+}
+__global__ void __launch_bounds__(256) k_minmax_final(const float* __restrict__ part, int g, float* out2) {
+    __shared__ float smn[4], smx[4];
+    float mn = INFINITY, mx = -INFINITY;
+    for (int i = threadIdx.x; i < g; i += 256) { mn = fminf(mn, part[2 * i]); mx = fmaxf(mx, part[2 * i + 1]); }
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out2[0] = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+        out2[1] = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+    }
+}
+extern "C" int edadm_minmax(const float* x, int64_t n, float* out2, float* ws, void* stream) {
+    if (!x || !out2 || !ws || n <= 0) return EDADM_EINVAL;
+    int g = edadm_grid(n, 256);
+    if (g > EDADM_RED_BLOCKS) g = EDADM_RED_BLOCKS;
+    hipLaunchKernelGGL(k_minmax, dim3(g), dim3(256), 0, (hipStream_t)stream, x, n, ws);
+    hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(256), 0, (hipStream_t)stream, ws, g, out2);
+    return edadm_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------ K7
+__global__ void __launch_bounds__(256) k_lp_fwd(const float* __restrict__ p, const float* __restrict__ t, int64_t n,
+                                                float* __restrict__ part) {
+    __shared__ float sm[4];
+    float acc = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if ((n & 3) == 0) {
+        const int64_t n4 = n >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+            const float4 a = reinterpret_cast<const float4*>(p)[i], b = reinterpret_cast<const float4*>(t)[i];
+            const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
+            acc += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+            const float d = p[i] - t[i];
+            acc += d * d;
+        }
+    }
+    const float s = block_sum_256(acc, sm);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ void __launch_bounds__(256) k_lp_bwd(const float* __restrict__ p, const float* __restrict__ t, int64_t n,
+                                                float inv_denom, const float* __restrict__ gscale,
+                                                float* __restrict__ gp) {
+    const float k = 2.0f * inv_denom * gscale[0];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) gp[i] = k * (p[i] - t[i]);
+}
+extern "C" int edadm_lp_loss_fwd(const float* pred, const float* tgt, int64_t n, float inv_denom, float* loss,
+                                 float* ws, void* stream) {
+    if (!pred || !tgt || !loss || !ws || n <= 0) return EDADM_EINVAL;
+    int g = edadm_grid((n + 3) / 4, 256);
+    if (g > EDADM_RED_BLOCKS) g = EDADM_RED_BLOCKS;
+    hipLaunchKernelGGL(k_lp_fwd, dim3(g), dim3(256), 0, (hipStream_t)stream, pred, tgt, n, ws);
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, (hipStream_t)stream, ws, g, 1, loss, inv_denom);
+    return edadm_launch_status();
+}
+extern "C" int edadm_lp_loss_bwd(const float* pred, const float* tgt, int64_t n, float inv_denom,
+                                 const float* gscale, float* gpred, void* stream) {
+    if (!pred || !tgt || !gscale || !gpred || n <= 0) return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_lp_bwd, dim3(edadm_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, pred, tgt, n,
+                       inv_denom, gscale, gpred);
+    return edadm_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------ K8
+__global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float* __restrict__ g,
+                                              float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                              const float* __restrict__ hyper) {
+    const float step = hyper[0], bc2s = hyper[1], b1 = hyper[2], b2 = hyper[3];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float gi = g[i];
+        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);          // exp_avg.lerp_(grad, 1-beta1)
+        const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;          // mul_(beta2).addcmul_(g, g, 1-beta2)
+        const float denom = sqrtf(vi) / bc2s + 1e-8f;
+        p[i] = p[i] - step * (mi / denom);
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+extern "C" int edadm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
+                               void* stream) {
+    if (!p || !g || !m || !v || !hyper || n <= 0) return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_adam, dim3(edadm_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, hyper);
+    return edadm_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------ K10
+__global__ void __launch_bounds__(256) k_mix(const float* __restrict__ a, const float* __restrict__ b,
+                                             float* __restrict__ out, int64_t n, const float* __restrict__ u,
+                                             float prob, uint64_t seed) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float r = u ? u[i] : rng_uniform(seed, (uint64_t)i);
+        out[i] = r < prob ? a[i] : b[i];
+    }
+}
+extern "C" int edadm_mix_where(const float* a, const float* b, float* out, int64_t n, const float* u, float prob,
+                               uint64_t seed, void* stream) {
+    if (!a || !b || !out || n <= 0) return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_mix, dim3(edadm_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n, u, prob,
+                       seed);
+    return edadm_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------ K9
+// coef[b] = {sqrt(1-a_t), sqrt(a_t), sqrt(a_prev), sqrt(1-a_prev-sigma^2), sigma}: 5 floats per sample.
+__global__ void __launch_bounds__(256) k_ddim(const float* __restrict__ x, const float* __restrict__ ec,
+                                              const float* __restrict__ eu, float s, const float* __restrict__ coef,
+                                              const float* __restrict__ noise, float* __restrict__ xp,
+                                              float* __restrict__ px0, int64_t B, int64_t chw) {
+    const int64_t n = B * chw, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t b = i / chw;
+        const float* c = coef + 5 * b;
+        float e = ec[i];
+        if (eu) { const float u_ = eu[i]; e = u_ + s * (e - u_); }
+        const float p0 = (x[i] - c[0] * e) / c[1];
+        float r = c[2] * p0 + c[3] * e;
+        if (noise) r += c[4] * noise[i];
+        xp[i] = r;
+        if (px0) px0[i] = p0;
+    }
+}
+extern "C" int edadm_ddim_step(const float* x, const float* e_cond, const float* e_uncond, float cfg_scale,
+                               const float* coef, const float* noise, float* x_prev, float* pred_x0, int64_t B,
+                               int64_t chw, void* stream) {
+    if (!x || !e_cond || !coef || !x_prev || B <= 0 || chw <= 0) return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_ddim, dim3(edadm_grid(B * chw, 256)), dim3(256), 0, (hipStream_t)stream, x, e_cond,
+                       e_uncond, cfg_scale, coef, noise, x_prev, pred_x0, B, chw);
+    return edadm_launch_status();
+}

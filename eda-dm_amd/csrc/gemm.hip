@@ -1,0 +1,256 @@
+// K4 / K6 contractions on the gfx950 matrix cores.
+//
+// One kernel template serves the quantised conv / linear layers (int8 operands,
+// v_mfma_i32_32x32x32_i8, implicit-GEMM gather over NHWC activations) and the attention
+// products (integer-valued f16 operands, v_mfma_f32_32x32x16_f16; exact in fp32).
+//
+// Tile: 256 threads = 4 waves as 2(M) x 2(N); each wave owns TM x TN MFMA tiles of 32x32, so a
+// workgroup computes (64*TM) x (64*TN) outputs.  K advances 64 BYTES per step (64 int8 / 32 f16):
+// every row of a tile is one 64-byte segment = four 16-byte chunks; chunk c of row r lives at
+// LDS chunk c ^ ((r >> 2) & 3), which makes the ds_read_b128 fragment reads (lane -> row lane&31,
+// chunk 2*ks + (lane>>5)) hit 16 distinct 16-byte slots per 16-lane group (conflict-free).
+// Global -> register -> LDS staging with the next tile's loads issued before the current tile's
+// MFMAs (double-buffered LDS, one barrier per K-step).  A and B fragments use the same
+// (lane, byte) -> k map, so the dot product is independent of the hardware's k numbering.
+#include "common.h"
+#include "../../include/edadm.h"
+#include <hip/hip_fp16.h>
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+
+struct ConvGeom {
+    int mode, B, H, W, Cin, Ho, Wo, KH, KW, stride, pad0, ups, padval, r0, r1, r2;
+};
+
+template <bool I8>
+struct Acc;
+template <>
+struct Acc<true> { typedef v16i type; };
+template <>
+struct Acc<false> { typedef v16f type; };
+
+template <bool I8, int TM, int TN>
+__global__ void __launch_bounds__(256)
+k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const uint8_t* __restrict__ Bm,
+          int64_t ldb_b, int64_t strideB_b, int64_t M, int64_t N, int64_t Kb, ConvGeom g,
+          const float* __restrict__ scale, const float* __restrict__ bias, const float* __restrict__ rowadd,
+          int64_t rows_per_batch, const float* __restrict__ residual, int64_t ldr, float* __restrict__ out,
+          int64_t ldo, int64_t strideC, float alpha) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int NA = BM / 64, NB = BN / 64;   // 16-byte chunks staged per thread
+    __shared__ __attribute__((aligned(16))) uint8_t smem[2 * (BM + BN) * 64];
+    uint8_t* As = smem;
+    uint8_t* Bs = smem + 2 * BM * 64;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+    A += (int64_t)blockIdx.z * strideA_b;
+    Bm += (int64_t)blockIdx.z * strideB_b;
+    out += (int64_t)blockIdx.z * strideC;
+
+    // ---- per-thread staging coordinates
+    const int sc = tid & 3, sr = tid >> 2;      // chunk, row (+64*i)
+    int64_t a_base[NA];                          // dense: byte offset of the row; conv: packed (b,y,x)
+    int a_y[NA], a_x[NA];
+    bool a_ok[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int64_t m = m0 + sr + 64 * i;
+        a_ok[i] = m < M;
+        if (g.mode == 0) {
+            a_base[i] = m * lda_b;
+            a_y[i] = a_x[i] = 0;
+        } else {
+            const int64_t hw = (int64_t)g.Ho * g.Wo;
+            const int64_t b = m / hw, r = m - b * hw;
+            a_y[i] = (int)(r / g.Wo);
+            a_x[i] = (int)(r - (int64_t)a_y[i] * g.Wo);
+            a_base[i] = b * (int64_t)g.H * g.W;
+        }
+    }
+    const uint32_t padw = (uint32_t)(uint8_t)g.padval * 0x01010101u;
+
+    uint4 ra[NA], rb[NB];
+    auto load_tiles = [&](int64_t kb) {  // kb = byte offset along K
+        if (g.mode == 0) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int64_t off = kb + sc * 16;
+                ra[i] = (a_ok[i] && off < Kb) ? *reinterpret_cast<const uint4*>(A + a_base[i] + off)
+                                              : make_uint4(0, 0, 0, 0);
+            }
+        } else {
+            const int tap = (int)(kb / g.Cin);
+            const int ci0 = (int)(kb - (int64_t)tap * g.Cin);
+            const int ky = tap / g.KW, kx = tap - ky * g.KW;
+            const int Hl = g.ups ? 2 * g.H : g.H, Wl = g.ups ? 2 * g.W : g.W;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                int iy = a_y[i] * g.stride + ky - g.pad0, ix = a_x[i] * g.stride + kx - g.pad0;
+                const bool in = a_ok[i] && iy >= 0 && iy < Hl && ix >= 0 && ix < Wl;
+                if (g.ups) { iy >>= 1; ix >>= 1; }
+                ra[i] = in ? *reinterpret_cast<const uint4*>(
+                                 A + ((a_base[i] + (int64_t)iy * g.W + ix) * g.Cin + ci0 + sc * 16))
+                           : (a_ok[i] ? make_uint4(padw, padw, padw, padw) : make_uint4(0, 0, 0, 0));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int64_t n = n0 + sr + 64 * i, off = kb + sc * 16;
+            rb[i] = (n < N && off < Kb) ? *reinterpret_cast<const uint4*>(Bm + n * ldb_b + off)
+                                        : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int r = sr + 64 * i;
+            *reinterpret_cast<uint4*>(As + ((buf * BM + r) * 4 + (sc ^ ((r >> 2) & 3))) * 16) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int r = sr + 64 * i;
+            *reinterpret_cast<uint4*>(Bs + ((buf * BN + r) * 4 + (sc ^ ((r >> 2) & 3))) * 16) = rb[i];
+        }
+    };
+
+    typename Acc<I8>::type acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+
+    const int64_t nk = (Kb + 63) / 64;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    const int fr = lane & 31, fh = lane >> 5;
+    for (int64_t kt = 0; kt < nk; ++kt) {
+        const int cur = (int)(kt & 1);
+        if (kt + 1 < nk) load_tiles((kt + 1) * 64);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int c = 2 * ks + fh;
+            uint4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int r = wm * (TM * 32) + i * 32 + fr;
+                fa[i] = *reinterpret_cast<const uint4*>(As + ((cur * BM + r) * 4 + (c ^ ((r >> 2) & 3))) * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int r = wn * (TN * 32) + j * 32 + fr;
+                fb[j] = *reinterpret_cast<const uint4*>(Bs + ((cur * BN + r) * 4 + (c ^ ((r >> 2) & 3))) * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (I8) {
+                        acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(
+                            *reinterpret_cast<v4i*>(&fa[i]), *reinterpret_cast<v4i*>(&fb[j]), acc[i][j], 0, 0, 0);
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                            *reinterpret_cast<v8h*>(&fa[i]), *reinterpret_cast<v8h*>(&fb[j]), acc[i][j], 0, 0, 0);
+                    }
+                }
+        }
+        if (kt + 1 < nk) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int64_t col = n0 + wn * (TN * 32) + j * 32 + fr;
+        if (col >= N) continue;
+        const float s = scale ? scale[col] : alpha;
+        const float bs = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (row >= M) continue;
+                float v = (float)acc[i][j][r] * s + bs;
+                if (rowadd) v += rowadd[(row / rows_per_batch) * N + col];
+                if (residual) v += residual[row * ldr + col];
+                out[row * ldo + col] = v;
+            }
+        }
+    }
+}
+
+template <bool I8>
+static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm, int64_t ldb_b, int64_t sB,
+                       int64_t M, int64_t N, int64_t Kb, const ConvGeom& g, const float* scale, const float* bias,
+                       const float* rowadd, int64_t rpb, const float* residual, int64_t ldr, float* out, int64_t ldo,
+                       int64_t sC, int64_t batch, float alpha, hipStream_t st) {
+    // tile choice: widest N tile that divides N well (192 for the 192-multiples of LDM-4, else 128, 64)
+    int tn = 2;
+    if (N % 192 == 0) tn = 3;
+    else if (N <= 64) tn = 1;
+    int tm = 2;
+    if (M <= 64) tm = 1;
+    const dim3 blk(256);
+#define EDADM_GEMM_CASE(TM_, TN_)                                                                              \
+    if (tm == TM_ && tn == TN_) {                                                                              \
+        const dim3 grid((unsigned)((N + 64 * TN_ - 1) / (64 * TN_)), (unsigned)((M + 64 * TM_ - 1) / (64 * TM_)), \
+                        (unsigned)batch);                                                                      \
+        hipLaunchKernelGGL((k_gemm_nt<I8, TM_, TN_>), grid, blk, 0, st, (const uint8_t*)A, lda_b, sA,          \
+                           (const uint8_t*)Bm, ldb_b, sB, M, N, Kb, g, scale, bias, rowadd, rpb, residual, ldr, \
+                           out, ldo, sC, alpha);                                                               \
+        return edadm_launch_status();                                                                          \
+    }
+    EDADM_GEMM_CASE(2, 3)
+    EDADM_GEMM_CASE(2, 2)
+    EDADM_GEMM_CASE(2, 1)
+    EDADM_GEMM_CASE(1, 3)
+    EDADM_GEMM_CASE(1, 2)
+    EDADM_GEMM_CASE(1, 1)
+#undef EDADM_GEMM_CASE
+    return EDADM_EINVAL;
+}
+
+extern "C" int edadm_qgemm_i8(const int8_t* A, int64_t lda, const int8_t* Wt, int64_t ldw, int64_t M, int64_t N,
+                              int64_t K, const int32_t* geom, const float* scale, const float* bias,
+                              const float* rowadd, int64_t rows_per_batch, const float* residual, int64_t ldr,
+                              float* out, int64_t ldo, void* stream) {
+    if (!A || !Wt || !out || !scale || M <= 0 || N <= 0 || K <= 0 || (K & 15) || (ldw & 15)) return EDADM_EINVAL;
+    if (((uintptr_t)A & 15) || ((uintptr_t)Wt & 15)) return EDADM_EINVAL;
+    ConvGeom g;
+    if (geom) {
+        const int32_t* p = geom;
+        g = ConvGeom{p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[9], p[10], p[11], p[12], 0, 0, 0};
+    } else {
+        g = ConvGeom{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    if (g.mode == 0) {
+        if (lda & 15) return EDADM_EINVAL;
+    } else {
+        if (g.mode != 1 || (g.Cin & 63) || (int64_t)g.KH * g.KW * g.Cin != K || g.stride < 1 ||
+            (int64_t)g.B * g.Ho * g.Wo != M)
+            return EDADM_EINVAL;
+    }
+    if (rowadd && rows_per_batch <= 0) return EDADM_EINVAL;
+    return launch_gemm<true>(A, lda, 0, Wt, ldw, 0, M, N, K, g, scale, bias, rowadd, rows_per_batch, residual, ldr,
+                             out, ldo, 0, 1, 1.0f, (hipStream_t)stream);
+}
+
+extern "C" int edadm_gemm_f16_nt(const void* A, int64_t lda, int64_t strideA, const void* Bm, int64_t ldb,
+                                 int64_t strideB, float* C, int64_t ldc, int64_t strideC, int64_t batch, int64_t M,
+                                 int64_t N, int64_t K, float alpha, void* stream) {
+    if (!A || !Bm || !C || batch <= 0 || M <= 0 || N <= 0 || K <= 0 || (K & 7) || (lda & 7) || (ldb & 7) ||
+        (strideA & 7) || (strideB & 7))
+        return EDADM_EINVAL;
+    if (((uintptr_t)A & 15) || ((uintptr_t)Bm & 15)) return EDADM_EINVAL;
+    ConvGeom g{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    return launch_gemm<false>(A, lda * 2, strideA * 2, Bm, ldb * 2, strideB * 2, M, N, K * 2, g, nullptr, nullptr,
+                              nullptr, 1, nullptr, 0, C, ldc, strideC, batch, alpha, (hipStream_t)stream);
+}

@@ -1,0 +1,521 @@
+// Producers of MFMA operands for the quantised sampling path: activation quantisation (inference
+// form of K1), fused GroupNorm / LayerNorm / SiLU / GEGLU + quantise (K5), softmax + quantise
+// (K6), layout changes.  All HBM-bound: each input element is read once (GroupNorm: twice — one
+// statistics pass, one apply pass) and each operand byte written once; 16-byte accesses.
+#include "common.h"
+#include "../../include/edadm.h"
+#include <hip/hip_fp16.h>
+
+struct QP { float d, z, qmax, pad; };
+
+__device__ __forceinline__ int q_code_i8(float x, const QP& q) {
+    const float c = fminf(fmaxf(rintf(x / q.d) + q.z, 0.f), q.qmax);
+    return (int)c - 128;
+}
+__device__ __forceinline__ uint32_t pack4_i8(int a, int b, int c, int d) {
+    return (uint32_t)(a & 0xff) | ((uint32_t)(b & 0xff) << 8) | ((uint32_t)(c & 0xff) << 16) |
+           ((uint32_t)(d & 0xff) << 24);
+}
+__device__ __forceinline__ uint32_t quant4(const float4& v, const QP& q) {
+    return pack4_i8(q_code_i8(v.x, q), q_code_i8(v.y, q), q_code_i8(v.z, q), q_code_i8(v.w, q));
+}
+
+// ------------------------------------------------------------------ plain quantise [rows][C]
+__global__ void __launch_bounds__(256) k_quant_i8(const float* __restrict__ x, int8_t* __restrict__ out,
+                                                  int64_t rows, int64_t C, const QP* __restrict__ qp,
+                                                  int64_t split) {
+    const int64_t n = rows * C, stride = (int64_t)gridDim.x * blockDim.x;
+    const QP q0 = qp[0];
+    const QP q1 = split > 0 ? qp[1] : qp[0];
+    if ((C & 3) == 0 && (split & 3) == 0) {
+        const int64_t n4 = n >> 2, C4 = C >> 2, s4 = split >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+            const float4 v = reinterpret_cast<const float4*>(x)[i];
+            const bool second = split > 0 && (i % C4) >= s4;
+            reinterpret_cast<uint32_t*>(out)[i] = quant4(v, second ? q1 : q0);
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+            const bool second = split > 0 && (i % C) >= split;
+            out[i] = (int8_t)q_code_i8(x[i], second ? q1 : q0);
+        }
+    }
+}
+extern "C" int edadm_quant_i8(const float* x, int8_t* out, int64_t rows, int64_t C, const float* qp, int64_t split,
+                              void* stream) {
+    if (!x || !out || !qp || rows <= 0 || C <= 0 || split < 0 || split >= C + (split == 0)) return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_quant_i8, dim3(edadm_grid(rows * C / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       out, rows, C, (const QP*)qp, split);
+    return edadm_launch_status();
+}
+
+// f16 operand = code - zp (exact integers), optional pre-multiplier (q*scale, openaimodel.py:391)
+__global__ void __launch_bounds__(256) k_quant_f16(const float* __restrict__ x, int64_t ldx,
+                                                   __half* __restrict__ out, int64_t ldo, int64_t rows, int64_t C,
+                                                   const QP* __restrict__ qp, float premul) {
+    const QP q = qp[0];
+    const int64_t n = rows * C, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t r = i / C, c = i - r * C;
+        float v = x[r * ldx + c];
+        if (premul != 1.0f) v = v * premul;
+        const float code = fminf(fmaxf(rintf(v / q.d) + q.z, 0.f), q.qmax);
+        out[r * ldo + c] = __float2half(code - q.z);
+    }
+}
+extern "C" int edadm_quant_f16(const float* x, int64_t ldx, void* out, int64_t ldo, int64_t rows, int64_t C,
+                               const float* qp, float premul, void* stream) {
+    if (!x || !out || !qp || rows <= 0 || C <= 0 || ldx < C || ldo < C) return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_quant_f16, dim3(edadm_grid(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                       (__half*)out, ldo, rows, C, (const QP*)qp, premul);
+    return edadm_launch_status();
+}
+
+// ------------------------------------------------------------------ NCHW <-> NHWC (model boundary)
+__global__ void __launch_bounds__(256) k_nchw_to_nhwc(const float* __restrict__ x, float* __restrict__ out,
+                                                      int64_t B, int64_t C, int64_t HW) {
+    __shared__ float tile[32][33];
+    const int64_t b = blockIdx.z;
+    const int64_t hw0 = (int64_t)blockIdx.x * 32, c0 = (int64_t)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        const int64_t c = c0 + j, hw = hw0 + tx;
+        tile[j][tx] = (c < C && hw < HW) ? x[(b * C + c) * HW + hw] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int64_t hw = hw0 + j, c = c0 + tx;
+        if (c < C && hw < HW) out[(b * HW + hw) * C + c] = tile[tx][j];
+    }
+}
+extern "C" int edadm_nchw_to_nhwc(const float* x, float* out, int64_t B, int64_t C, int64_t HW, void* stream) {
+    if (!x || !out || B <= 0 || C <= 0 || HW <= 0) return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_nchw_to_nhwc, dim3((unsigned)((HW + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)B),
+                       dim3(256), 0, (hipStream_t)stream, x, out, B, C, HW);
+    return edadm_launch_status();
+}
+extern "C" int edadm_nhwc_to_nchw(const float* x, float* out, int64_t B, int64_t C, int64_t HW, void* stream) {
+    // the same transpose with the roles of C and HW exchanged
+    if (!x || !out || B <= 0 || C <= 0 || HW <= 0) return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_nchw_to_nhwc, dim3((unsigned)((C + 31) / 32), (unsigned)((HW + 31) / 32), (unsigned)B),
+                       dim3(256), 0, (hipStream_t)stream, x, out, B, HW, C);
+    return edadm_launch_status();
+}
+
+// im2col + quantise for tiny-Cin 3x3/pad-1 convolutions: out[m][Kpad], k = (ky*3+kx)*C + c
+__global__ void __launch_bounds__(256) k_im2col_q(const float* __restrict__ x, int8_t* __restrict__ out,
+                                                  int64_t B, int64_t H, int64_t W, int64_t C, int64_t Kpad,
+                                                  const QP* __restrict__ qp) {
+    const QP q = qp[0];
+    const int padv = (int)q.z - 128;
+    const int64_t n = B * H * W * Kpad, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t m = i / Kpad, k = i - m * Kpad;
+        int v = 0;
+        if (k < 9 * C) {
+            const int64_t tap = k / C, c = k - tap * C;
+            const int64_t b = m / (H * W), r = m - b * H * W, y = r / W, xx = r - y * W;
+            const int64_t iy = y + tap / 3 - 1, ix = xx + tap % 3 - 1;
+            v = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? q_code_i8(x[((b * H + iy) * W + ix) * C + c], q) : padv;
+        }
+        out[i] = (int8_t)v;
+    }
+}
+extern "C" int edadm_im2col_quant_i8(const float* x, int8_t* out, int64_t B, int64_t H, int64_t W, int64_t C,
+                                     int64_t Kpad, const float* qp, void* stream) {
+    if (!x || !out || !qp || B <= 0 || H <= 0 || W <= 0 || C <= 0 || Kpad < 9 * C) return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_im2col_q, dim3(edadm_grid(B * H * W * Kpad, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       out, B, H, W, C, Kpad, (const QP*)qp);
+    return edadm_launch_status();
+}
+
+// ------------------------------------------------------------------ GroupNorm on NHWC
+// pass 1: per (b, chunk of rows) block, per-channel (sum, sumsq) partials -> ws[b][chunk][C][2];
+// finalize: per (b, group) sum of chunks x channels-in-group in double -> stats[b][g] = {mean, rstd}
+#define GN_CHUNKS(HW) ((int)((HW) >= 1024 ? 32 : ((HW) >= 64 ? 8 : 1)))
+
+__global__ void __launch_bounds__(256) k_gn_partial(const float* __restrict__ x, float* __restrict__ ws,
+                                                    int64_t HW, int64_t C, int nchunk) {
+    extern __shared__ float sm[];  // [RS][C][2] when RS > 1
+    const int64_t b = blockIdx.y;
+    const int chunk = blockIdx.x;
+    const int64_t r0 = HW * chunk / nchunk, r1 = HW * (chunk + 1) / nchunk;
+    const int Q = (int)(C >> 2);
+    const int RS = Q <= 256 ? 256 / Q : 1;
+    const int tid = threadIdx.x;
+    const float* xb = x + b * HW * C;
+    float* wb = ws + ((b * nchunk + chunk) * C) * 2;
+    if (Q <= 256) {
+        const int q = tid % Q, rs = tid / Q;
+        float s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+        if (rs < RS) {
+            for (int64_t r = r0 + rs; r < r1; r += RS) {
+                const float4 v = reinterpret_cast<const float4*>(xb + r * C)[q];
+                s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+                ss[0] += v.x * v.x; ss[1] += v.y * v.y; ss[2] += v.z * v.z; ss[3] += v.w * v.w;
+            }
+            for (int j = 0; j < 4; ++j) {
+                sm[((int64_t)rs * C + q * 4 + j) * 2] = s[j];
+                sm[((int64_t)rs * C + q * 4 + j) * 2 + 1] = ss[j];
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < C; c += 256) {
+            float a = 0.f, bq = 0.f;
+            for (int r = 0; r < RS; ++r) { a += sm[((int64_t)r * C + c) * 2]; bq += sm[((int64_t)r * C + c) * 2 + 1]; }
+            wb[2 * c] = a;
+            wb[2 * c + 1] = bq;
+        }
+    } else {
+        for (int q = tid; q < Q; q += 256) {
+            float s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+            for (int64_t r = r0; r < r1; ++r) {
+                const float4 v = reinterpret_cast<const float4*>(xb + r * C)[q];
+                s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+                ss[0] += v.x * v.x; ss[1] += v.y * v.y; ss[2] += v.z * v.z; ss[3] += v.w * v.w;
+            }
+            for (int j = 0; j < 4; ++j) { wb[2 * (q * 4 + j)] = s[j]; wb[2 * (q * 4 + j) + 1] = ss[j]; }
+        }
+    }
+}
+__global__ void __launch_bounds__(64) k_gn_final(const float* __restrict__ ws, float* __restrict__ stats,
+                                                 int64_t HW, int64_t C, int64_t G, int nchunk, float eps) {
+    const int64_t b = blockIdx.y, g = blockIdx.x;
+    const int cpg = (int)(C / G);
+    double s = 0.0, ss = 0.0;
+    const int items = nchunk * cpg;
+    for (int i = threadIdx.x; i < items; i += 64) {
+        const int ch = i / cpg, c = (int)(g * cpg) + i % cpg;
+        const float* p = ws + ((b * nchunk + ch) * C + c) * 2;
+        s += (double)p[0];
+        ss += (double)p[1];
+    }
+    s = wave_sum_d(s);
+    ss = wave_sum_d(ss);
+    if (threadIdx.x == 0) {
+        const double n = (double)HW * cpg;
+        const double mean = s / n;
+        double var = ss / n - mean * mean;
+        if (var < 0) var = 0;
+        stats[(b * G + g) * 2] = (float)mean;
+        stats[(b * G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+extern "C" int64_t edadm_gn_ws_floats(int64_t B, int64_t HW, int64_t C) { return B * GN_CHUNKS(HW) * C * 2; }
+extern "C" int edadm_groupnorm_stats(const float* x, float* stats, float* ws, int64_t B, int64_t HW, int64_t C,
+                                     int64_t G, float eps, void* stream) {
+    if (!x || !stats || !ws || B <= 0 || HW <= 0 || C <= 0 || G <= 0 || (C % G) || (C & 3)) return EDADM_EINVAL;
+    const int nchunk = GN_CHUNKS(HW);
+    const int Q = (int)(C >> 2);
+    const int RS = Q <= 256 ? 256 / Q : 1;
+    const size_t smem = Q <= 256 ? (size_t)RS * C * 2 * sizeof(float) : 0;
+    hipLaunchKernelGGL(k_gn_partial, dim3(nchunk, (unsigned)B), dim3(256), smem, (hipStream_t)stream, x, ws, HW, C,
+                       nchunk);
+    hipLaunchKernelGGL(k_gn_final, dim3((unsigned)G, (unsigned)B), dim3(64), 0, (hipStream_t)stream, ws, stats, HW,
+                       C, G, nchunk, eps);
+    return edadm_launch_status();
+}
+
+// pass 2: y = x*a + b per (batch, channel) [scale-shift] [silu] -> fp32 and/or up to 3 i8 operands
+__global__ void __launch_bounds__(256) k_gn_apply(const float* __restrict__ x, const float* __restrict__ stats,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  const float* __restrict__ scale_shift, int64_t HW, int64_t C,
+                                                  int64_t G, int silu, float* __restrict__ out_f32,
+                                                  int8_t* __restrict__ q0, int8_t* __restrict__ q1,
+                                                  int8_t* __restrict__ q2, const QP* __restrict__ qp, int nq,
+                                                  int rows_per_block) {
+    const int64_t b = blockIdx.y;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < HW ? r0 + rows_per_block : HW;
+    const int Q = (int)(C >> 2);
+    const int cpg = (int)(C / G);
+    QP qa = qp ? qp[0] : QP{1, 0, 255, 0}, qb = (qp && nq > 1) ? qp[1] : qa, qc = (qp && nq > 2) ? qp[2] : qa;
+    const int RS = Q <= 256 ? 256 / Q : 1;
+    const int tid = threadIdx.x;
+    const int qstep = Q <= 256 ? Q : 256;           // a thread keeps its quad(s): constants loaded once
+    const int rs = Q <= 256 ? tid / Q : 0;
+    if (Q <= 256 && rs >= RS) return;
+    for (int q = Q <= 256 ? tid % Q : tid; q < Q; q += qstep) {
+        float a[4], bb[4], sc[4], sh[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = q * 4 + j;
+            const int g = c / cpg;
+            const float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
+            a[j] = rstd * gamma[c];
+            bb[j] = beta[c] - mean * a[j];
+            sc[j] = 1.f; sh[j] = 0.f;
+            if (scale_shift) { sc[j] = 1.0f + scale_shift[b * 2 * C + c]; sh[j] = scale_shift[b * 2 * C + C + c]; }
+        }
+        for (int64_t r = r0 + rs; r < r1; r += RS) {
+            const int64_t idx = (b * HW + r) * Q + q;
+            float4 v = reinterpret_cast<const float4*>(x)[idx];
+            float y[4] = {v.x * a[0] + bb[0], v.y * a[1] + bb[1], v.z * a[2] + bb[2], v.w * a[3] + bb[3]};
+            if (scale_shift) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) y[j] = y[j] * sc[j] + sh[j];
+            }
+            if (silu) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) y[j] = silu_f(y[j]);
+            }
+            const float4 o = make_float4(y[0], y[1], y[2], y[3]);
+            if (out_f32) reinterpret_cast<float4*>(out_f32)[idx] = o;
+            if (q0) reinterpret_cast<uint32_t*>(q0)[idx] = quant4(o, qa);
+            if (q1) reinterpret_cast<uint32_t*>(q1)[idx] = quant4(o, qb);
+            if (q2) reinterpret_cast<uint32_t*>(q2)[idx] = quant4(o, qc);
+        }
+        if (Q <= 256) break;
+    }
+}
+extern "C" int edadm_groupnorm_apply(const float* x, const float* stats, const float* gamma, const float* beta,
+                                     const float* scale_shift, int64_t B, int64_t HW, int64_t C, int64_t G,
+                                     int silu, float* out_f32, int8_t* q0, int8_t* q1, int8_t* q2, const float* qp,
+                                     int nq, void* stream) {
+    if (!x || !stats || !gamma || !beta || B <= 0 || HW <= 0 || C <= 0 || (C & 3) || (C % G)) return EDADM_EINVAL;
+    if ((q0 || q1 || q2) && !qp) return EDADM_EINVAL;
+    // rows per block: a multiple of what keeps (quad) fixed per thread when Q | 256, ~16 KB of input per block
+    int rpb = (int)(16384 / C);   // ~64 KB of fp32 input per block
+    if (rpb < 1) rpb = 1;
+    const unsigned gx = (unsigned)((HW + rpb - 1) / rpb);
+    hipLaunchKernelGGL(k_gn_apply, dim3(gx, (unsigned)B), dim3(256), 0, (hipStream_t)stream, x, stats, gamma, beta,
+                       scale_shift, HW, C, G, silu, out_f32, q0, q1, q2, (const QP*)qp, nq, rpb);
+    return edadm_launch_status();
+}
+
+// ------------------------------------------------------------------ LayerNorm (+ up to 3 quantised outputs)
+// one wave per row; the row stays in registers (C <= 64*MAXPL) between the two passes
+#define LN_MAXPL 32
+__global__ void __launch_bounds__(256) k_ln_quant(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, int64_t rows, int64_t C,
+                                                  float eps, float* __restrict__ out_f32, int8_t* __restrict__ q0,
+                                                  int8_t* __restrict__ q1, int8_t* __restrict__ q2,
+                                                  const QP* __restrict__ qp, int nq) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    QP qa = qp ? qp[0] : QP{1, 0, 255, 0}, qb = (qp && nq > 1) ? qp[1] : qa, qc = (qp && nq > 2) ? qp[2] : qa;
+    const float* xr = x + row * C;
+    float v[LN_MAXPL];
+    const int npl = (int)((C + 63) / 64);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXPL; ++j) {
+        if (j < npl) {
+            const int64_t c = (int64_t)j * 64 + lane;
+            v[j] = c < C ? xr[c] : 0.f;
+            s += v[j];
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXPL; ++j) {
+        if (j < npl) {
+            const int64_t c = (int64_t)j * 64 + lane;
+            const float d = c < C ? v[j] - mean : 0.f;
+            ss += d * d;
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)C + eps);
+#pragma unroll
+    for (int j = 0; j < LN_MAXPL; ++j) {
+        if (j < npl) {
+            const int64_t c = (int64_t)j * 64 + lane;
+            if (c < C) {
+                const float y = (v[j] - mean) * rstd * gamma[c] + beta[c];
+                if (out_f32) out_f32[row * C + c] = y;
+                if (q0) q0[row * C + c] = (int8_t)q_code_i8(y, qa);
+                if (q1) q1[row * C + c] = (int8_t)q_code_i8(y, qb);
+                if (q2) q2[row * C + c] = (int8_t)q_code_i8(y, qc);
+            }
+        }
+    }
+}
+extern "C" int edadm_layernorm_quant(const float* x, const float* gamma, const float* beta, int64_t rows, int64_t C,
+                                     float eps, float* out_f32, int8_t* q0, int8_t* q1, int8_t* q2, const float* qp,
+                                     int nq, void* stream) {
+    if (!x || !gamma || !beta || rows <= 0 || C <= 0 || C > 64 * LN_MAXPL) return EDADM_EINVAL;
+    if ((q0 || q1 || q2) && !qp) return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_ln_quant, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma,
+                       beta, rows, C, eps, out_f32, q0, q1, q2, (const QP*)qp, nq);
+    return edadm_launch_status();
+}
+
+// ------------------------------------------------------------------ small fused producers
+__global__ void __launch_bounds__(256) k_silu_q(const float* __restrict__ x, int8_t* __restrict__ out, int64_t n,
+                                                const QP* __restrict__ qp) {
+    const QP q = qp[0];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = (int8_t)q_code_i8(silu_f(x[i]), q);
+}
+extern "C" int edadm_silu_quant_i8(const float* x, int8_t* out, int64_t n, const float* qp, void* stream) {
+    if (!x || !out || !qp || n <= 0) return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_silu_q, dim3(edadm_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, out, n,
+                       (const QP*)qp);
+    return edadm_launch_status();
+}
+__global__ void __launch_bounds__(256) k_silu(const float* __restrict__ x, float* __restrict__ out, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = silu_f(x[i]);
+}
+extern "C" int edadm_silu(const float* x, float* out, int64_t n, void* stream) {
+    if (!x || !out || n <= 0) return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_silu, dim3(edadm_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, out, n);
+    return edadm_launch_status();
+}
+// GEGLU: x[rows][2*inner] -> a * gelu(gate) quantised  (attention.py:37-45; exact-erf gelu)
+__global__ void __launch_bounds__(256) k_geglu_q(const float* __restrict__ x, int8_t* __restrict__ out,
+                                                 int64_t rows, int64_t inner, const QP* __restrict__ qp) {
+    const QP q = qp[0];
+    const int64_t n = rows * inner, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t r = i / inner, c = i - r * inner;
+        const float a = x[r * 2 * inner + c], g = x[r * 2 * inner + inner + c];
+        const float gl = 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f));
+        out[i] = (int8_t)q_code_i8(a * gl, q);
+    }
+}
+extern "C" int edadm_geglu_quant_i8(const float* x, int8_t* out, int64_t rows, int64_t inner, const float* qp,
+                                    void* stream) {
+    if (!x || !out || !qp || rows <= 0 || inner <= 0) return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_geglu_q, dim3(edadm_grid(rows * inner, 256)), dim3(256), 0, (hipStream_t)stream, x, out,
+                       rows, inner, (const QP*)qp);
+    return edadm_launch_status();
+}
+__global__ void __launch_bounds__(256) k_add(const float* __restrict__ a, const float* __restrict__ b,
+                                             float* __restrict__ out, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = a[i] + b[i];
+}
+extern "C" int edadm_add(const float* a, const float* b, float* out, int64_t n, void* stream) {
+    if (!a || !b || !out || n <= 0) return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_add, dim3(edadm_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+    return edadm_launch_status();
+}
+// channel concat of two NHWC tensors (the UNet skip connection, openaimodel.py:778)
+__global__ void __launch_bounds__(256) k_concat(const float* __restrict__ a, int64_t Ca, const float* __restrict__ b,
+                                                int64_t Cb, float* __restrict__ out, int64_t rows) {
+    const int64_t C4 = (Ca + Cb) >> 2, A4 = Ca >> 2, B4 = Cb >> 2;
+    const int64_t n = rows * C4, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t r = i / C4, c = i - r * C4;
+        reinterpret_cast<float4*>(out)[i] = c < A4 ? reinterpret_cast<const float4*>(a)[r * A4 + c]
+                                                   : reinterpret_cast<const float4*>(b)[r * B4 + (c - A4)];
+    }
+}
+extern "C" int edadm_concat_c(const float* a, int64_t Ca, const float* b, int64_t Cb, float* out, int64_t rows,
+                              void* stream) {
+    if (!a || !b || !out || rows <= 0 || (Ca & 3) || (Cb & 3)) return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_concat, dim3(edadm_grid(rows * (Ca + Cb) / 4, 256)), dim3(256), 0, (hipStream_t)stream, a,
+                       Ca, b, Cb, out, rows);
+    return edadm_launch_status();
+}
+__global__ void __launch_bounds__(256) k_avgpool2(const float* __restrict__ x, float* __restrict__ out, int64_t B,
+                                                  int64_t H, int64_t W, int64_t C) {
+    const int64_t Ho = H / 2, Wo = W / 2, n = B * Ho * Wo * C, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t c = i % C, p = i / C, xo = p % Wo, yo = (p / Wo) % Ho, b = p / (Wo * Ho);
+        const float* s = x + ((b * H + 2 * yo) * W + 2 * xo) * C + c;
+        out[i] = (s[0] + s[C] + s[W * C] + s[W * C + C]) * 0.25f;
+    }
+}
+extern "C" int edadm_avgpool2_nhwc(const float* x, float* out, int64_t B, int64_t H, int64_t W, int64_t C,
+                                   void* stream) {
+    if (!x || !out || B <= 0 || H < 2 || W < 2 || C <= 0) return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_avgpool2, dim3(edadm_grid(B * H * W * C / 4, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       out, B, H, W, C);
+    return edadm_launch_status();
+}
+__global__ void __launch_bounds__(256) k_upsample2(const float* __restrict__ x, float* __restrict__ out, int64_t B,
+                                                   int64_t H, int64_t W, int64_t C) {
+    const int64_t Ho = H * 2, Wo = W * 2, n = B * Ho * Wo * C, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t c = i % C, p = i / C, xo = p % Wo, yo = (p / Wo) % Ho, b = p / (Wo * Ho);
+        out[i] = x[((b * H + yo / 2) * W + xo / 2) * C + c];
+    }
+}
+extern "C" int edadm_upsample2_nhwc(const float* x, float* out, int64_t B, int64_t H, int64_t W, int64_t C,
+                                    void* stream) {
+    if (!x || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0) return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_upsample2, dim3(edadm_grid(B * H * W * C * 4, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       out, B, H, W, C);
+    return edadm_launch_status();
+}
+
+// ------------------------------------------------------------------ K6: softmax rows + quantise to f16 codes
+__global__ void __launch_bounds__(256) k_softmax_q(const float* __restrict__ s, __half* __restrict__ out,
+                                                   int64_t rows, int64_t cols, int64_t ldo,
+                                                   const QP* __restrict__ qp) {
+    const QP q = qp[0];
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* sr = s + row * cols;
+    float mx = -INFINITY;
+    for (int64_t c = lane; c < cols; c += 64) mx = fmaxf(mx, sr[c]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int64_t c = lane; c < cols; c += 64) sum += expf(sr[c] - mx);
+    sum = wave_sum(sum);
+    for (int64_t c = lane; c < cols; c += 64) {
+        const float p = expf(sr[c] - mx) / sum;
+        const float code = fminf(fmaxf(rintf(p / q.d) + q.z, 0.f), q.qmax);
+        out[row * ldo + c] = __float2half(code - q.z);
+    }
+    for (int64_t c = cols + lane; c < ldo; c += 64) out[row * ldo + c] = __float2half(0.f);
+}
+extern "C" int edadm_softmax_quant_f16(const float* s, void* out, int64_t rows, int64_t cols, int64_t ldo,
+                                       const float* qp, void* stream) {
+    if (!s || !out || !qp || rows <= 0 || cols <= 0 || ldo < cols) return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_softmax_q, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, s,
+                       (__half*)out, rows, cols, ldo, (const QP*)qp);
+    return edadm_launch_status();
+}
+
+// f16 [b][n][d] -> [b][d][n]  (B operand of the PV product); pads n up to ldo with zeros
+__global__ void __launch_bounds__(256) k_transpose_f16(const __half* __restrict__ x, int64_t ldx, int64_t strideX,
+                                                       __half* __restrict__ out, int64_t ldo, int64_t strideO,
+                                                       int64_t n, int64_t d) {
+    __shared__ __half tile[32][34];
+    const int64_t b = blockIdx.z;
+    const int64_t n0 = (int64_t)blockIdx.x * 32, d0 = (int64_t)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int64_t nn = n0 + j, dd = d0 + tx;
+        tile[j][tx] = (nn < n && dd < d) ? x[b * strideX + nn * ldx + dd] : __float2half(0.f);
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int64_t dd = d0 + j, nn = n0 + tx;
+        if (dd < d && nn < ldo) out[b * strideO + dd * ldo + nn] = tile[tx][j];
+    }
+}
+extern "C" int edadm_transpose_f16(const void* x, int64_t ldx, int64_t strideX, void* out, int64_t ldo,
+                                   int64_t strideO, int64_t batch, int64_t n, int64_t d, void* stream) {
+    if (!x || !out || batch <= 0 || n <= 0 || d <= 0 || ldo < n) return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_transpose_f16, dim3((unsigned)((ldo + 31) / 32), (unsigned)((d + 31) / 32), (unsigned)batch),
+                       dim3(256), 0, (hipStream_t)stream, (const __half*)x, ldx, strideX, (__half*)out, ldo, strideO,
+                       n, d);
+    return edadm_launch_status();
+}
+
+// int4 nibble codes (two per byte, low nibble first) -> int8 operand code - zp[row]
+__global__ void __launch_bounds__(256) k_unpack_w4(const uint8_t* __restrict__ p, const float* __restrict__ zp,
+                                                   int8_t* __restrict__ out, int64_t rows, int64_t cols) {
+    const int64_t n = rows * cols, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t r = i / cols;
+        const uint8_t byte = p[i >> 1];
+        const int code = (i & 1) ? (byte >> 4) : (byte & 15);
+        out[i] = (int8_t)(code - (int)zp[r]);
+    }
+}
+extern "C" int edadm_unpack_w4(const uint8_t* packed, const float* zp, int8_t* out, int64_t rows, int64_t cols,
+                               void* stream) {
+    if (!packed || !zp || !out || rows <= 0 || cols <= 0 || ((rows * cols) & 1)) return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_unpack_w4, dim3(edadm_grid(rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, packed,
+                       zp, out, rows, cols);
+    return edadm_launch_status();
+}

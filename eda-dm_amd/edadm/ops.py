@@ -1,0 +1,325 @@
+"""Torch-tensor front end of the C ABI (include/edadm.h).  Tensors only lend their device
+pointers; every launch goes to torch's current HIP stream so it orders with the surrounding
+torch work and can be captured into a HIP graph.  No CPU fallback: non-device tensors raise."""
+import ctypes
+
+import torch
+
+from . import lib
+
+_ws = {}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t, dtype=None):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise lib.EdadmError("edadm ops need device tensors (no CPU fallback)")
+    if not t.is_contiguous():
+        raise lib.EdadmError("edadm ops need contiguous tensors")
+    if dtype is not None and t.dtype != dtype:
+        raise lib.EdadmError("expected %s, got %s" % (dtype, t.dtype))
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _pf(t):
+    return _p(t, torch.float32)
+
+
+def workspace(device, floats=None):
+    n = int(lib.load().edadm_reduce_ws_floats()) if floats is None else int(floats)
+    key = (device.index, "r" if floats is None else "x")
+    w = _ws.get(key)
+    if w is None or w.numel() < n:
+        w = torch.empty(max(n, 1), dtype=torch.float32, device=device)
+        _ws[key] = w
+    return w
+
+
+def qp_tensor(entries, device):
+    """entries: list of (delta, zp, qmax) python floats / 0-d tensors -> device float[4*n]."""
+    rows = []
+    for d, z, qmax in entries:
+        rows.append(torch.stack([torch.as_tensor(d, dtype=torch.float32, device=device).reshape(()),
+                                 torch.as_tensor(z, dtype=torch.float32, device=device).reshape(()),
+                                 torch.tensor(float(qmax), device=device), torch.zeros((), device=device)]))
+    return torch.stack(rows).reshape(-1).contiguous()
+
+
+# ------------------------------------------------------------------------------ K1
+def fake_quant_fwd(x, delta, zp, qmax, inner=1, u=None, prob=1.0, seed=0, want_codes=False):
+    out = torch.empty_like(x)
+    codes = torch.empty_like(x) if want_codes else None
+    nq = delta.numel()
+    lib.call("edadm_fake_quant_fwd", _pf(x), _pf(out), _pf(codes), x.numel(), _pf(delta), _pf(zp), nq, int(inner),
+             float(qmax), _pf(u), float(prob), int(seed), _stream())
+    return (out, codes) if want_codes else out
+
+
+def fake_quant_bwd(gy, x, delta, zp, qmax, u=None, prob=1.0, seed=0, need_gx=True):
+    gx = torch.empty_like(x) if need_gx else None
+    gd = torch.empty(1, dtype=torch.float32, device=x.device)
+    lib.call("edadm_fake_quant_bwd", _pf(gy), _pf(x), _pf(gx), _pf(gd), x.numel(), _pf(delta), _pf(zp), float(qmax),
+             _pf(u), float(prob), int(seed), _pf(workspace(x.device)), _stream())
+    return gx, gd
+
+
+# ------------------------------------------------------------------------------ K2
+def _rows_cols(w):
+    return w.shape[0], w[0].numel()
+
+
+def adaround_init_alpha(w_view, delta):
+    """w_view: weight or a dim-1 slice of it (rows keep the parent's leading dimension)."""
+    rows, cols = _rows_cols(w_view)
+    alpha = torch.empty(w_view.shape, dtype=torch.float32, device=w_view.device)
+    lib.call("edadm_adaround_init_alpha", ctypes.c_void_p(w_view.data_ptr()), w_view.stride(0), _pf(alpha), rows, cols,
+             _pf(delta.reshape(-1).contiguous()), _stream())
+    return alpha
+
+
+def adaround_fwd(w_view, alpha, out_view, delta, zp, qmax, soft):
+    rows, cols = _rows_cols(w_view)
+    lib.call("edadm_adaround_fwd", ctypes.c_void_p(w_view.data_ptr()), w_view.stride(0), _pf(alpha),
+             ctypes.c_void_p(out_view.data_ptr()), out_view.stride(0), rows, cols, _pf(delta), _pf(zp), float(qmax),
+             1 if soft else 0, _stream())
+    return out_view
+
+
+def adaround_bwd(gy_view, w_view, alpha, delta, zp, qmax):
+    rows, cols = _rows_cols(w_view)
+    ga = torch.empty_like(alpha)
+    lib.call("edadm_adaround_bwd", ctypes.c_void_p(gy_view.data_ptr()), gy_view.stride(0),
+             ctypes.c_void_p(w_view.data_ptr()), w_view.stride(0), _pf(alpha), _pf(ga), rows, cols, _pf(delta), _pf(zp),
+             float(qmax), _stream())
+    return ga
+
+
+# ------------------------------------------------------------------------------ K3
+def mse_scores_tensor(x, scale, zp, qmax):
+    nc = scale.numel()
+    score = torch.empty(nc, dtype=torch.float32, device=x.device)
+    lib.call("edadm_mse_scores_tensor", _pf(x), x.numel(), _pf(scale), _pf(zp), nc, float(qmax), _pf(score),
+             _pf(workspace(x.device)), _stream())
+    return score
+
+
+def mse_scores_channel(x2d, scale, zp, qmax):
+    """x2d [rows][cols]; scale/zp [nc][rows] -> score [nc][rows]."""
+    rows, cols = x2d.shape
+    nc = scale.shape[0]
+    score = torch.empty(nc, rows, dtype=torch.float32, device=x2d.device)
+    lib.call("edadm_mse_scores_channel", _pf(x2d), rows, cols, _pf(scale), _pf(zp), nc, float(qmax), _pf(score),
+             _stream())
+    return score
+
+
+def minmax(x):
+    out = torch.empty(2, dtype=torch.float32, device=x.device)
+    lib.call("edadm_minmax", _pf(x), x.numel(), _pf(out), _pf(workspace(x.device)), _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------ K7 / K8 / K9 / K10
+def lp_loss_fwd(pred, tgt):
+    loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+    inv = 1.0 / (pred.numel() / pred.shape[1])
+    lib.call("edadm_lp_loss_fwd", _pf(pred), _pf(tgt), pred.numel(), inv, _pf(loss), _pf(workspace(pred.device)),
+             _stream())
+    return loss
+
+
+def lp_loss_bwd(pred, tgt, gscale):
+    g = torch.empty_like(pred)
+    inv = 1.0 / (pred.numel() / pred.shape[1])
+    lib.call("edadm_lp_loss_bwd", _pf(pred), _pf(tgt), pred.numel(), inv, _pf(gscale), _pf(g), _stream())
+    return g
+
+
+def adam_step(p, g, m, v, hyper):
+    lib.call("edadm_adam_step", _pf(p), _pf(g), _pf(m), _pf(v), p.numel(), _pf(hyper), _stream())
+
+
+def mix_where(a, b, prob, u=None, seed=0):
+    out = torch.empty_like(a)
+    lib.call("edadm_mix_where", _pf(a), _pf(b), _pf(out), a.numel(), _pf(u), float(prob), int(seed), _stream())
+    return out
+
+
+def ddim_step(x, e_cond, e_uncond, cfg_scale, coef, noise=None, want_x0=False):
+    xp = torch.empty_like(x)
+    p0 = torch.empty_like(x) if want_x0 else None
+    B = x.shape[0]
+    lib.call("edadm_ddim_step", _pf(x), _pf(e_cond), _pf(e_uncond), float(cfg_scale), _pf(coef), _pf(noise), _pf(xp),
+             _pf(p0), B, x.numel() // B, _stream())
+    return (xp, p0) if want_x0 else xp
+
+
+# ------------------------------------------------------------------------------ operand producers
+def quant_i8(x2d, qp, split=0, out=None):
+    rows, C = x2d.shape
+    if out is None:
+        out = torch.empty(rows, C, dtype=torch.int8, device=x2d.device)
+    lib.call("edadm_quant_i8", _pf(x2d), _p(out, torch.int8), rows, C, _pf(qp), int(split), _stream())
+    return out
+
+
+def quant_f16(x2d, qp, premul=1.0, out=None):
+    rows, C = x2d.shape
+    if out is None:
+        out = torch.empty(rows, C, dtype=torch.float16, device=x2d.device)
+    lib.call("edadm_quant_f16", ctypes.c_void_p(x2d.data_ptr()), x2d.stride(0), ctypes.c_void_p(out.data_ptr()),
+             out.stride(0), rows, C, _pf(qp), float(premul), _stream())
+    return out
+
+
+def nchw_to_nhwc(x):
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C)
+    out = torch.empty((B,) + tuple(x.shape[2:]) + (C,), dtype=torch.float32, device=x.device)
+    lib.call("edadm_nchw_to_nhwc", _pf(x), _pf(out), B, C, HW, _stream())
+    return out
+
+
+def nhwc_to_nchw(x):
+    B, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * C)
+    out = torch.empty((B, C) + tuple(x.shape[1:-1]), dtype=torch.float32, device=x.device)
+    lib.call("edadm_nhwc_to_nchw", _pf(x), _pf(out), B, C, HW, _stream())
+    return out
+
+
+def im2col_quant_i8(x_nhwc, Kpad, qp):
+    B, H, W, C = x_nhwc.shape
+    out = torch.empty(B * H * W, Kpad, dtype=torch.int8, device=x_nhwc.device)
+    lib.call("edadm_im2col_quant_i8", _pf(x_nhwc), _p(out, torch.int8), B, H, W, C, Kpad, _pf(qp), _stream())
+    return out
+
+
+def groupnorm_stats(x_nhwc, G, eps):
+    B, C = x_nhwc.shape[0], x_nhwc.shape[-1]
+    HW = x_nhwc.numel() // (B * C)
+    stats = torch.empty(B, G, 2, dtype=torch.float32, device=x_nhwc.device)
+    ws = workspace(x_nhwc.device, lib.load().edadm_gn_ws_floats(B, HW, C))
+    lib.call("edadm_groupnorm_stats", _pf(x_nhwc), _pf(stats), _pf(ws), B, HW, C, G, float(eps), _stream())
+    return stats
+
+
+def groupnorm_apply(x_nhwc, stats, gamma, beta, G, silu, qp=None, nq=0, want_f32=False, scale_shift=None):
+    B, C = x_nhwc.shape[0], x_nhwc.shape[-1]
+    HW = x_nhwc.numel() // (B * C)
+    dev = x_nhwc.device
+    out = torch.empty_like(x_nhwc) if want_f32 else None
+    qs = [torch.empty(x_nhwc.shape, dtype=torch.int8, device=dev) for _ in range(nq)]
+    qq = qs + [None] * (3 - nq)
+    lib.call("edadm_groupnorm_apply", _pf(x_nhwc), _pf(stats), _pf(gamma), _pf(beta), _pf(scale_shift), B, HW, C, G,
+             1 if silu else 0, _pf(out), _p(qq[0]), _p(qq[1]), _p(qq[2]), _pf(qp), nq, _stream())
+    return out, qs
+
+
+def layernorm_quant(x2d, gamma, beta, eps, qp=None, nq=0, want_f32=False):
+    rows, C = x2d.shape
+    out = torch.empty_like(x2d) if want_f32 else None
+    qs = [torch.empty(rows, C, dtype=torch.int8, device=x2d.device) for _ in range(nq)]
+    qq = qs + [None] * (3 - nq)
+    lib.call("edadm_layernorm_quant", _pf(x2d), _pf(gamma), _pf(beta), rows, C, float(eps), _pf(out), _p(qq[0]),
+             _p(qq[1]), _p(qq[2]), _pf(qp), nq, _stream())
+    return out, qs
+
+
+def silu_quant_i8(x, qp):
+    out = torch.empty(x.shape, dtype=torch.int8, device=x.device)
+    lib.call("edadm_silu_quant_i8", _pf(x), _p(out, torch.int8), x.numel(), _pf(qp), _stream())
+    return out
+
+
+def geglu_quant_i8(x2d, qp):
+    rows, two = x2d.shape
+    out = torch.empty(rows, two // 2, dtype=torch.int8, device=x2d.device)
+    lib.call("edadm_geglu_quant_i8", _pf(x2d), _p(out, torch.int8), rows, two // 2, _pf(qp), _stream())
+    return out
+
+
+def silu(x):
+    out = torch.empty_like(x)
+    lib.call("edadm_silu", _pf(x), _pf(out), x.numel(), _stream())
+    return out
+
+
+def add(a, b):
+    out = torch.empty_like(a)
+    lib.call("edadm_add", _pf(a), _pf(b), _pf(out), a.numel(), _stream())
+    return out
+
+
+def concat_c(a, b):
+    Ca, Cb = a.shape[-1], b.shape[-1]
+    rows = a.numel() // Ca
+    out = torch.empty(tuple(a.shape[:-1]) + (Ca + Cb,), dtype=torch.float32, device=a.device)
+    lib.call("edadm_concat_c", _pf(a), Ca, _pf(b), Cb, _pf(out), rows, _stream())
+    return out
+
+
+def avgpool2_nhwc(x):
+    B, H, W, C = x.shape
+    out = torch.empty(B, H // 2, W // 2, C, dtype=torch.float32, device=x.device)
+    lib.call("edadm_avgpool2_nhwc", _pf(x), _pf(out), B, H, W, C, _stream())
+    return out
+
+
+def upsample2_nhwc(x):
+    B, H, W, C = x.shape
+    out = torch.empty(B, H * 2, W * 2, C, dtype=torch.float32, device=x.device)
+    lib.call("edadm_upsample2_nhwc", _pf(x), _pf(out), B, H, W, C, _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------ K4 / K6
+def make_geom(B, H, W, Cin, Ho, Wo, KH, KW, stride, pad0, ups, padval):
+    return (ctypes.c_int32 * 16)(1, B, H, W, Cin, Ho, Wo, KH, KW, stride, pad0, 1 if ups else 0, int(padval), 0, 0, 0)
+
+
+def qgemm_i8(A, Wt, M, N, K, scale, bias, out, geom=None, lda=None, ldw=None, rowadd=None, rows_per_batch=1,
+             residual=None):
+    """out[M][N] (fp32, contiguous rows of length N) = scale[n] * (A . Wt^T) + bias[n] [+rowadd] [+residual]."""
+    lda = K if lda is None else lda
+    ldw = K if ldw is None else ldw
+    gptr = ctypes.cast(geom, ctypes.c_void_p) if geom is not None else None
+    lib.call("edadm_qgemm_i8", ctypes.c_void_p(A.data_ptr()), int(lda), ctypes.c_void_p(Wt.data_ptr()), int(ldw),
+             int(M), int(N), int(K), gptr, _pf(scale), _pf(bias), _pf(rowadd), int(rows_per_batch), _pf(residual),
+             int(N), _pf(out), int(N), _stream())
+    return out
+
+
+def gemm_f16_nt(A, lda, strideA, Bm, ldb, strideB, batch, M, N, K, alpha, out=None):
+    if out is None:
+        out = torch.empty(batch, M, N, dtype=torch.float32, device=A.device)
+    lib.call("edadm_gemm_f16_nt", ctypes.c_void_p(A.data_ptr()), int(lda), int(strideA),
+             ctypes.c_void_p(Bm.data_ptr()), int(ldb), int(strideB), _pf(out), int(N), int(M * N), int(batch), int(M),
+             int(N), int(K), float(alpha), _stream())
+    return out
+
+
+def softmax_quant_f16(s2d, qp, ldo=None):
+    rows, cols = s2d.shape
+    ldo = cols if ldo is None else ldo
+    out = torch.empty(rows, ldo, dtype=torch.float16, device=s2d.device)
+    lib.call("edadm_softmax_quant_f16", _pf(s2d), ctypes.c_void_p(out.data_ptr()), rows, cols, ldo, _pf(qp), _stream())
+    return out
+
+
+def transpose_f16(x, ldx, strideX, batch, n, d, ldo):
+    out = torch.empty(batch, d, ldo, dtype=torch.float16, device=x.device)
+    lib.call("edadm_transpose_f16", ctypes.c_void_p(x.data_ptr()), int(ldx), int(strideX),
+             ctypes.c_void_p(out.data_ptr()), int(ldo), int(d * ldo), int(batch), int(n), int(d), _stream())
+    return out
+
+
+def unpack_w4(packed, zp, rows, cols):
+    out = torch.empty(rows, cols, dtype=torch.int8, device=packed.device)
+    lib.call("edadm_unpack_w4", _p(packed, torch.uint8), _pf(zp), _p(out, torch.int8), rows, cols, _stream())
+    return out

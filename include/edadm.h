@@ -1,0 +1,171 @@
+/* edadm.h — C ABI of the MI355X-native EDA-DM hot path (libedadm.so, gfx950 only).
+ *
+ * The reference (BienLuky/EDA-DM) has no FFI layer: its hot path is chains of stock PyTorch ops
+ * inside qdiff/ *.py and the UNet definitions.  Each entry point below replaces one such chain
+ * (SURVEY.md §2 "K#" table) and cites the reference file:line it stands for.  The Python host
+ * (eda-dm_amd/qdiff, .../edadm) binds these with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer borrowed from the caller (kept alive until the stream
+ *    op completes); no torch types; sizes are element counts unless said otherwise;
+ *  - `stream` is a hipStream_t passed as void*; every call only enqueues work on it
+ *    (graph-capturable: no allocation, no synchronisation inside);
+ *  - return 0 on success, negative errno-style code otherwise (-22 bad argument,
+ *    -5 launch failure); nothing throws;
+ *  - float arithmetic that decides integer codes is IEEE fp32 with true division and
+ *    round-half-to-even, exactly like the reference (`round(x / delta)`).
+ */
+#ifndef EDADM_H
+#define EDADM_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int edadm_abi_version(void);
+
+/* ---- K1: uniform affine fake-quant -------------------------------------------------------
+ * qdiff/quant_layer.py:266-276 (UniformAffineQuantizer.forward, inited path).
+ * out = (clamp(rint(x/delta)+zp, 0, qmax) - zp) * delta ; per-tensor (nq==1) or per-row-block
+ * (nq>1: parameter index = (i / inner) % nq, i.e. dim-0 channel-wise for weights).
+ * Training "prob" mix (`where(rand < prob, xq, x)`, :271-272): if u!=NULL the uniforms are
+ * taken from u (injected mask, parity tests); else if prob<1 a counter RNG keyed by
+ * (seed, element index) is used; prob>=1 disables mixing.  codes (optional, may be NULL)
+ * receives the unsigned integer code as float. */
+int edadm_fake_quant_fwd(const float* x, float* out, float* codes, int64_t n,
+                         const float* delta, const float* zp, int64_t nq, int64_t inner,
+                         float qmax, const float* u, float prob, uint64_t seed, void* stream);
+
+/* Backward of the above for per-tensor delta (LSQ-style): quant_layer.py:19-23,266-276 through
+ * autograd.  gx = (gy*delta*inrange)/delta [masked-out elements pass gy]; gdelta (1 float) =
+ * sum gy*(code-zp) - (gy*delta*inrange)*((x/delta)/delta).  ws: >= edadm_reduce_ws_floats()
+ * floats of scratch. */
+int edadm_fake_quant_bwd(const float* gy, const float* x, float* gx, float* gdelta, int64_t n,
+                         const float* delta, const float* zp, float qmax,
+                         const float* u, float prob, uint64_t seed, float* ws, void* stream);
+int64_t edadm_reduce_ws_floats(void);
+
+/* ---- K2: AdaRound ---------------------------------------------------------------------------
+ * qdiff/adaptive_rounding.py:49-72.  Weight viewed as rows x cols with leading dimensions
+ * (split weights are column slices of the full tensor, quant_layer.py:424-427); alpha/galpha are
+ * dense rows*cols; delta/zp per row.  soft!=0: floor(w/d)+clamp(sigmoid(a)*1.2-0.1,0,1);
+ * soft==0: floor(w/d)+(a>=0). */
+int edadm_adaround_init_alpha(const float* w, int64_t ldw, float* alpha, int64_t rows, int64_t cols,
+                              const float* delta, void* stream);
+int edadm_adaround_fwd(const float* w, int64_t ldw, const float* alpha, float* out, int64_t ldo,
+                       int64_t rows, int64_t cols, const float* delta, const float* zp, float qmax,
+                       int soft, void* stream);
+int edadm_adaround_bwd(const float* gy, int64_t ldg, const float* w, int64_t ldw, const float* alpha,
+                       float* galpha, int64_t rows, int64_t cols, const float* delta, const float* zp,
+                       float qmax, void* stream);
+
+/* ---- K3: MSE clip-range search scores ---------------------------------------------------------
+ * qdiff/quant_layer.py:120-147,150-213: score[c] = mean |q_c(x) - x|^2.4 for candidate c with
+ * (scale[c], zp[c]); per-tensor: x[n], nc candidates -> score[nc];
+ * per-channel: x[rows][cols], candidates laid out [nc][rows] -> score[nc][rows]. nc <= 128. */
+int edadm_mse_scores_tensor(const float* x, int64_t n, const float* scale, const float* zp, int nc,
+                            float qmax, float* score, float* ws, void* stream);
+int edadm_mse_scores_channel(const float* x, int64_t rows, int64_t cols, const float* scale,
+                             const float* zp, int nc, float qmax, float* score, void* stream);
+int edadm_minmax(const float* x, int64_t n, float* out2, float* ws, void* stream);
+
+/* ---- K7: reconstruction loss -------------------------------------------------------------------
+ * qdiff/quant_layer.py:26-33 with p=2, reduction 'none': sum((pred-tgt)^2) / (numel / C).
+ * fwd writes 1 float; bwd: gpred = gscale[0] * 2 (pred-tgt) / (numel/C). */
+int edadm_lp_loss_fwd(const float* pred, const float* tgt, int64_t n, float inv_denom, float* loss,
+                      float* ws, void* stream);
+int edadm_lp_loss_bwd(const float* pred, const float* tgt, int64_t n, float inv_denom,
+                      const float* gscale, float* gpred, void* stream);
+
+/* ---- K8: fused Adam step (torch.optim.Adam semantics as used at block_recon.py:112-117,199-206)
+ * hyper = device float[4]: {lr/bias_corr1, sqrt(bias_corr2), beta1, beta2}; eps fixed 1e-8. */
+int edadm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
+                    void* stream);
+
+/* ---- K10: stochastic input mixing  block_recon.py:141-145 ------------------------------------ */
+int edadm_mix_where(const float* a, const float* b, float* out, int64_t n, const float* u, float prob,
+                    uint64_t seed, void* stream);
+
+/* ---- K9: DDIM update -------------------------------------------------------------------------
+ * ddim/functions/denoising.py:50-56 and ldm/models/diffusion/ddim_control.py:221-253.
+ * Per-sample coefficient table coef[B][5] = {sqrt(1-a_t), sqrt(a_t), sqrt(a_prev),
+ * sqrt(1-a_prev-sigma^2), sigma}; classifier-free guidance:
+ * e = e_u + s (e_c - e_u) when e_uncond != NULL. x, e: [B][chw]. */
+int edadm_ddim_step(const float* x, const float* e_cond, const float* e_uncond, float cfg_scale,
+                    const float* coef, const float* noise, float* x_prev, float* pred_x0,
+                    int64_t B, int64_t chw, void* stream);
+
+/* ---- activation quantisation to MFMA operands (inference form of K1) --------------------------
+ * code = clamp(rint(x/delta)+zp,0,qmax); i8 operand = code-128; f16 operand = code-zp.
+ * qp = device float[4*nseg]: {delta, zp, qmax, unused} per channel segment; channels
+ * [0,split) use segment 0, [split,C) segment 1 (quant_layer.py:415-419). x is [rows][C]. */
+int edadm_quant_i8(const float* x, int8_t* out, int64_t rows, int64_t C, const float* qp, int64_t split,
+                   void* stream);
+int edadm_quant_f16(const float* x, int64_t ldx, void* out, int64_t ldo, int64_t rows, int64_t C,
+                    const float* qp, float premul, void* stream);
+/* NCHW fp32 -> NHWC (boundary transposes of QuantModel.forward, quant_model.py:69). */
+int edadm_nchw_to_nhwc(const float* x, float* out, int64_t B, int64_t C, int64_t HW, void* stream);
+int edadm_nhwc_to_nchw(const float* x, float* out, int64_t B, int64_t C, int64_t HW, void* stream);
+/* im2col for tiny-Cin convolutions (conv_in, Cin=3/4): NHWC fp32 -> quantised [M][Kpad] i8 */
+int edadm_im2col_quant_i8(const float* x, int8_t* out, int64_t B, int64_t H, int64_t W, int64_t C,
+                          int64_t Kpad, const float* qp, void* stream);
+
+/* ---- K5: GroupNorm (+SiLU) (+quantise) on NHWC -------------------------------------------------
+ * ddim/models/diffusion.py:27-33,121-128; ldm/modules/diffusionmodules/util.py:199-216;
+ * openaimodel.py:201-228.  stats: mean/rstd per (b, group) into stats[B][G][2].
+ * apply: y = (x-mean)*rstd*gamma+beta [* (1+scale[b][c]) + shift[b][c]] [-> silu] then either
+ * fp32 out and/or up to 3 quantised i8 outputs with their own (delta,zp,qmax) (q,k,v convs share
+ * one normalised input, quant_block.py:419-424). */
+int64_t edadm_gn_ws_floats(int64_t B, int64_t HW, int64_t C);
+int edadm_groupnorm_stats(const float* x, float* stats, float* ws, int64_t B, int64_t HW, int64_t C, int64_t G,
+                          float eps, void* stream);
+int edadm_groupnorm_apply(const float* x, const float* stats, const float* gamma, const float* beta,
+                          const float* scale_shift, int64_t B, int64_t HW, int64_t C, int64_t G, int silu,
+                          float* out_f32, int8_t* q0, int8_t* q1, int8_t* q2, const float* qp, int nq,
+                          void* stream);
+/* LayerNorm over the last dim, same output options (ldm/modules/attention.py:222-242). */
+int edadm_layernorm_quant(const float* x, const float* gamma, const float* beta, int64_t rows, int64_t C,
+                          float eps, float* out_f32, int8_t* q0, int8_t* q1, int8_t* q2, const float* qp,
+                          int nq, void* stream);
+/* SiLU / GEGLU producers (quant_block.py:86-116 emb path; attention.py:37-45). */
+int edadm_silu_quant_i8(const float* x, int8_t* out, int64_t n, const float* qp, void* stream);
+int edadm_geglu_quant_i8(const float* x, int8_t* out, int64_t rows, int64_t inner, const float* qp,
+                         void* stream);
+int edadm_silu(const float* x, float* out, int64_t n, void* stream);
+int edadm_add(const float* a, const float* b, float* out, int64_t n, void* stream);
+int edadm_concat_c(const float* a, int64_t Ca, const float* b, int64_t Cb, float* out, int64_t rows,
+                   void* stream);
+int edadm_avgpool2_nhwc(const float* x, float* out, int64_t B, int64_t H, int64_t W, int64_t C, void* stream);
+int edadm_upsample2_nhwc(const float* x, float* out, int64_t B, int64_t H, int64_t W, int64_t C, void* stream);
+
+/* ---- K4: quantised conv / linear on int8 MFMA ---------------------------------------------------
+ * qdiff/quant_layer.py:406-437 at inference: out[m][n] = scale[n]*sum_k a[m][k]*w[n][k] + bias[n]
+ * (+ rowadd[m / rows_per_batch][n]) (+ residual[m][n]) with a = code-128 (int8), w = wcode-zp_w
+ * (int8); the (128-zp_x)*sum_k w term and delta_x*delta_w[n] are folded into bias/scale by the
+ * host.  geom (device-independent ints, 16 of them):
+ *  {mode, B, H, W, Cin, Ho, Wo, KH, KW, stride, pad0, upsample, padval, 0,0,0}
+ *  mode 0: dense rows A[m][lda]; mode 1: implicit-GEMM convolution over NHWC int8 input,
+ *  K ordered [ky][kx][ci]; padval = int8 operand of real zero (zp_x-128). */
+int edadm_qgemm_i8(const int8_t* A, int64_t lda, const int8_t* Wt, int64_t ldw, int64_t M, int64_t N,
+                   int64_t K, const int32_t* geom, const float* scale, const float* bias,
+                   const float* rowadd, int64_t rows_per_batch, const float* residual, int64_t ldr,
+                   float* out, int64_t ldo, void* stream);
+/* Batched f16 NT GEMM for the attention products (integer-valued f16 operands, exact in fp32):
+ * C[b][m][n] = alpha * sum_k A[b][m][k] * B[b][n][k]. quant_block.py:427-446,204-235. */
+int edadm_gemm_f16_nt(const void* A, int64_t lda, int64_t strideA, const void* Bm, int64_t ldb,
+                      int64_t strideB, float* C, int64_t ldc, int64_t strideC, int64_t batch,
+                      int64_t M, int64_t N, int64_t K, float alpha, void* stream);
+/* K6: row softmax + quantise to f16 codes (code - zp); rows x cols fp32 in. */
+int edadm_softmax_quant_f16(const float* s, void* out, int64_t rows, int64_t cols, int64_t ldo,
+                            const float* qp, void* stream);
+/* f16 [b][n][d] (ld) -> [b][d][npad] transpose for the PV product's B operand */
+int edadm_transpose_f16(const void* x, int64_t ldx, int64_t strideX, void* out, int64_t ldo,
+                        int64_t strideO, int64_t batch, int64_t n, int64_t d, void* stream);
+/* weight packing: int4 nibble codes <-> int8 operand (code - zp_row) */
+int edadm_unpack_w4(const uint8_t* packed, const float* zp, int8_t* out, int64_t rows, int64_t cols,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
