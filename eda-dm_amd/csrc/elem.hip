@@ -5,7 +5,7 @@
 #include "../../include/edadm.h"
 
 extern "C" int edadm_abi_version(void) { return 1; }
-extern "C" int64_t edadm_reduce_ws_floats(void) { return 4 * EDADM_RED_BLOCKS + 256; }
+extern "C" int64_t edadm_reduce_ws_floats(void) { return 128 * EDADM_RED_BLOCKS + 256; }
 
 // ------------------------------------------------------------------------------------------ K1
 __device__ __forceinline__ float fq_one(float x, float d, float z, float qmax, float* code) {
@@ -274,9 +274,7 @@ extern "C" int edadm_mse_scores_tensor(const float* x, int64_t n, const float* s
                                        float qmax, float* score, float* ws, void* stream) {
     if (!x || !scale || !zp || !score || !ws || n <= 0 || nc < 1 || nc > MSE_MAXC) return EDADM_EINVAL;
     int g = edadm_grid(n, 256);
-    const int maxg = (int)(4 * EDADM_RED_BLOCKS / nc);
-    if (g > maxg) g = maxg;
-    if (g > 1024) g = 1024;
+    if (g > EDADM_RED_BLOCKS) g = EDADM_RED_BLOCKS;   // ws holds [g][nc] partials, nc <= 128
     hipLaunchKernelGGL(k_mse_tensor, dim3(g), dim3(256), 0, (hipStream_t)stream, x, n, scale, zp, nc, qmax, ws);
     hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, (hipStream_t)stream, ws, g, nc, score,
                        (float)(1.0 / (double)n));

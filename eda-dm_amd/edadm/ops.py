@@ -295,12 +295,37 @@ def qgemm_i8(A, Wt, M, N, K, scale, bias, out, geom=None, lda=None, ldw=None, ro
     return out
 
 
-def gemm_f16_nt(A, lda, strideA, Bm, ldb, strideB, batch, M, N, K, alpha, out=None):
+def gemm_f16_nt(A, lda, strideA, Bm, ldb, strideB, batch, M, N, K, alpha, out=None, inner=1, strideA_i=0,
+                strideB_i=0, ldc=None, strideC=None, strideC_i=0):
+    """C[z] = alpha * A[z] . B[z]^T, z = outer*inner + head (two-level strides, in elements)."""
+    ldc = N if ldc is None else ldc
+    strideC = M * N * inner if strideC is None else strideC
+    if strideC_i == 0 and inner > 1:
+        strideC_i = M * N
     if out is None:
-        out = torch.empty(batch, M, N, dtype=torch.float32, device=A.device)
-    lib.call("edadm_gemm_f16_nt", ctypes.c_void_p(A.data_ptr()), int(lda), int(strideA),
-             ctypes.c_void_p(Bm.data_ptr()), int(ldb), int(strideB), _pf(out), int(N), int(M * N), int(batch), int(M),
-             int(N), int(K), float(alpha), _stream())
+        out = torch.empty(batch * inner, M, N, dtype=torch.float32, device=A.device)
+    lib.call("edadm_gemm_f16_nt", ctypes.c_void_p(A.data_ptr()), int(lda), int(strideA), int(strideA_i),
+             ctypes.c_void_p(Bm.data_ptr()), int(ldb), int(strideB), int(strideB_i), _pf(out), int(ldc), int(strideC),
+             int(strideC_i), int(batch), int(inner), int(M), int(N), int(K), float(alpha), _stream())
+    return out
+
+
+def qgemm_f16(A, Wt, M, N, K, scale, bias, out, geom=None, lda=None, ldw=None, rowadd=None, rows_per_batch=1,
+              residual=None):
+    lda = K if lda is None else lda
+    ldw = K if ldw is None else ldw
+    gptr = ctypes.cast(geom, ctypes.c_void_p) if geom is not None else None
+    lib.call("edadm_qgemm_f16", ctypes.c_void_p(A.data_ptr()), int(lda), ctypes.c_void_p(Wt.data_ptr()), int(ldw),
+             int(M), int(N), int(K), gptr, _pf(scale), _pf(bias), _pf(rowadd), int(rows_per_batch), _pf(residual),
+             int(N), _pf(out), int(N), _stream())
+    return out
+
+
+def conv3x3_f32_smalln(x_nhwc, w, bias):
+    B, H, W, C = x_nhwc.shape
+    N = w.shape[0]
+    out = torch.empty(B, H, W, N, dtype=torch.float32, device=x_nhwc.device)
+    lib.call("edadm_conv3x3_f32_smalln", _pf(x_nhwc), _pf(w), _pf(bias), _pf(out), B, H, W, C, N, _stream())
     return out
 
 
@@ -312,10 +337,13 @@ def softmax_quant_f16(s2d, qp, ldo=None):
     return out
 
 
-def transpose_f16(x, ldx, strideX, batch, n, d, ldo):
-    out = torch.empty(batch, d, ldo, dtype=torch.float16, device=x.device)
+def transpose_f16(x, ldx, strideX, batch, n, d, ldo, out=None, strideO=None):
+    """[b][n][d] (row stride ldx, batch stride strideX) -> [b][d][ldo] with zero padding past n."""
+    if out is None:
+        out = torch.empty(batch, d, ldo, dtype=torch.float16, device=x.device)
+    strideO = d * ldo if strideO is None else strideO
     lib.call("edadm_transpose_f16", ctypes.c_void_p(x.data_ptr()), int(ldx), int(strideX),
-             ctypes.c_void_p(out.data_ptr()), int(ldo), int(d * ldo), int(batch), int(n), int(d), _stream())
+             ctypes.c_void_p(out.data_ptr()), int(ldo), int(strideO), int(batch), int(n), int(d), _stream())
     return out
 
 

@@ -1,0 +1,236 @@
+"""The reconstruction inner loop (H1) shared by block_reconstruction / layer_reconstruction and
+their qdiff_control twins (block_recon.py:13-232, layer_recon.py:13-129 of the reference).
+
+Per iteration (block): quantised forward #1, FP forward #2 (per-module targets), quantised
+forward #3 (per-module outputs, fresh masks), loss = L_block + add_loss * sum_j L_module_j,
+backward, Adam on all AdaRound alphas (lr_w) and all activation deltas (lr_a), cosine to 0.
+
+MI355X-native pieces: fake-quant fwd/bwd (K1), AdaRound fwd/bwd (K2), loss (K7), one fused Adam
+launch over a flat parameter slab per group (K8), stochastic input mixing (K10) are HIP kernels;
+cached activations stay in HBM; the fp32 contraction inside the block graph is torch's for now.
+"""
+import math
+import random
+
+import torch
+
+from . import ops, dist as edist
+from qdiff.quant_layer import QuantModule, lp_loss, _mask_rng
+from qdiff.adaptive_rounding import AdaRoundQuantizer
+from qdiff.utils import AttentionMap
+
+
+class LinearTempDecay:
+    def __init__(self, t_max: int, rel_start_decay: float = 0.2, start_b: int = 10, end_b: int = 2):
+        self.t_max = t_max
+        self.start_decay = rel_start_decay * t_max
+        self.start_b, self.end_b = start_b, end_b
+
+    def __call__(self, t):
+        if t < self.start_decay:
+            return self.start_b
+        rel_t = (t - self.start_decay) / (self.t_max - self.start_decay)
+        return self.end_b + (self.start_b - self.end_b) * max(0.0, (1 - rel_t))
+
+
+class LossFunction:
+    """rec loss (+ the AdaRound rounding regulariser, which the reference switches off with
+    round_loss='none', block_recon.py:119, but keeps in the API)."""
+
+    def __init__(self, block, round_loss='relaxation', weight=1., rec_loss='mse', max_count=2000, b_range=(10, 2),
+                 decay_start=0.0, warmup=0.0, p=2.):
+        self.block = self.layer = block
+        self.round_loss, self.weight, self.rec_loss = round_loss, weight, rec_loss
+        self.loss_start = max_count * warmup
+        self.p, self.iters = p, max_count
+        self.temp_decay = LinearTempDecay(max_count, rel_start_decay=warmup + (1 - warmup) * decay_start,
+                                          start_b=b_range[0], end_b=b_range[1])
+        self.count = 0
+
+    def __call__(self, pred, tgt, grad=None):
+        self.count += 1
+        if self.rec_loss == 'mse':
+            rec = lp_loss(pred, tgt, p=self.p)
+        elif self.rec_loss == 'fisher_diag':
+            rec = ((pred - tgt).pow(2) * grad.pow(2)).sum(1).mean()
+        elif self.rec_loss == 'fisher_full':
+            a, g = (pred - tgt).abs(), grad.abs()
+            rec = (torch.sum(a * g, (1, 2, 3)).view(-1, 1, 1, 1) * a * g).mean() / 100
+        else:
+            raise ValueError('Not supported reconstruction loss function: {}'.format(self.rec_loss))
+        b = self.temp_decay(self.count)
+        if self.count < self.loss_start or self.round_loss == 'none':
+            rnd = 0
+        elif self.round_loss == 'relaxation':
+            rnd = 0
+            mods = [self.block] if isinstance(self.block, QuantModule) else \
+                [m for m in self.block.modules() if isinstance(m, QuantModule)]
+            for m in mods:
+                rv = m.weight_quantizer.get_soft_targets()
+                rnd = rnd + self.weight * (1 - ((rv - .5).abs() * 2).pow(b)).sum()
+        else:
+            raise NotImplementedError
+        return rec + rnd
+
+
+class FusedAdam:
+    """torch.optim.Adam + CosineAnnealingLR(T_max, eta_min=0) for a parameter group, as ONE HIP
+    launch per step: the parameters are re-homed as views of a flat slab (so are their grads)."""
+
+    def __init__(self, params, lr, t_max, betas=(0.9, 0.999)):
+        self.params = list(params)
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.empty(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        o = 0
+        for p in self.params:
+            k = p.numel()
+            self.flat[o:o + k].copy_(p.data.reshape(-1))
+            p.data = self.flat[o:o + k].view(p.shape)
+            p.grad = self.grad[o:o + k].view(p.shape)
+            o += k
+        self.lr0, self.t_max, self.betas = lr, t_max, betas
+        self.t = 0
+        self.hyper = torch.zeros(4, dtype=torch.float32, device=dev)
+
+    def zero_grad(self):
+        self.grad.zero_()
+        o = 0
+        for p in self.params:          # autograd may have replaced .grad; keep it pointing into the slab
+            k = p.numel()
+            if p.grad is None or p.grad.data_ptr() != self.grad[o:o + k].data_ptr():
+                p.grad = self.grad[o:o + k].view(p.shape)
+            o += k
+
+    def step(self):
+        lr = self.lr0 * (1 + math.cos(math.pi * self.t / self.t_max)) / 2
+        self.t += 1
+        b1, b2 = self.betas
+        self.hyper.copy_(torch.tensor([lr / (1 - b1 ** self.t), math.sqrt(1 - b2 ** self.t), b1, b2]))
+        ops.adam_step(self.flat, self.grad, self.m, self.v, self.hyper)
+
+
+def _as_param(q):
+    q.delta = torch.nn.Parameter(q.delta.detach().clone())
+
+
+def _attention_quantizers(module):
+    """q, k, v, w activation quantizers owned by an attention wrapper, in the reference's order."""
+    from qdiff.quant_block import QuantAttnBlock, QuantAttentionBlock, QuantBasicTransformerBlock
+    names = ("act_quantizer_q", "act_quantizer_k", "act_quantizer_v", "act_quantizer_w")
+    if isinstance(module, QuantAttentionBlock):
+        qk, smv = module.attention.qkv_matmul, module.attention.smv_matmul
+        return [qk.act_quantizer_q, qk.act_quantizer_k, smv.act_quantizer_v, smv.act_quantizer_w]
+    if isinstance(module, QuantAttnBlock):
+        return [getattr(module, n) for n in names]
+    if isinstance(module, QuantBasicTransformerBlock):
+        return [getattr(a, n) for a in (module.attn1, module.attn2) for n in names]
+    return []
+
+
+def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000, weight=0.01, opt_mode='mse',
+                asym=False, b_range=(20, 2), warmup=0.0, act_quant=False, lr_a=4e-5, lr_w=1e-2, p=2.0,
+                input_prob=1.0, keep_gpu=True, recon_w=False, recon_a=False, add_loss=0.0, cache_batch=32,
+                batch_transform=None, control=False, save_fn=None):
+    from qdiff.quant_block import BaseQuantBlock
+    from qdiff.data_utils import save_inp_oup_data
+    save_fn = save_fn or save_inp_oup_data
+    unit.set_quant_state(True, act_quant)
+    round_mode = 'learned_hard_sigmoid'
+    hooks, w_para, a_para, trained_aq = [], [], [], []
+    modules = list(unit.modules()) if is_block else [unit]
+    for module in modules:
+        if isinstance(module, QuantModule):
+            if is_block:
+                hooks.append(AttentionMap(module))
+            if module.split == 0 or (control and not is_block):
+                module.weight_quantizer = AdaRoundQuantizer(uaq=module.weight_quantizer, round_mode=round_mode,
+                                                            weight_tensor=module.org_weight.data)
+                wqs = [module.weight_quantizer]
+            else:
+                module.weight_quantizer = AdaRoundQuantizer(
+                    uaq=module.weight_quantizer, round_mode=round_mode,
+                    weight_tensor=module.org_weight.data[:, :module.split, ...])
+                module.weight_quantizer_0 = AdaRoundQuantizer(
+                    uaq=module.weight_quantizer_0, round_mode=round_mode,
+                    weight_tensor=module.org_weight.data[:, module.split:, ...])
+                wqs = [module.weight_quantizer, module.weight_quantizer_0]
+            if recon_w:
+                for q in wqs:
+                    q.soft_targets = True
+                    w_para.append(q.alpha)
+        if isinstance(module, (QuantModule, BaseQuantBlock)):
+            aqs = _attention_quantizers(module) if act_quant else []
+            if act_quant and module.act_quantizer.delta is not None:
+                aqs = aqs + [module.act_quantizer]
+                if module.split != 0 and not (control and not is_block):
+                    aqs.append(module.act_quantizer_0)
+            for q in aqs:
+                _as_param(q)
+                if recon_a:
+                    a_para.append(q.delta)
+                    q.is_training = True
+                    trained_aq.append(q)
+    w_opt = FusedAdam(w_para, lr_w, iters) if w_para else None
+    a_opt = FusedAdam(a_para, lr_a, iters) if a_para else None
+    loss_func = LossFunction(unit, round_loss='none', weight=weight, max_count=iters, rec_loss=opt_mode,
+                             b_range=b_range, decay_start=0, warmup=warmup, p=p)
+
+    resblock, cached_inps, cached_outs = save_fn(model, unit, cali_data, asym, act_quant, batch_size=cache_batch,
+                                                 input_prob=True, keep_gpu=keep_gpu)
+    sz = cached_outs.size(0)
+    model.block_count = model.block_count + 1
+    eng, model.engine = getattr(model, "engine", None), None
+    for _ in range(iters):
+        idx = random.sample(range(sz), batch_size)
+        idx_t = torch.tensor(idx, device=cached_outs.device)
+        cur_out = cached_outs[idx_t]
+        if resblock:
+            cur_inp, cur_sym = cached_inps[0][0][idx_t], cached_inps[1][0][idx_t]
+            temb_inp, temb_sym = cached_inps[0][1][idx_t], cached_inps[1][1][idx_t]
+        else:
+            cur_inp, cur_sym = cached_inps[0][idx_t], cached_inps[1][idx_t]
+        if input_prob < 1.0:
+            cur_inp = ops.mix_where(cur_inp.contiguous(), cur_sym.contiguous(), input_prob, seed=_mask_rng.getrandbits(62))
+        elif is_block:
+            cur_inp = cur_sym                 # block_recon.py:144-145 (the layer loop keeps cur_inp)
+        for o in (w_opt, a_opt):
+            if o:
+                o.zero_grad()
+        args_q = (cur_inp, temb_inp) if resblock else (cur_inp,)
+        out_quant = unit(*args_q)
+        m_loss = 0.0
+        if is_block and hooks:
+            args_fp = (cur_sym, temb_sym) if resblock else (cur_sym,)
+            unit.set_quant_state(False, False)
+            with torch.no_grad():
+                unit(*args_fp)
+            module_r = [h.out for h in hooks]
+            unit.set_quant_state(True, act_quant)
+            unit(*args_q)
+            module_q = [h.out for h in hooks]
+            for j in range(len(module_r) - 1):
+                m_loss = m_loss + lp_loss(module_q[j], module_r[j], p=2)
+        loss = loss_func(out_quant, cur_out) + add_loss * m_loss
+        loss.backward()
+        for o in (w_opt, a_opt):
+            if o:
+                o.step()
+    model.engine = eng
+    for module in modules:
+        if isinstance(module, QuantModule):
+            module.weight_quantizer.soft_targets = False
+            module.act_quantizer.is_training = False
+            if module.split != 0 and hasattr(module, "weight_quantizer_0"):
+                if isinstance(module.weight_quantizer_0, AdaRoundQuantizer):
+                    module.weight_quantizer_0.soft_targets = False
+                module.act_quantizer_0.is_training = False
+    for q in trained_aq:
+        q.is_training = False
+    for h in hooks:
+        h.remove()
+    # replicas stay bit-identical: rank 0's learned parameters win (no-op on one GPU)
+    edist.broadcast_params([p for p in w_para + a_para])

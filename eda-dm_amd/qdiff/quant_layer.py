@@ -1,0 +1,359 @@
+"""Quantizers and the quantised layer — API of the reference's qdiff/quant_layer.py
+(`UniformAffineQuantizer` :36-357, `QuantModule` :360-446, `lp_loss` :26-33, `round_ste` :19-23),
+re-implemented on the HIP kernels of libedadm.so:
+
+  * fake-quant forward / STE + LSQ backward ........ edadm_fake_quant_fwd / _bwd       (K1)
+  * MSE clip-range search (the O(numel x 100) part) . edadm_mse_scores_tensor/_channel   (K3)
+  * reconstruction loss ............................ edadm_lp_loss_fwd / _bwd          (K7)
+
+Device tensors only: there is no CPU code path (ops raise on host tensors).
+"""
+import logging
+import random
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from edadm import ops
+
+logger = logging.getLogger(__name__)
+_mask_rng = random.Random(0x5EEDED)      # seeds of the in-kernel mask RNG; separate from `random`
+
+
+def seed_mask_rng(seed):
+    _mask_rng.seed(seed)
+
+
+class StraightThrough(nn.Module):
+    def __init__(self, channel_num: int = 1):
+        super().__init__()
+
+    def forward(self, input):
+        return input
+
+
+def round_ste(x):
+    return (x.round() - x).detach() + x
+
+
+# ----------------------------------------------------------------------------- K7
+class _LpLoss2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, tgt):
+        pred, tgt = pred.contiguous(), tgt.contiguous()
+        ctx.save_for_backward(pred, tgt)
+        return ops.lp_loss_fwd(pred, tgt).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, tgt = ctx.saved_tensors
+        return ops.lp_loss_bwd(pred, tgt, g.reshape(1).contiguous().float()), None
+
+
+def lp_loss(pred, tgt, p=2.0, reduction='none'):
+    """sum over dim 1, mean over the rest (reduction 'none') or plain mean."""
+    if p == 2.0 and reduction == 'none':
+        return _LpLoss2.apply(pred, tgt.detach())
+    e = (pred - tgt).abs().pow(p)
+    return e.sum(1).mean() if reduction == 'none' else e.mean()
+
+
+# ----------------------------------------------------------------------------- K1
+class _FakeQuantTensor(torch.autograd.Function):
+    """Per-tensor delta (activations): x and delta receive gradients."""
+
+    @staticmethod
+    def forward(ctx, x, delta, zp, qmax, prob, seed, u):
+        x = x.contiguous()
+        d1, z1 = delta.detach().reshape(1).contiguous(), zp.detach().reshape(1).float().contiguous()
+        ctx.save_for_backward(x, d1, z1, u)
+        ctx.meta = (qmax, prob, seed, delta.shape)
+        return ops.fake_quant_fwd(x, d1, z1, qmax, u=u, prob=prob, seed=seed)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, d1, z1, u = ctx.saved_tensors
+        qmax, prob, seed, dshape = ctx.meta
+        gx, gd = ops.fake_quant_bwd(gy.contiguous(), x, d1, z1, qmax, u=u, prob=prob, seed=seed,
+                                    need_gx=ctx.needs_input_grad[0])
+        return gx, gd.reshape(dshape) if ctx.needs_input_grad[1] else None, None, None, None, None, None
+
+
+class _FakeQuantChannel(torch.autograd.Function):
+    """Per-channel delta (weights): constants in the reconstruction loop; straight-through gradient."""
+
+    @staticmethod
+    def forward(ctx, x, delta, zp, qmax):
+        x = x.contiguous()
+        inner = x[0].numel()
+        return ops.fake_quant_fwd(x, delta.reshape(-1).contiguous(), zp.reshape(-1).float().contiguous(), qmax,
+                                  inner=inner)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return gy, None, None, None
+
+
+def _first_argmin(scores, dim=0):
+    """Index of the FIRST minimum along `dim` (the reference keeps the earliest candidate on ties:
+    strict `<` in the sequential search, argmin on CPU)."""
+    n = scores.shape[dim]
+    shape = [1] * scores.dim()
+    shape[dim] = n
+    idx = torch.arange(n, device=scores.device).view(shape).expand_as(scores)
+    mn = scores.min(dim=dim, keepdim=True)[0]
+    return torch.where(scores == mn, idx, torch.full_like(idx, n)).min(dim=dim)[0]
+
+
+class UniformAffineQuantizer(nn.Module):
+    """Uniform affine quantizer with MSE (p=2.4) clip search, EMA range tracking for activations
+    (`leaf_param`), and the dropout-like `prob` mixing during reconstruction."""
+
+    def __init__(self, n_bits: int = 8, symmetric: bool = False, channel_wise: bool = False,
+                 scale_method: str = 'max', leaf_param: bool = False, always_zero: bool = False, prob: float = 1.0):
+        super().__init__()
+        self.sym = symmetric
+        self.bitwidth_refactor(n_bits)
+        self.delta = None
+        self.zero_point = None
+        self.inited = False
+        self.leaf_param = leaf_param
+        self.channel_wise = channel_wise
+        self.scale_method = scale_method
+        self.running_stat = False
+        self.always_zero = always_zero
+        if self.leaf_param:
+            self.x_min, self.x_max = None, None
+        self.running_min = None
+        self.running_max = None
+        self.one_side_dist = None
+        self.num = 100
+        self.eps = torch.tensor(1e-8, dtype=torch.float32)
+        self.prob = prob
+        self.is_training = False
+        self.injected_uniform = None     # parity tests: uniforms that replace the in-kernel RNG
+
+    def set_inited(self, inited: bool = True):
+        self.inited = inited
+
+    def bitwidth_refactor(self, refactored_bit: int):
+        self.n_bits = refactored_bit
+        self.n_levels = 2 ** self.n_bits
+
+    # -- range tracking / qparams (O(1) work: torch device ops in the reference's op order)
+    def update_quantize_range(self, x_min, x_max):
+        if self.running_min is None:
+            self.running_min, self.running_max = x_min, x_max
+        self.running_min = 0.1 * x_min + 0.9 * self.running_min
+        self.running_max = 0.1 * x_max + 0.9 * self.running_max
+        return self.running_min, self.running_max
+
+    def calculate_qparams(self, min_val, max_val):
+        quant_min, quant_max = 0, self.n_levels - 1
+        min_neg = torch.min(min_val, torch.zeros_like(min_val))
+        max_pos = torch.max(max_val, torch.zeros_like(max_val))
+        scale = (max_pos - min_neg) / float(quant_max - quant_min)
+        scale = torch.max(scale, self.eps.to(scale.device))
+        zero_point = quant_min - torch.round(min_neg / scale)
+        return scale, torch.clamp(zero_point, quant_min, quant_max)
+
+    def quantize(self, x, x_max, x_min):
+        delta, zp = self.calculate_qparams(x_min, x_max)
+        inner = x[0].numel() if self.channel_wise else 1
+        return ops.fake_quant_fwd(x.detach().contiguous(), delta.reshape(-1).contiguous(),
+                                  zp.reshape(-1).contiguous(), self.n_levels - 1, inner=inner)
+
+    # -- searches: candidate grids are O(100) torch ops, the scores are one HIP pass over x
+    def _scores(self, x, scale, zp):
+        """scale/zp: [nc] (per tensor) or [nc][rows] (per channel) -> scores of the same shape."""
+        qmax = self.n_levels - 1
+        if not self.channel_wise:
+            xs = x.detach().reshape(-1).contiguous()
+            out = []
+            for i in range(0, scale.numel(), 128):
+                out.append(ops.mse_scores_tensor(xs, scale[i:i + 128].contiguous(), zp[i:i + 128].contiguous(), qmax))
+            return torch.cat(out)
+        x2 = x.detach().reshape(x.shape[0], -1).contiguous()
+        out = []
+        for i in range(0, scale.shape[0], 4096):
+            out.append(ops.mse_scores_channel(x2, scale[i:i + 4096].contiguous(), zp[i:i + 4096].contiguous(), qmax))
+        return torch.cat(out)
+
+    def _aminmax(self, x):
+        if self.channel_wise:
+            return torch.aminmax(torch.flatten(x.detach(), 1), dim=1)
+        mm = ops.minmax(x.detach().reshape(-1).contiguous())
+        return mm[0], mm[1]
+
+    def perform_1D_search(self, x):
+        x_min, x_max = self._aminmax(x)
+        xrange = torch.max(x_min.abs(), x_max)
+        steps = torch.arange(1, self.num + 1, device=x.device)
+        if not self.channel_wise:
+            thres = xrange / self.num * steps
+            new_min = torch.zeros_like(thres) if self.one_side_dist == "pos" else -thres
+            new_max = torch.zeros_like(thres) if self.one_side_dist == "neg" else thres
+            scale = (new_max - new_min) / float(self.n_levels - 1)
+            scale = torch.max(scale, self.eps.to(x.device))
+            zp = torch.clamp(-torch.round(new_min / scale), 0, self.n_levels - 1)
+        else:
+            mins, maxs, sc, zps = [], [], [], []
+            for i in range(1, self.num + 1):
+                thres = xrange / self.num * i
+                nmin = torch.zeros_like(x_min) if self.one_side_dist == "pos" else -thres
+                nmax = torch.zeros_like(x_max) if self.one_side_dist == "neg" else thres
+                s, z = self.calculate_qparams(nmin, nmax)
+                mins.append(nmin), maxs.append(nmax), sc.append(s), zps.append(z)
+            new_min, new_max, scale, zp = (torch.stack(t) for t in (mins, maxs, sc, zps))
+        ind = _first_argmin(self._scores(x, scale, zp), 0)
+        if not self.channel_wise:
+            return new_min[ind], new_max[ind]
+        return new_min.gather(0, ind[None])[0], new_max.gather(0, ind[None])[0]
+
+    def perform_2D_search(self, x):
+        x_min, x_max = self._aminmax(x)
+        if self.channel_wise:
+            x_max = torch.max(x_max, torch.zeros_like(x_max))
+            x_min = torch.min(x_min, torch.zeros_like(x_min))
+        xrange = x_max - x_min
+        mins, maxs, sc, zps = [], [], [], []
+        for i in range(1, self.num + 1):
+            tmp_max = xrange / self.num * i
+            tmp_delta = (tmp_max - torch.zeros_like(x_min)) / (2 ** self.n_bits - 1)
+            for zp in range(0, self.n_levels):
+                nmin, nmax = torch.zeros_like(x_min) - zp * tmp_delta, tmp_max - zp * tmp_delta
+                s, z = self.calculate_qparams(nmin, nmax)
+                mins.append(nmin), maxs.append(nmax), sc.append(s), zps.append(z)
+        new_min, new_max, scale, zp = (torch.stack(t) for t in (mins, maxs, sc, zps))
+        ind = _first_argmin(self._scores(x, scale, zp), 0)
+        if not self.channel_wise:
+            return new_min[ind], new_max[ind]
+        return new_min.gather(0, ind[None])[0], new_max.gather(0, ind[None])[0]
+
+    def get_x_min_x_max(self, x):
+        if self.scale_method != "mse":
+            raise NotImplementedError
+        if self.one_side_dist is None:
+            self.one_side_dist = "pos" if x.min() >= 0.0 else "neg" if x.max() <= 0.0 else "no"
+        if self.one_side_dist != "no" or self.sym:
+            best_min, best_max = self.perform_1D_search(x)
+        else:
+            best_min, best_max = self.perform_2D_search(x)
+        if self.leaf_param:
+            return self.update_quantize_range(best_min, best_max)
+        return best_min, best_max
+
+    def init_quantization_scale_1(self, x, channel_wise=False):
+        with torch.no_grad():
+            x_min, x_max = self.get_x_min_x_max(x)
+            delta, zero_point = self.calculate_qparams(x_min, x_max)
+        if channel_wise:
+            shp = [1] * x.dim()
+            shp[0] = x.shape[0]
+            delta, zero_point = delta.reshape(shp), zero_point.reshape(shp)
+        return delta, zero_point
+
+    def forward(self, x):
+        if self.inited is False:
+            if self.scale_method != 'mse':
+                # the shipped scripts only use 'mse' (sample_diffusion_*.py); 'max' is not built
+                raise NotImplementedError
+            delta, self.zero_point = self.init_quantization_scale_1(x, self.channel_wise)
+            self.delta = nn.Parameter(delta) if self.leaf_param else delta
+        qmax = self.n_levels - 1
+        if self.channel_wise:
+            return _FakeQuantChannel.apply(x, self.delta, self.zero_point, qmax)
+        prob, seed, u = 1.0, 0, None
+        if self.is_training and self.prob < 1.0:
+            prob = self.prob
+            if self.injected_uniform is not None:
+                u = self.injected_uniform(x).contiguous()
+            else:
+                seed = _mask_rng.getrandbits(62)
+        return _FakeQuantTensor.apply(x, self.delta, self.zero_point, qmax, prob, seed, u)
+
+    def extra_repr(self):
+        return 'bit={n_bits}, scale_method={scale_method}, symmetric={sym}, channel_wise={channel_wise},' \
+               ' leaf_param={leaf_param}'.format(**self.__dict__)
+
+
+class QuantModule(nn.Module):
+    """Conv2d / Conv1d / Linear with weight and activation quantizers, optional channel split of
+    the input (the UNet skip concatenation gets one quantizer per half, quant_layer.py:406-427)."""
+
+    def __init__(self, org_module, weight_quant_params: dict = {}, act_quant_params: dict = {},
+                 disable_act_quant: bool = False, act_quant_mode: str = 'qdiff'):
+        super().__init__()
+        self.weight_quant_params = weight_quant_params
+        self.act_quant_params = act_quant_params
+        if isinstance(org_module, (nn.Conv2d, nn.Conv1d)):
+            self.fwd_kwargs = dict(stride=org_module.stride, padding=org_module.padding,
+                                   dilation=org_module.dilation, groups=org_module.groups)
+            self.fwd_func = F.conv2d if isinstance(org_module, nn.Conv2d) else F.conv1d
+        else:
+            self.fwd_kwargs = dict()
+            self.fwd_func = F.linear
+        self.weight = org_module.weight
+        self.org_weight = org_module.weight.data.clone()
+        if org_module.bias is not None:
+            self.bias = org_module.bias
+            self.org_bias = org_module.bias.data.clone()
+        else:
+            self.bias = None
+            self.org_bias = None
+        self.use_weight_quant = False
+        self.use_act_quant = False
+        self.act_quant_mode = act_quant_mode
+        self.disable_act_quant = disable_act_quant
+        self.weight_quantizer = UniformAffineQuantizer(**self.weight_quant_params)
+        if self.act_quant_mode == 'qdiff':
+            self.act_quantizer = UniformAffineQuantizer(**self.act_quant_params)
+        self.split = 0
+        self.activation_function = StraightThrough()
+        self.ignore_reconstruction = False
+        self.extra_repr = org_module.extra_repr
+
+    def _apply(self, fn, *a, **k):
+        # org_weight / org_bias are plain tensors in the reference; keep them on the module's device
+        super()._apply(fn, *a, **k)
+        self.org_weight = fn(self.org_weight)
+        if self.org_bias is not None:
+            self.org_bias = fn(self.org_bias)
+        return self
+
+    def forward(self, input, split: int = 0):
+        if split != 0 and self.split != 0:
+            assert split == self.split
+        elif split != 0:
+            logger.info(f"split at {split}!")
+            self.split = split
+            self.set_split()
+        if not self.disable_act_quant and self.use_act_quant:
+            if self.split != 0:
+                input = torch.cat([self.act_quantizer(input[:, :self.split]),
+                                   self.act_quantizer_0(input[:, self.split:])], dim=1)
+            else:
+                input = self.act_quantizer(input)
+        if self.use_weight_quant:
+            if self.split != 0:
+                weight = torch.cat([self.weight_quantizer(self.weight[:, :self.split, ...]),
+                                    self.weight_quantizer_0(self.weight[:, self.split:, ...])], dim=1)
+            else:
+                weight = self.weight_quantizer(self.weight)
+            bias = self.bias
+        else:
+            weight, bias = self.org_weight, self.org_bias
+        # the fp32 contraction of the calibration graph: torch (MIOpen / rocBLAS) for now — see
+        # DESIGN.md "H1 contraction"; the sampling path never comes here (edadm/engine.py)
+        out = self.fwd_func(input, weight, bias, **self.fwd_kwargs)
+        return self.activation_function(out)
+
+    def set_quant_state(self, weight_quant: bool = False, act_quant: bool = False):
+        self.use_weight_quant = weight_quant
+        self.use_act_quant = act_quant
+
+    def set_split(self):
+        self.weight_quantizer_0 = UniformAffineQuantizer(**self.weight_quant_params)
+        if self.act_quant_mode == 'qdiff':
+            self.act_quantizer_0 = UniformAffineQuantizer(**self.act_quant_params)

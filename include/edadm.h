@@ -151,10 +151,23 @@ int edadm_qgemm_i8(const int8_t* A, int64_t lda, const int8_t* Wt, int64_t ldw, 
                    const float* rowadd, int64_t rows_per_batch, const float* residual, int64_t ldr,
                    float* out, int64_t ldo, void* stream);
 /* Batched f16 NT GEMM for the attention products (integer-valued f16 operands, exact in fp32):
- * C[b][m][n] = alpha * sum_k A[b][m][k] * B[b][n][k]. quant_block.py:427-446,204-235. */
-int edadm_gemm_f16_nt(const void* A, int64_t lda, int64_t strideA, const void* Bm, int64_t ldb,
-                      int64_t strideB, float* C, int64_t ldc, int64_t strideC, int64_t batch,
-                      int64_t M, int64_t N, int64_t K, float alpha, void* stream);
+ * C[z][m][n] = alpha * sum_k A[z][m][k] * B[z][n][k], z = outer*inner + head with two-level
+ * element strides (outer = batch sample, inner = attention head inside a [B][N][heads*d] tensor).
+ * quant_block.py:427-446,204-235; openaimodel.py:384-406. */
+int edadm_gemm_f16_nt(const void* A, int64_t lda, int64_t strideA, int64_t strideA_i, const void* Bm,
+                      int64_t ldb, int64_t strideB, int64_t strideB_i, float* C, int64_t ldc,
+                      int64_t strideC, int64_t strideC_i, int64_t batch, int64_t inner, int64_t M,
+                      int64_t N, int64_t K, float alpha, void* stream);
+/* edadm_qgemm_i8's contract with f16 operands (a = code - zp_x, w = wcode - zp_w, exact integers):
+ * for layers whose integer weights do not fit int8 (8-bit weights whose zero point is 127). */
+int edadm_qgemm_f16(const void* A, int64_t lda, const void* Wt, int64_t ldw, int64_t M, int64_t N,
+                    int64_t K, const int32_t* geom, const float* scale, const float* bias,
+                    const float* rowadd, int64_t rows_per_batch, const float* residual, int64_t ldr,
+                    float* out, int64_t ldo, void* stream);
+/* fp32 3x3 / pad-1 convolution with few output channels (the network's last layer, whose
+ * activation quantizer is disabled, quant_model.py:90-95): x NHWC fp32, w [N][3][3][C] fp32. */
+int edadm_conv3x3_f32_smalln(const float* x, const float* w, const float* bias, float* out, int64_t B,
+                             int64_t H, int64_t W, int64_t C, int64_t N, void* stream);
 /* K6: row softmax + quantise to f16 codes (code - zp); rows x cols fp32 in. */
 int edadm_softmax_quant_f16(const float* s, void* out, int64_t rows, int64_t cols, int64_t ldo,
                             const float* qp, void* stream);

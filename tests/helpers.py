@@ -1,0 +1,69 @@
+"""Test helpers: rebuild the tiny fixture networks in the product's module classes."""
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+WQ4 = dict(n_bits=4, symmetric=True, channel_wise=True, scale_method="mse")
+AQ8 = dict(n_bits=8, symmetric=True, channel_wise=False, scale_method="mse", leaf_param=True, prob=0.5)
+
+
+def sub_sd(g, prefix):
+    return {k[len(prefix):]: torch.as_tensor(np.asarray(g[k])) for k in g.files if k.startswith(prefix)}
+
+
+def build_cifar(g):
+    from edadm.nets.ddpm_unet import Model
+    cfg = SimpleNamespace(
+        model=SimpleNamespace(type="simple", in_channels=3, out_ch=3, ch=int(g["cfg/ch"]),
+                              ch_mult=[int(v) for v in g["cfg/ch_mult"]], num_res_blocks=int(g["cfg/nres"]),
+                              attn_resolutions=[int(v) for v in g["cfg/attn"]], dropout=0.0, resamp_with_conv=True),
+        data=SimpleNamespace(image_size=int(g["cfg/res"])),
+        diffusion=SimpleNamespace(num_diffusion_timesteps=1000))
+    m = Model(cfg)
+    m.load_state_dict(sub_sd(g, "sd/"))
+    return m.eval()
+
+
+def build_ldm(g):
+    from edadm.nets.ldm_unet import UNetModel
+    kw = {}
+    for k in g.files:
+        if k.startswith("cfg/"):
+            v = g[k]
+            kw[k[4:]] = v.tolist() if v.ndim else v.item()
+    m = UNetModel(**kw)
+    m.load_state_dict(sub_sd(g, "sd/"))
+    return m.eval()
+
+
+def splits_from_golden(g, prefix="qp/"):
+    """split of a skip conv = number of input channels its first act quantizer covers; the
+    fixtures do not store it, but every split layer has a `weight_quantizer_0` whose delta is
+    per-output-channel, so the split comes from the network structure: set by one FP forward."""
+    return None
+
+
+def quantize_like_reference(model, g, kind, split=True):
+    """QuantModel wrapped and configured exactly as the fixture generator did, with the
+    reference's own deltas / zero points loaded."""
+    from qdiff import QuantModel
+    from edadm.state import load_quant_state
+    qnn = QuantModel(model, WQ4, AQ8, sm_abit=8)
+    qnn.cuda().eval()
+    qnn.set_quant_state(False, False)
+    qnn.set_first_last_layer_to_8bit()
+    qnn.disable_network_output_quantization()
+    if kind == "cifar":
+        qnn.model.config.split_shortcut = split
+    else:
+        qnn.set_grad_ckpt(False)
+        qnn.model.split_shortcut = split
+    x = torch.as_tensor(g["x"]).cuda()
+    t = torch.as_tensor(g["t"]).cuda()
+    ctx = torch.as_tensor(g["ctx"]).cuda() if "ctx" in g.files else None
+    with torch.no_grad():
+        out_fp = qnn(x[:2], t[:2], None if ctx is None else ctx[:2])     # FP pass: creates the split quantizers
+    qnn.cuda()
+    n = load_quant_state(qnn, {k: g[k] for k in g.files if k.startswith("qp/")}, prefix="qp/")
+    return qnn, (x, t, ctx), n

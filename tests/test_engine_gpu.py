@@ -1,0 +1,46 @@
+"""-m gpu: the quantised UNet forward (H2).  Two product paths are checked against the reference's
+own outputs (golden g13_*): the fake-quant module graph (calibration-time forward, HIP K1/K2 +
+torch contraction) and the frozen int8 executor (all-HIP).  Tolerance: the reference accumulates
+fp32 products of de-quantised operands, the executor accumulates exact integers and scales once;
+per-layer that is ~1e-6 relative, but an activation that lands within that distance of a rounding
+boundary flips one integer code and moves downstream values by one quantisation step, so the
+whole-network bound is stated in units of the output's own range."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import build_cifar, build_ldm, quantize_like_reference
+
+pytestmark = pytest.mark.gpu
+
+
+def _cmp(name, got, ref, tol_max, tol_mean):
+    got = got.detach().cpu().numpy().astype(np.float64)
+    rng = np.abs(ref).max()
+    err = np.abs(got - ref)
+    print("%s: max err %.3e (%.2e of range), mean err %.3e" % (name, err.max(), err.max() / rng, err.mean()))
+    assert err.max() <= tol_max * rng and err.mean() <= tol_mean * rng, name
+
+
+@pytest.mark.parametrize("kind", ["cifar", "imagenet", "church"])
+def test_quantised_forward_matches_reference(golden, kind):
+    g = golden("g13_cifar_unet" if kind == "cifar" else "g13_ldm_%s" % kind)
+    model = build_cifar(g) if kind == "cifar" else build_ldm(g)
+    qnn, (x, t, ctx), n = quantize_like_reference(model, g, "cifar" if kind == "cifar" else "ldm")
+    assert n == len([k for k in g.files if k.startswith("qp/") and k.endswith("/delta")])
+    with torch.no_grad():
+        _cmp("fp graph", qnn(x, t, ctx), g["out_fp"], 1e-4, 1e-5)
+        qnn.set_quant_state(True, False)
+        _cmp("weight-quant graph", qnn(x, t, ctx), g["out_wq"], 2e-3, 2e-4)
+        qnn.set_quant_state(True, True)
+        fq = qnn(x, t, ctx)
+        _cmp("fake-quant graph", fq, g["out_q"], 5e-2, 5e-3)
+        eng = qnn.freeze()
+        modes = {}
+        for L in eng.layers.values():
+            modes[L.mode] = modes.get(L.mode, 0) + 1
+        print("engine layer modes:", modes)
+        out = qnn(x, t, ctx)
+        assert qnn.engine is not None
+        _cmp("int8 engine vs reference", out, g["out_q"], 5e-2, 5e-3)
+        _cmp("int8 engine vs fake-quant graph", out, fq.cpu().numpy(), 5e-2, 5e-3)
