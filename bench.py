@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py — images/sec of W4A8 LDM-4 ImageNet 256x256 sampling on MI355X (BASELINE.json metric).
+
+A "step" = one batch of 50 images taken through the whole quantised sampling path: 20 DDIM steps,
+classifier-free guidance 3.0 (100 UNet rows per call), on the frozen int8 executor with the UNet
+forward replayed from a HIP graph.  Inputs (noise latents, class-embedding context) are resident
+in HBM before the timed region; weights are random-init LDM-4 (cin256-v2 shapes, 400.9 M params),
+quantised W4A8 by the build's own scale-initialisation path (no checkpoint / dataset is available).
+The first-stage VQ decoder (FP32, never quantised, SURVEY.md §8f-3 "next") is not part of the hot
+path and is outside the timed region.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "eda-dm_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+I8_PEAK_TFLOPS = 5033.0      # gfx950 dense int8 MFMA: 2048 op/clk/SIMD x 1024 SIMDs x 2.4 GHz (MI355X_MICROARCH.md)
+UNET_GFLOP_PER_ROW = 208.4   # conv/linear/attention matmul FLOPs per sample-forward
+
+LDM4 = dict(image_size=64, in_channels=3, out_channels=3, model_channels=192, attention_resolutions=[8, 4, 2],
+            num_res_blocks=2, channel_mult=[1, 2, 3, 5], num_heads=1, use_spatial_transformer=True,
+            transformer_depth=1, context_dim=512)
+WQ = dict(n_bits=4, symmetric=True, channel_wise=True, scale_method="mse")
+AQ = dict(n_bits=8, symmetric=True, channel_wise=False, scale_method="mse", leaf_param=True, prob=0.5)
+
+
+def build_quantised_unet(device, calib_rows=16, seed=1234):
+    from edadm.nets.ldm_unet import UNetModel
+    from qdiff import QuantModel, set_weight_quantize_params, set_act_quantize_params
+    from qdiff.utils import seed_everything
+    seed_everything(seed)
+    model = UNetModel(**LDM4)
+    g = torch.Generator().manual_seed(seed)
+    for prm in model.parameters():                      # zero_module convs: give them weights
+        if float(prm.detach().abs().max()) == 0.0:
+            with torch.no_grad():
+                prm.copy_(torch.randn(prm.shape, generator=g) * 0.02)
+    model = model.to(device).eval()
+    sd_cpu = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    qnn = QuantModel(model, WQ, AQ, sm_abit=8, act_quant_mode="qdiff").to(device).eval()
+    qnn.set_quant_state(False, False)
+    qnn.set_first_last_layer_to_8bit()
+    qnn.disable_network_output_quantization()
+    qnn.set_grad_ckpt(False)
+    qnn.model.split_shortcut = True
+    ts = np.arange(0, 1000, 50) + 1
+    x = torch.randn(calib_rows, 3, 64, 64, generator=g).to(device)
+    t = torch.tensor(ts[torch.randint(0, 20, (calib_rows,), generator=g).numpy()], dtype=torch.long, device=device)
+    c = torch.randn(calib_rows, 1, 512, generator=g).to(device)
+    t0 = time.time()
+    set_weight_quantize_params(qnn, (x, t, c))
+    torch.cuda.synchronize()
+    t1 = time.time()
+    from qdiff.set_quantize_params_LDM import all_act_quantizers
+    set_act_quantize_params(qnn, (x, t, c), batch_size=calib_rows // 2)
+    for q in all_act_quantizers(qnn):
+        q.set_inited(True)
+    torch.cuda.synchronize()
+    t2 = time.time()
+    qnn.set_quant_state(True, True)
+    return qnn, sd_cpu, dict(weight_init_s=t1 - t0, act_init_s=t2 - t1, calib_rows=calib_rows)
+
+
+def cpu_baseline(qnn, sd_cpu):
+    """The oracle (CPU restatement of the reference's PyTorch fake-quant path) on this box's host
+    cores: ONE UNet forward of one CFG-doubled image (2 rows), 1/20 of an image's work."""
+    from oracle import qdiff_oracle as O
+    from edadm.state import quant_state_dict
+    net = O.OUNet(sd_cpu, WQ, AQ, 8, **LDM4)
+    net.set_first_last_layer_to_8bit()
+    net.disable_network_output_quantization()
+    net.split_shortcut = True
+    g = torch.Generator().manual_seed(7)
+    x, t, c = torch.randn(2, 3, 64, 64, generator=g), torch.tensor([501, 501]), torch.randn(2, 1, 512, generator=g)
+    with torch.no_grad():
+        net(x, t, c)                                        # FP pass: creates split quantizers, warms up
+    st = {"qp/" + k: v for k, v in quant_state_dict(qnn).items()}
+    net.load_qparams(st, prefix="qp/model.")
+    net.set_quant_state(True, True)
+    with torch.no_grad():
+        t0 = time.time()
+        net(x, t, c)
+        dt = time.time() - t0
+    return dict(value=1.0 / (20 * dt), unit="images/sec", cores=torch.get_num_threads(), kind="port",
+                sample="1 fake-quant UNet forward of 1 CFG-doubled image (2 rows) = 1/20 of an image; %.2f s" % dt)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from edadm import lib
+    lib.load()                                                # fail loudly if the HIP library is missing
+    from edadm.sampling import DDIMLoop
+
+    qnn, sd_cpu, calib = build_quantised_unet(dev)
+    eng = qnn.freeze()
+    B = args.batch
+    loop = DDIMLoop(eng, (3, 64, 64), B, steps=20, eta=0.0, scale=3.0, context_shape=(1, 512), device=dev)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    n_total = args.steps + args.warmup
+    noise = [torch.randn(B, 3, 64, 64, generator=gen, device=dev) for _ in range(n_total)]
+    cond = torch.randn(B, 1, 512, generator=gen, device=dev)
+    uncond = torch.randn(1, 1, 512, generator=gen, device=dev).expand(B, 1, 512).contiguous()
+
+    for i in range(args.warmup):
+        loop.sample(noise[i], cond, uncond)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.time()
+    for i in range(args.warmup, n_total):
+        loop.sample(noise[i], cond, uncond)
+    torch.cuda.synchronize()
+    elapsed = time.time() - t0
+    if world > 1:
+        dist.barrier()
+        tt = torch.tensor([elapsed], device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # roofline pass: HIP events around every int8 MFMA GEMM launch of one eager UNet call
+    eng.prof = []
+    x_in = torch.cat([noise[0], noise[0]])
+    t_in = torch.full((2 * B,), 501, dtype=torch.long, device=dev)
+    c_in = torch.cat([uncond, cond])
+    eng(x_in, t_in, c_in)
+    torch.cuda.synchronize()
+    prof, eng.prof = eng.prof, None
+    i8 = [(f, ev[0].elapsed_time(ev[1])) for mode, _, _, _, _, f, ev in prof if mode == "i8"]
+    gemm_flop, gemm_ms = sum(f for f, _ in i8), sum(ms for _, ms in i8)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    loop.unet(x_in, t_in, c_in)
+    ev1.record()
+    torch.cuda.synchronize()
+    unet_ms = ev0.elapsed_time(ev1)
+
+    if rank == 0:
+        images = B * args.steps * world
+        achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12
+        line = {
+            "metric": "images/sec W4A8 LDM-4 ImageNet 256x256 sampling (20 DDIM steps, CFG 3.0)",
+            "value": images / elapsed, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "int8 (i8 MFMA, i32 accumulate; fp32 epilogues)",
+            "data": "synthetic",
+            "config": {"workload": "ImageNet LDM-4 256x256 W4A8: 50-image batches x 20 DDIM steps x CFG (100 UNet rows/call), "
+                                   "400.9M-param cin256-v2 UNet, random-init weights, latents+context resident in HBM; "
+                                   "first-stage VQ decode outside the hot path (SURVEY 8f-3)",
+                       "images_per_step": B, "ddim_steps": 20, "cfg_scale": 3.0, "parallelism": "dp%d (independent batches, no collective)" % world},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": I8_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / I8_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "k_gemm_nt<int8> (edadm_qgemm_i8): %d launches per UNet call, %.1f GFLOP, %.2f ms summed"
+                                   % (len(i8), gemm_flop / 1e9, gemm_ms),
+                         "unet_call_ms": unet_ms,
+                         "unet_algorithmic_tflops": 2 * B * UNET_GFLOP_PER_ROW / unet_ms},
+            "calibration": calib,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(qnn, sd_cpu)
+            except Exception as e:      # the baseline is a report, never a reason to lose the bench line
+                line["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": torch.get_num_threads(),
+                                        "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

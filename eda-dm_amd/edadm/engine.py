@@ -110,8 +110,24 @@ class Engine:
                 self.layers[id(m)] = FrozenLayer(m, name)
         self._attn_cache = {}
         self.graph = None
+        self.prof = None
 
     # ------------------------------------------------------------------ primitives
+    def _sinusoid(self, t, dim, ddpm):
+        """Timestep table with the frequency vector cached on the device (no host->device copy inside
+        a captured graph): sin|cos (diffusion.py:6-24) or cos|sin (util.py:151-171)."""
+        key = ("freq", dim, ddpm)
+        if key not in self._attn_cache:
+            half = dim // 2
+            if ddpm:
+                f = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000) / (half - 1)))
+            else:
+                f = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half)
+            self._attn_cache[key] = f.to(self.dev)
+        arg = t.float()[:, None] * self._attn_cache[key][None, :]
+        parts = [arg.sin(), arg.cos()] if ddpm else [arg.cos(), arg.sin()]
+        return torch.cat(parts, dim=1).contiguous()
+
     def L(self, qm):
         return self.layers[id(qm)]
 
@@ -126,16 +142,23 @@ class Engine:
     def _gemm(self, L, a, M, geom=None, rowadd=None, rpb=1, residual=None):
         out = torch.empty(M, L.N, dtype=torch.float32, device=self.dev)
         fn = ops.qgemm_i8 if L.mode == "i8" else ops.qgemm_f16
+        ev = None
+        if self.prof is not None:            # bench.py's roofline pass: HIP events on the launch stream
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         if geom is not None:
             s = L.segs[0]
             fn(a, s["w"], M, L.N, s["K"], s["scale"], L.bias, out, geom=geom, rowadd=rowadd, rows_per_batch=rpb,
                residual=residual)
-            return out
-        ctot = a.shape[-1]
-        for i, s in enumerate(L.segs):
-            av = a if len(L.segs) == 1 else a[:, s["lo"]:s["hi"]]
-            fn(av, s["w"], M, L.N, s["K"], s["scale"], L.bias if i == 0 else None, out, lda=ctot,
-               rowadd=rowadd if i == 0 else None, rows_per_batch=rpb, residual=residual if i == 0 else out)
+        else:
+            ctot = a.shape[-1]
+            for i, s in enumerate(L.segs):
+                av = a if len(L.segs) == 1 else a[:, s["lo"]:s["hi"]]
+                fn(av, s["w"], M, L.N, s["K"], s["scale"], L.bias if i == 0 else None, out, lda=ctot,
+                   rowadd=rowadd if i == 0 else None, rows_per_batch=rpb, residual=residual if i == 0 else out)
+        if ev is not None:
+            ev[1].record()
+            self.prof.append((L.mode, L.name, M, L.N, L.K, 2.0 * M * L.N * L.K, ev))
         return out
 
     def lin(self, qm, x2d, rowadd=None, rpb=1, residual=None, pre=None):
@@ -262,7 +285,7 @@ class Engine:
     def forward_ddpm(self, x, t, context=None):
         net = self.net
         B = x.shape[0]
-        temb = ddpm_unet.get_timestep_embedding(t, net.ch).contiguous()
+        temb = self._sinusoid(t, net.ch, ddpm=True)
         h0 = self.lin(net.temb.dense[0], temb)
         L1 = self.L(net.temb.dense[1])
         temb = self._gemm(L1, ops.silu_quant_i8(h0, L1.qp), B)
@@ -433,7 +456,7 @@ class Engine:
     def forward_ldm(self, x, timesteps, context=None):
         net = self.net
         B = x.shape[0]
-        temb = ldm_unet.timestep_embedding(timesteps, net.model_channels).contiguous()
+        temb = self._sinusoid(timesteps, net.model_channels, ddpm=False)
         h0 = self.lin(net.time_embed[0], temb)
         L2 = self.L(net.time_embed[2])
         emb = self._gemm(L2, ops.silu_quant_i8(h0, L2.qp), B)
