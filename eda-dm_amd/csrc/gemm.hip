@@ -32,6 +32,13 @@ struct Acc<true> { typedef v16i type; };
 template <>
 struct Acc<false> { typedef v16f type; };
 
+// Source rows for everything that is not real data (convolution padding, M/N/K tails): row v holds
+// 64 bytes of value v, so a direct-to-LDS load can fetch "padding" like any other address.
+__device__ uint8_t g_pad_rows[256 * 64];
+__global__ void k_init_pad_rows() {
+    for (int i = threadIdx.x; i < 256 * 64; i += blockDim.x) g_pad_rows[i] = (uint8_t)(i >> 6);
+}
+
 template <bool I8, int TM, int TN>
 __global__ void __launch_bounds__(256)
 k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const uint8_t* __restrict__ Bm,
@@ -41,12 +48,17 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
           int64_t ldo, int64_t strideC, float alpha, int inner, int64_t strideA_i, int64_t strideB_i,
           int64_t strideC_i) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
-    constexpr int NA = BM / 64, NB = BN / 64;   // 16-byte chunks staged per thread
-    __shared__ __attribute__((aligned(16))) uint8_t smem[2 * (BM + BN) * 64];
-    uint8_t* As = smem;
-    uint8_t* Bs = smem + 2 * BM * 64;
+    constexpr int NA = BM / 64, NB = BN / 64;   // 16-byte direct-to-LDS loads per thread per K-step
+    constexpr int LPT = NA + NB;
+    constexpr int STAGES = 3;
+    constexpr int TILE = (BM + BN) * 64;
+    constexpr int EST = TN * 32 + 4;                       // epilogue staging row stride (floats)
+    constexpr int EPI_BYTES = 4 * 32 * EST * 4;
+    constexpr int SMEM_BYTES = STAGES * TILE > EPI_BYTES ? STAGES * TILE : EPI_BYTES;
+    __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM_BYTES];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
     {   // batch index z = outer * inner + head: (batch, head) views of [B][N][heads*d] tensors
@@ -56,9 +68,13 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
         out += zo * strideC + zi * strideC_i;
     }
 
-    // ---- per-thread staging coordinates
-    const int sc = tid & 3, sr = tid >> 2;      // chunk, row (+64*i)
-    int64_t a_base[NA];                          // dense: byte offset of the row; conv: packed (b,y,x)
+    // ---- staging coordinates.  LDS image is lane-linear (thread t writes bytes [16t, 16t+16) of each
+    // 4 KiB slab = row (t>>2)+64i, physical chunk t&3); the XOR swizzle is applied to the SOURCE chunk.
+    const int sr = tid >> 2;
+    const int sc = (tid & 3) ^ ((tid >> 4) & 3);      // logical chunk this thread fetches
+    const uint8_t* zero_row = g_pad_rows;             // value 0
+    const uint8_t* pad_row = g_pad_rows + (int)(uint8_t)g.padval * 64;
+    int64_t a_base[NA];
     int a_y[NA], a_x[NA];
     bool a_ok[NA];
 #pragma unroll
@@ -76,54 +92,54 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
             a_base[i] = b * (int64_t)g.H * g.W;
         }
     }
-    const uint32_t padw = (uint32_t)(uint8_t)g.padval * 0x01010101u;
-
+    const uint8_t* b_row[NB];
+    bool b_ok[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int64_t n = n0 + sr + 64 * i;
+        b_ok[i] = n < N;
+        b_row[i] = Bm + (b_ok[i] ? n : 0) * ldb_b;
+    }
     int tap_c = 0, ci_c = 0;
     if (g.mode != 0) { tap_c = (sc * 16) / g.Cin; ci_c = (sc * 16) % g.Cin; }
-    uint4 ra[NA], rb[NB];
-    auto load_tiles = [&](int64_t kb) {  // kb = byte offset along K
+
+    auto issue_tile = [&](int stage, int64_t kb) {  // kb = byte offset along K
+        uint8_t* As = smem + stage * TILE;
+        uint8_t* Bs = As + BM * 64;
+        const int64_t off = kb + sc * 16;
+        const bool kin = off < Kb;
+        const uint8_t* src[NA];
         if (g.mode == 0) {
 #pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                const int64_t off = kb + sc * 16;
-                ra[i] = (a_ok[i] && off < Kb) ? *reinterpret_cast<const uint4*>(A + a_base[i] + off)
-                                              : make_uint4(0, 0, 0, 0);
-            }
+            for (int i = 0; i < NA; ++i) src[i] = (a_ok[i] && kin) ? A + a_base[i] + off : zero_row;
         } else {
-            // this thread's 16-byte chunk sits at k = kb + 16*sc: tap/ci tracked incrementally (Cin % 16 == 0
-            // keeps a chunk inside one tap; Cin % 64 == 0 makes the whole K-step share one tap)
+            // this thread's chunk sits at k = kb + 16*sc: tap/ci tracked incrementally (Cin % 16 == 0 keeps a
+            // chunk inside one tap)
             const int ky = tap_c / g.KW, kx = tap_c - ky * g.KW;
             const int Hl = g.ups ? 2 * g.H : g.H, Wl = g.ups ? 2 * g.W : g.W;
-            const bool kin = kb + sc * 16 < Kb;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 int iy = a_y[i] * g.stride + ky - g.pad0, ix = a_x[i] * g.stride + kx - g.pad0;
-                const bool in = a_ok[i] && kin && iy >= 0 && iy < Hl && ix >= 0 && ix < Wl;
+                const bool in = iy >= 0 && iy < Hl && ix >= 0 && ix < Wl;
                 if (g.ups) { iy >>= 1; ix >>= 1; }
-                ra[i] = in ? *reinterpret_cast<const uint4*>(
-                                 A + ((a_base[i] + (int64_t)iy * g.W + ix) * g.Cin + ci_c))
-                           : ((a_ok[i] && kin) ? make_uint4(padw, padw, padw, padw) : make_uint4(0, 0, 0, 0));
+                src[i] = !(a_ok[i] && kin) ? zero_row
+                         : in ? A + ((a_base[i] + (int64_t)iy * g.W + ix) * g.Cin + ci_c)
+                              : pad_row;
             }
             ci_c += 64;
             while (ci_c >= g.Cin) { ci_c -= g.Cin; ++tap_c; }
         }
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int64_t n = n0 + sr + 64 * i, off = kb + sc * 16;
-            rb[i] = (n < N && off < Kb) ? *reinterpret_cast<const uint4*>(Bm + n * ldb_b + off)
-                                        : make_uint4(0, 0, 0, 0);
-        }
-    };
-    auto store_tiles = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int r = sr + 64 * i;
-            *reinterpret_cast<uint4*>(As + ((buf * BM + r) * 4 + (sc ^ ((r >> 2) & 3))) * 16) = ra[i];
-        }
+        for (int i = 0; i < NA; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
+                                             (__attribute__((address_space(3))) void*)(As + i * 4096 + wave * 1024),
+                                             16, 0, 0);
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int r = sr + 64 * i;
-            *reinterpret_cast<uint4*>(Bs + ((buf * BN + r) * 4 + (sc ^ ((r >> 2) & 3))) * 16) = rb[i];
+            const uint8_t* s = (b_ok[i] && kin) ? b_row[i] + off : zero_row;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
+                                             (__attribute__((address_space(3))) void*)(Bs + i * 4096 + wave * 1024),
+                                             16, 0, 0);
         }
     };
 
@@ -136,13 +152,18 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
 
     const int64_t nk = (Kb + 63) / 64;
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
     const int fr = lane & 31, fh = lane >> 5;
+    issue_tile(0, 0);
+    if (nk > 1) issue_tile(1, 64);
     for (int64_t kt = 0; kt < nk; ++kt) {
-        const int cur = (int)(kt & 1);
-        if (kt + 1 < nk) load_tiles((kt + 1) * 64);
+        // tile kt has landed once at most the newer tile's LPT loads are still in flight
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + 2 < nk) issue_tile((int)((kt + 2) % STAGES), (kt + 2) * 64);
+        const uint8_t* As = smem + (int)(kt % STAGES) * TILE;
+        const uint8_t* Bs = As + BM * 64;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int c = 2 * ks + fh;
@@ -150,12 +171,12 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int r = wm * (TM * 32) + i * 32 + fr;
-                fa[i] = *reinterpret_cast<const uint4*>(As + ((cur * BM + r) * 4 + (c ^ ((r >> 2) & 3))) * 16);
+                fa[i] = *reinterpret_cast<const uint4*>(As + (r * 4 + (c ^ ((r >> 2) & 3))) * 16);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int r = wn * (TN * 32) + j * 32 + fr;
-                fb[j] = *reinterpret_cast<const uint4*>(Bs + ((cur * BN + r) * 4 + (c ^ ((r >> 2) & 3))) * 16);
+                fb[j] = *reinterpret_cast<const uint4*>(Bs + (r * 4 + (c ^ ((r >> 2) & 3))) * 16);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -170,11 +191,67 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
                     }
                 }
         }
-        if (kt + 1 < nk) store_tiles(cur ^ 1);
-        __syncthreads();
     }
 
-    // ---- epilogue
+    // ---- epilogue.  The accumulator layout puts one column on a lane (4-byte stores, two 128-B row pieces
+    // per instruction); staging each wave's 32 x (32*TN) slab through LDS turns that into 16-byte
+    // row-contiguous stores (and 16-byte residual / row-add loads).
+    const bool vec = ((N & 3) == 0) && ((ldo & 3) == 0) && (!residual || (ldr & 3) == 0) &&
+                     (!rowadd || true) && ((((uintptr_t)out) & 15) == 0) &&
+                     (!residual || (((uintptr_t)residual) & 15) == 0);
+    if (vec) {
+        __syncthreads();                                   // every wave is done reading the stage buffers
+        float* ep = reinterpret_cast<float*>(smem) + wave * (32 * EST);
+        constexpr int C4 = TN * 8;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ep[((r & 3) + 8 * (r >> 2) + 4 * fh) * EST + j * 32 + fr] = (float)acc[i][j][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            constexpr int NIT = C4 / 2;                    // 32*C4 float4 per slab / 64 lanes
+            constexpr int GRP = 4;                         // global loads kept in flight per lane
+            static_assert(NIT % GRP == 0, "slab iterations must split into groups");
+#pragma unroll 1
+            for (int g0 = 0; g0 < NIT; g0 += GRP) {
+                float4 rr[GRP], ra4[GRP];
+                int64_t rows[GRP], cols[GRP];
+                bool ok[GRP];
+#pragma unroll
+                for (int u = 0; u < GRP; ++u) {
+                    const int idx = lane + 64 * (g0 + u);
+                    const int rl = idx / C4, c4 = idx - rl * C4;
+                    rows[u] = m0 + wm * (TM * 32) + i * 32 + rl;
+                    cols[u] = n0 + wn * (TN * 32) + c4 * 4;
+                    ok[u] = rows[u] < M && cols[u] < N;
+                    rr[u] = ra4[u] = make_float4(0, 0, 0, 0);
+                    if (ok[u] && residual) rr[u] = *reinterpret_cast<const float4*>(residual + rows[u] * ldr + cols[u]);
+                    if (ok[u] && rowadd)
+                        ra4[u] = *reinterpret_cast<const float4*>(rowadd + (rows[u] / rows_per_batch) * N + cols[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < GRP; ++u) {
+                    if (!ok[u]) continue;
+                    const int idx = lane + 64 * (g0 + u);
+                    const int rl = idx / C4, c4 = idx - rl * C4;
+                    float4 v = *reinterpret_cast<const float4*>(ep + rl * EST + c4 * 4);
+                    const int64_t col = cols[u];
+                    float4 sc4 = scale ? *reinterpret_cast<const float4*>(scale + col)
+                                       : make_float4(alpha, alpha, alpha, alpha);
+                    float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + col) : make_float4(0, 0, 0, 0);
+                    v.x = v.x * sc4.x + b4.x + ra4[u].x + rr[u].x;
+                    v.y = v.y * sc4.y + b4.y + ra4[u].y + rr[u].y;
+                    v.z = v.z * sc4.z + b4.z + ra4[u].z + rr[u].z;
+                    v.w = v.w * sc4.w + b4.w + ra4[u].w + rr[u].w;
+                    *reinterpret_cast<float4*>(out + rows[u] * ldo + col) = v;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int64_t col = n0 + wn * (TN * 32) + j * 32 + fr;
@@ -202,6 +279,11 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
                        const float* rowadd, int64_t rpb, const float* residual, int64_t ldr, float* out, int64_t ldo,
                        int64_t sC, int64_t batch, float alpha, hipStream_t st, int inner = 1, int64_t sAi = 0,
                        int64_t sBi = 0, int64_t sCi = 0) {
+    static bool pad_ready = false;
+    if (!pad_ready) {       // stream-ordered ahead of the first GEMM; idempotent if it lands inside a captured graph
+        hipLaunchKernelGGL(k_init_pad_rows, dim3(1), dim3(256), 0, st);
+        pad_ready = true;
+    }
     // tile choice: widest N tile that divides N well (192 for the 192-multiples of LDM-4, else 128, 64)
     int tn = 2;
     if (N % 192 == 0) tn = 3;
