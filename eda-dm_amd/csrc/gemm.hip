@@ -15,11 +15,26 @@
 #include "common.h"
 #include "../../include/edadm.h"
 #include <hip/hip_fp16.h>
+#ifndef EDADM_GEMM_STAGES
+#define EDADM_GEMM_STAGES 4
+#endif
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+
+// Direct-to-LDS 16-byte load issued from inline asm: hipcc's waitcnt pass would otherwise put
+// `s_waitcnt vmcnt(0)` in front of every ds_read that may alias an in-flight LDS-DMA write, which
+// serialises the pipeline (seen in the .s).  M0 carries the wave-uniform LDS byte address and is
+// restored inside the same statement; completion is tracked by the hand-counted vmcnt below.
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_addr) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_addr)
+                 : "memory");
+}
 
 struct ConvGeom {
     int mode, B, H, W, Cin, Ho, Wo, KH, KW, stride, pad0, ups, padval, r0, r1, r2;
@@ -50,7 +65,7 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int NA = BM / 64, NB = BN / 64;   // 16-byte direct-to-LDS loads per thread per K-step
     constexpr int LPT = NA + NB;
-    constexpr int STAGES = 3;
+    constexpr int STAGES = EDADM_GEMM_STAGES;
     constexpr int TILE = (BM + BN) * 64;
     constexpr int EST = TN * 32 + 4;                       // epilogue staging row stride (floats)
     constexpr int EPI_BYTES = 4 * 32 * EST * 4;
@@ -59,6 +74,7 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
     const int wm = wave >> 1, wn = wave & 1;
     const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
     {   // batch index z = outer * inner + head: (batch, head) views of [B][N][heads*d] tensors
@@ -104,8 +120,6 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
     if (g.mode != 0) { tap_c = (sc * 16) / g.Cin; ci_c = (sc * 16) % g.Cin; }
 
     auto issue_tile = [&](int stage, int64_t kb) {  // kb = byte offset along K
-        uint8_t* As = smem + stage * TILE;
-        uint8_t* Bs = As + BM * 64;
         const int64_t off = kb + sc * 16;
         const bool kin = off < Kb;
         const uint8_t* src[NA];
@@ -131,15 +145,11 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
         }
 #pragma unroll
         for (int i = 0; i < NA; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
-                                             (__attribute__((address_space(3))) void*)(As + i * 4096 + wave * 1024),
-                                             16, 0, 0);
+            glds16(src[i], lds0 + (uint32_t)(stage * TILE + i * 4096 + wave * 1024));
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const uint8_t* s = (b_ok[i] && kin) ? b_row[i] + off : zero_row;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
-                                             (__attribute__((address_space(3))) void*)(Bs + i * 4096 + wave * 1024),
-                                             16, 0, 0);
+            glds16(s, lds0 + (uint32_t)(stage * TILE + BM * 64 + i * 4096 + wave * 1024));
         }
     };
 
@@ -153,15 +163,20 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
 
     const int64_t nk = (Kb + 63) / 64;
     const int fr = lane & 31, fh = lane >> 5;
-    issue_tile(0, 0);
-    if (nk > 1) issue_tile(1, 64);
+#pragma unroll
+    for (int p = 0; p < STAGES - 1; ++p)
+        if (p < nk) issue_tile(p, (int64_t)p * 64);
     for (int64_t kt = 0; kt < nk; ++kt) {
         // tile kt has landed once at most the newer tile's LPT loads are still in flight
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+        // tiles kt+1 .. kt+STAGES-2 may still be in flight
+        const int64_t ahead = nk - 1 - kt < STAGES - 2 ? nk - 1 - kt : STAGES - 2;
+        if (ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPT) : "memory");
+        else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (kt + 2 < nk) issue_tile((int)((kt + 2) % STAGES), (kt + 2) * 64);
+        if (kt + STAGES - 1 < nk) issue_tile((int)((kt + STAGES - 1) % STAGES), (kt + STAGES - 1) * 64);
         const uint8_t* As = smem + (int)(kt % STAGES) * TILE;
         const uint8_t* Bs = As + BM * 64;
 #pragma unroll
