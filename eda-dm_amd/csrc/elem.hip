@@ -470,3 +470,98 @@ extern "C" int edadm_ddim_step(const float* x, const float* e_cond, const float*
                        e_uncond, cfg_scale, coef, noise, x_prev, pred_x0, B, chw);
     return edadm_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------ K3 bookkeeping
+// Candidate grids and the final (delta, zero_point) are O(100 x rows) work, but their float
+// arithmetic decides integer codes, so it runs here with IEEE division in the reference's exact
+// operation order (quant_layer.py:95-105,120-147,150-213,79-85) rather than in library
+// elementwise kernels whose division is not guaranteed to be correctly rounded.
+__device__ __forceinline__ void qparams_of(float mn, float mx, float levels_m1, float* scale, float* zp) {
+    const float min_neg = fminf(mn, 0.f), max_pos = fmaxf(mx, 0.f);
+    float s = (max_pos - min_neg) / levels_m1;
+    s = fmaxf(s, 1e-8f);
+    float z = 0.f - rintf(min_neg / s);
+    *scale = s;
+    *zp = fminf(fmaxf(z, 0.f), levels_m1);
+}
+// candidate c of row r -> (new_min, new_max); mode 1: c = i-1; mode 2: c = (i-1)*n_levels + zpi
+__device__ __forceinline__ void cand_minmax(float xmin, float xmax, int mode, int one_side, int n_levels, int num,
+                                            int c, float* nmin, float* nmax) {
+    if (mode == 1) {
+        const float xr = fmaxf(fabsf(xmin), xmax);
+        const float thr = xr / (float)num * (float)(c + 1);
+        *nmin = one_side > 0 ? 0.f : -thr;
+        *nmax = one_side < 0 ? 0.f : thr;
+    } else {
+        const int i = c / n_levels + 1, zpi = c % n_levels;
+        const float xr = xmax - xmin;
+        const float tmax = xr / (float)num * (float)i;
+        const float tdelta = (tmax - 0.f) / (float)(n_levels - 1);
+        *nmin = 0.f - (float)zpi * tdelta;
+        *nmax = tmax - (float)zpi * tdelta;
+    }
+}
+__global__ void __launch_bounds__(256) k_mse_cand(const float* __restrict__ xmin, const float* __restrict__ xmax,
+                                                  int64_t rows, int mode, int one_side, int n_levels, int num,
+                                                  int channel_clamp, int64_t nc, float* __restrict__ scale,
+                                                  float* __restrict__ zp) {
+    const int64_t n = nc * rows, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t c = i / rows, r = i - c * rows;
+        float mn = xmin[r], mx = xmax[r];
+        if (channel_clamp) { mx = fmaxf(mx, 0.f); mn = fminf(mn, 0.f); }   // 2-D per-channel (:125-126)
+        float a, b;
+        cand_minmax(mn, mx, mode, one_side, n_levels, num, (int)c, &a, &b);
+        qparams_of(a, b, (float)(n_levels - 1), &scale[i], &zp[i]);
+    }
+}
+extern "C" int edadm_mse_candidates(const float* xmin, const float* xmax, int64_t rows, int mode, int one_side,
+                                    int n_bits, int num, int channel_clamp, float* scale, float* zp, void* stream) {
+    if (!xmin || !xmax || !scale || !zp || rows <= 0 || (mode != 1 && mode != 2) || n_bits < 1 || n_bits > 8 || num < 1)
+        return EDADM_EINVAL;
+    const int n_levels = 1 << n_bits;
+    const int64_t nc = mode == 1 ? num : (int64_t)num * n_levels;
+    hipLaunchKernelGGL(k_mse_cand, dim3(edadm_grid(nc * rows, 256)), dim3(256), 0, (hipStream_t)stream, xmin, xmax,
+                       rows, mode, one_side, n_levels, num, channel_clamp, nc, scale, zp);
+    return edadm_launch_status();
+}
+// first minimum over candidates (strict '<' of the sequential search / argmin), EMA of the range for
+// activations (leaf_param), then the final qparams
+__global__ void __launch_bounds__(256) k_mse_select(const float* __restrict__ score, int64_t nc, int64_t rows,
+                                                    const float* __restrict__ xmin, const float* __restrict__ xmax,
+                                                    int mode, int one_side, int n_levels, int num, int channel_clamp,
+                                                    float* __restrict__ run_min, float* __restrict__ run_max,
+                                                    int first, float* __restrict__ delta, float* __restrict__ zp) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += stride) {
+        float best = score[r];
+        int64_t bi = 0;
+        for (int64_t c = 1; c < nc; ++c) {
+            const float s = score[c * rows + r];
+            if (s < best) { best = s; bi = c; }
+        }
+        float mn = xmin[r], mx = xmax[r];
+        if (channel_clamp) { mx = fmaxf(mx, 0.f); mn = fminf(mn, 0.f); }
+        float a, b;
+        cand_minmax(mn, mx, mode, one_side, n_levels, num, (int)bi, &a, &b);
+        if (run_min) {
+            float rm = first ? a : run_min[r], rM = first ? b : run_max[r];
+            rm = 0.1f * a + 0.9f * rm;
+            rM = 0.1f * b + 0.9f * rM;
+            run_min[r] = rm;
+            run_max[r] = rM;
+            a = rm;
+            b = rM;
+        }
+        qparams_of(a, b, (float)(n_levels - 1), &delta[r], &zp[r]);
+    }
+}
+extern "C" int edadm_mse_select(const float* score, int64_t nc, int64_t rows, const float* xmin, const float* xmax,
+                                int mode, int one_side, int n_bits, int num, int channel_clamp, float* run_min,
+                                float* run_max, int first, float* delta, float* zp, void* stream) {
+    if (!score || !xmin || !xmax || !delta || !zp || rows <= 0 || nc <= 0 || (mode != 1 && mode != 2)) return EDADM_EINVAL;
+    if ((run_min == nullptr) != (run_max == nullptr)) return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_mse_select, dim3(edadm_grid(rows, 256)), dim3(256), 0, (hipStream_t)stream, score, nc, rows,
+                       xmin, xmax, mode, one_side, 1 << n_bits, num, channel_clamp, run_min, run_max, first, delta, zp);
+    return edadm_launch_status();
+}

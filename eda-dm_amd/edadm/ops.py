@@ -118,6 +118,26 @@ def mse_scores_channel(x2d, scale, zp, qmax):
     return score
 
 
+def mse_candidates(xmin, xmax, mode, one_side, n_bits, num, channel_clamp):
+    rows = xmin.numel()
+    nc = num if mode == 1 else num * (1 << n_bits)
+    scale = torch.empty(nc, rows, dtype=torch.float32, device=xmin.device)
+    zp = torch.empty(nc, rows, dtype=torch.float32, device=xmin.device)
+    lib.call("edadm_mse_candidates", _pf(xmin), _pf(xmax), rows, int(mode), int(one_side), int(n_bits), int(num),
+             1 if channel_clamp else 0, _pf(scale), _pf(zp), _stream())
+    return scale, zp
+
+
+def mse_select(score, xmin, xmax, mode, one_side, n_bits, num, channel_clamp, run_min=None, run_max=None, first=True):
+    nc, rows = score.shape
+    delta = torch.empty(rows, dtype=torch.float32, device=score.device)
+    zp = torch.empty(rows, dtype=torch.float32, device=score.device)
+    lib.call("edadm_mse_select", _pf(score), nc, rows, _pf(xmin), _pf(xmax), int(mode), int(one_side), int(n_bits),
+             int(num), 1 if channel_clamp else 0, _pf(run_min), _pf(run_max), 1 if first else 0, _pf(delta), _pf(zp),
+             _stream())
+    return delta, zp
+
+
 def minmax(x):
     out = torch.empty(2, dtype=torch.float32, device=x.device)
     lib.call("edadm_minmax", _pf(x), x.numel(), _pf(out), _pf(workspace(x.device)), _stream())

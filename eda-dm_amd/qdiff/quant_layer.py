@@ -141,118 +141,58 @@ class UniformAffineQuantizer(nn.Module):
         self.n_bits = refactored_bit
         self.n_levels = 2 ** self.n_bits
 
-    # -- range tracking / qparams (O(1) work: torch device ops in the reference's op order)
-    def update_quantize_range(self, x_min, x_max):
-        if self.running_min is None:
-            self.running_min, self.running_max = x_min, x_max
-        self.running_min = 0.1 * x_min + 0.9 * self.running_min
-        self.running_max = 0.1 * x_max + 0.9 * self.running_max
-        return self.running_min, self.running_max
-
-    def calculate_qparams(self, min_val, max_val):
-        quant_min, quant_max = 0, self.n_levels - 1
-        min_neg = torch.min(min_val, torch.zeros_like(min_val))
-        max_pos = torch.max(max_val, torch.zeros_like(max_val))
-        scale = (max_pos - min_neg) / float(quant_max - quant_min)
-        scale = torch.max(scale, self.eps.to(scale.device))
-        zero_point = quant_min - torch.round(min_neg / scale)
-        return scale, torch.clamp(zero_point, quant_min, quant_max)
-
-    def quantize(self, x, x_max, x_min):
-        delta, zp = self.calculate_qparams(x_min, x_max)
-        inner = x[0].numel() if self.channel_wise else 1
-        return ops.fake_quant_fwd(x.detach().contiguous(), delta.reshape(-1).contiguous(),
-                                  zp.reshape(-1).contiguous(), self.n_levels - 1, inner=inner)
-
-    # -- searches: candidate grids are O(100) torch ops, the scores are one HIP pass over x
-    def _scores(self, x, scale, zp):
-        """scale/zp: [nc] (per tensor) or [nc][rows] (per channel) -> scores of the same shape."""
-        qmax = self.n_levels - 1
-        if not self.channel_wise:
-            xs = x.detach().reshape(-1).contiguous()
-            out = []
-            for i in range(0, scale.numel(), 128):
-                out.append(ops.mse_scores_tensor(xs, scale[i:i + 128].contiguous(), zp[i:i + 128].contiguous(), qmax))
-            return torch.cat(out)
-        x2 = x.detach().reshape(x.shape[0], -1).contiguous()
-        out = []
-        for i in range(0, scale.shape[0], 4096):
-            out.append(ops.mse_scores_channel(x2, scale[i:i + 4096].contiguous(), zp[i:i + 4096].contiguous(), qmax))
-        return torch.cat(out)
-
+    # -- scale search: per-row (min, max) -> candidate grid -> |x - q(x)|^2.4 scores (one HIP pass
+    #    over x, K3) -> first minimum -> EMA of the range (activations) -> (delta, zero_point).
+    #    All float bookkeeping runs in edadm_mse_candidates / edadm_mse_select with IEEE division in
+    #    the reference's operation order, so the scales come out bit-identical.
     def _aminmax(self, x):
         if self.channel_wise:
-            return torch.aminmax(torch.flatten(x.detach(), 1), dim=1)
+            mn, mx = torch.aminmax(torch.flatten(x.detach(), 1), dim=1)
+            return mn.contiguous(), mx.contiguous()
         mm = ops.minmax(x.detach().reshape(-1).contiguous())
-        return mm[0], mm[1]
+        return mm[0:1].contiguous(), mm[1:2].contiguous()
 
-    def perform_1D_search(self, x):
-        x_min, x_max = self._aminmax(x)
-        xrange = torch.max(x_min.abs(), x_max)
-        steps = torch.arange(1, self.num + 1, device=x.device)
+    def _scores(self, x, scale, zp):
+        """scale/zp [nc][rows] -> scores [nc][rows] (rows = 1 for per-tensor quantizers)."""
+        qmax = self.n_levels - 1
+        nc = scale.shape[0]
         if not self.channel_wise:
-            thres = xrange / self.num * steps
-            new_min = torch.zeros_like(thres) if self.one_side_dist == "pos" else -thres
-            new_max = torch.zeros_like(thres) if self.one_side_dist == "neg" else thres
-            scale = (new_max - new_min) / float(self.n_levels - 1)
-            scale = torch.max(scale, self.eps.to(x.device))
-            zp = torch.clamp(-torch.round(new_min / scale), 0, self.n_levels - 1)
-        else:
-            mins, maxs, sc, zps = [], [], [], []
-            for i in range(1, self.num + 1):
-                thres = xrange / self.num * i
-                nmin = torch.zeros_like(x_min) if self.one_side_dist == "pos" else -thres
-                nmax = torch.zeros_like(x_max) if self.one_side_dist == "neg" else thres
-                s, z = self.calculate_qparams(nmin, nmax)
-                mins.append(nmin), maxs.append(nmax), sc.append(s), zps.append(z)
-            new_min, new_max, scale, zp = (torch.stack(t) for t in (mins, maxs, sc, zps))
-        ind = _first_argmin(self._scores(x, scale, zp), 0)
-        if not self.channel_wise:
-            return new_min[ind], new_max[ind]
-        return new_min.gather(0, ind[None])[0], new_max.gather(0, ind[None])[0]
-
-    def perform_2D_search(self, x):
-        x_min, x_max = self._aminmax(x)
-        if self.channel_wise:
-            x_max = torch.max(x_max, torch.zeros_like(x_max))
-            x_min = torch.min(x_min, torch.zeros_like(x_min))
-        xrange = x_max - x_min
-        mins, maxs, sc, zps = [], [], [], []
-        for i in range(1, self.num + 1):
-            tmp_max = xrange / self.num * i
-            tmp_delta = (tmp_max - torch.zeros_like(x_min)) / (2 ** self.n_bits - 1)
-            for zp in range(0, self.n_levels):
-                nmin, nmax = torch.zeros_like(x_min) - zp * tmp_delta, tmp_max - zp * tmp_delta
-                s, z = self.calculate_qparams(nmin, nmax)
-                mins.append(nmin), maxs.append(nmax), sc.append(s), zps.append(z)
-        new_min, new_max, scale, zp = (torch.stack(t) for t in (mins, maxs, sc, zps))
-        ind = _first_argmin(self._scores(x, scale, zp), 0)
-        if not self.channel_wise:
-            return new_min[ind], new_max[ind]
-        return new_min.gather(0, ind[None])[0], new_max.gather(0, ind[None])[0]
+            xs = x.detach().reshape(-1).contiguous()
+            out = [ops.mse_scores_tensor(xs, scale[i:i + 128].reshape(-1).contiguous(),
+                                         zp[i:i + 128].reshape(-1).contiguous(), qmax) for i in range(0, nc, 128)]
+            return torch.cat(out).reshape(nc, 1)
+        x2 = x.detach().reshape(x.shape[0], -1).contiguous()
+        out = [ops.mse_scores_channel(x2, scale[i:i + 4096].contiguous(), zp[i:i + 4096].contiguous(), qmax)
+               for i in range(0, nc, 4096)]
+        return torch.cat(out)
 
     def get_x_min_x_max(self, x):
-        if self.scale_method != "mse":
-            raise NotImplementedError
-        if self.one_side_dist is None:
-            self.one_side_dist = "pos" if x.min() >= 0.0 else "neg" if x.max() <= 0.0 else "no"
-        if self.one_side_dist != "no" or self.sym:
-            best_min, best_max = self.perform_1D_search(x)
-        else:
-            best_min, best_max = self.perform_2D_search(x)
-        if self.leaf_param:
-            return self.update_quantize_range(best_min, best_max)
-        return best_min, best_max
+        raise NotImplementedError("folded into init_quantization_scale_1 (HIP K3 path)")
 
     def init_quantization_scale_1(self, x, channel_wise=False):
+        if self.scale_method != "mse":
+            raise NotImplementedError
         with torch.no_grad():
-            x_min, x_max = self.get_x_min_x_max(x)
-            delta, zero_point = self.calculate_qparams(x_min, x_max)
+            if self.one_side_dist is None:
+                self.one_side_dist = "pos" if x.min() >= 0.0 else "neg" if x.max() <= 0.0 else "no"
+            mode = 1 if (self.one_side_dist != "no" or self.sym) else 2
+            one = {"pos": 1, "neg": -1, "no": 0}[self.one_side_dist]
+            clamp = mode == 2 and self.channel_wise
+            xmin, xmax = self._aminmax(x)
+            scale, zp = ops.mse_candidates(xmin, xmax, mode, one, self.n_bits, self.num, clamp)
+            scores = self._scores(x, scale, zp)
+            first = self.running_min is None
+            if self.leaf_param and first:
+                self.running_min = torch.empty_like(xmin)
+                self.running_max = torch.empty_like(xmax)
+            delta, zero_point = ops.mse_select(scores, xmin, xmax, mode, one, self.n_bits, self.num, clamp,
+                                               self.running_min if self.leaf_param else None,
+                                               self.running_max if self.leaf_param else None, first)
         if channel_wise:
             shp = [1] * x.dim()
             shp[0] = x.shape[0]
-            delta, zero_point = delta.reshape(shp), zero_point.reshape(shp)
-        return delta, zero_point
+            return delta.reshape(shp), zero_point.reshape(shp)
+        return delta.reshape(()), zero_point.reshape(())
 
     def forward(self, x):
         if self.inited is False:

@@ -68,6 +68,17 @@ int edadm_mse_scores_tensor(const float* x, int64_t n, const float* scale, const
 int edadm_mse_scores_channel(const float* x, int64_t rows, int64_t cols, const float* scale,
                              const float* zp, int nc, float qmax, float* score, void* stream);
 int edadm_minmax(const float* x, int64_t n, float* out2, float* ws, void* stream);
+/* K3 bookkeeping with IEEE arithmetic in the reference's operation order: candidate (scale, zp) grids
+ * from per-row (min, max) — mode 1: 1-D search, num thresholds (one_side -1/0/+1 = neg/no/pos);
+ * mode 2: 2-D search, num x 2^bits (channel_clamp: the per-channel variant clamps the range to
+ * include 0, quant_layer.py:125-126) — laid out [nc][rows]; then the first-minimum selection, the
+ * 0.1/0.9 EMA of the range for activations (run_min/run_max state, first != 0 on the first batch,
+ * quant_layer.py:79-85) and the final delta / zero_point (quant_layer.py:95-105). */
+int edadm_mse_candidates(const float* xmin, const float* xmax, int64_t rows, int mode, int one_side,
+                         int n_bits, int num, int channel_clamp, float* scale, float* zp, void* stream);
+int edadm_mse_select(const float* score, int64_t nc, int64_t rows, const float* xmin, const float* xmax,
+                     int mode, int one_side, int n_bits, int num, int channel_clamp, float* run_min,
+                     float* run_max, int first, float* delta, float* zp, void* stream);
 
 /* ---- K7: reconstruction loss -------------------------------------------------------------------
  * qdiff/quant_layer.py:26-33 with p=2, reduction 'none': sum((pred-tgt)^2) / (numel / C).

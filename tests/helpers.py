@@ -67,3 +67,27 @@ def quantize_like_reference(model, g, kind, split=True):
     qnn.cuda()
     n = load_quant_state(qnn, {k: g[k] for k in g.files if k.startswith("qp/")}, prefix="qp/")
     return qnn, (x, t, ctx), n
+
+
+def build_toynet(g):
+    """The fixture's 2-block toy model (tests/golden/make_golden.py::_ToyNet) in product classes."""
+    import torch.nn as nn
+    from edadm.nets.ddpm_unet import ResnetBlock, AttnBlock
+
+    class ToyNet(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.in_channels = 3
+            self.conv_in = nn.Conv2d(3, 32, 3, padding=1)
+            self.temb_lin = nn.Linear(8, 64)
+            self.rb = ResnetBlock(in_channels=32, out_channels=32, dropout=0.0, temb_channels=64)
+            self.at = AttnBlock(32)
+            self.conv_out = nn.Conv2d(32, 3, 3, padding=1)
+
+        def forward(self, x, t, context=None):
+            temb = self.temb_lin(torch.stack([torch.sin(t * (i + 1) * 0.01) for i in range(8)], 1))
+            return self.conv_out(self.at(self.rb(self.conv_in(x), temb)))
+
+    m = ToyNet()
+    m.load_state_dict(sub_sd(g, "sd/"))
+    return m.eval()
