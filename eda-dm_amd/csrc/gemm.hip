@@ -15,8 +15,11 @@
 #include "common.h"
 #include "../../include/edadm.h"
 #include <hip/hip_fp16.h>
+#ifndef EDADM_USE_NT8
+#define EDADM_USE_NT8 1
+#endif
 #ifndef EDADM_GEMM_STAGES
-#define EDADM_GEMM_STAGES 4
+#define EDADM_GEMM_STAGES 3
 #endif
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -47,6 +50,113 @@ struct Acc<true> { typedef v16i type; };
 template <>
 struct Acc<false> { typedef v16f type; };
 
+// Per-column epilogue constants live in LDS (scale, bias, and the time-embedding rows of the few batch
+// entries a tile spans), so the store phase issues no global load except the residual, and all residual
+// loads of a slab are issued before its first store: on gfx950 vmcnt counts stores too and retires in
+// order, so a load waited behind earlier stores would serialise the store stream.
+template <int BN, int RA>
+__device__ __forceinline__ void stage_epilogue_consts(float* ec, int tid, int nthreads, int64_t m0, int64_t n0,
+                                                      int64_t M, int64_t N, const float* __restrict__ scale,
+                                                      const float* __restrict__ bias,
+                                                      const float* __restrict__ rowadd, int64_t rows_per_batch,
+                                                      float alpha) {
+    for (int c = tid; c < BN; c += nthreads) {
+        const int64_t col = n0 + c;
+        const bool in = col < N;
+        ec[c] = in ? (scale ? scale[col] : alpha) : 0.f;
+        ec[BN + c] = (in && bias) ? bias[col] : 0.f;
+        const int64_t b0 = m0 / rows_per_batch;
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            const int64_t b = b0 + j;
+            ec[(2 + j) * BN + c] = (in && rowadd && b * rows_per_batch < M) ? rowadd[b * N + col] : 0.f;
+        }
+    }
+}
+
+template <bool I8, int TM, int TN, int BN, int RA, int HG>
+__device__ __forceinline__ void gemm_epilogue(typename Acc<I8>::type (&acc)[TM][TN], uint8_t* smem, const float* ec,
+                                              int wave, int lane, int64_t m0, int64_t row0, int64_t col0, int ecol0,
+                                              int64_t M, int64_t N, int64_t rows_per_batch, bool has_rowadd,
+                                              const float* __restrict__ residual, int64_t ldr,
+                                              float* __restrict__ out, int64_t ldo) {
+    constexpr int EST = TN * 32 + 4;
+    const int fr = lane & 31, fh = lane >> 5;
+    const bool vec = ((N & 3) == 0) && ((ldo & 3) == 0) && (!residual || (ldr & 3) == 0) &&
+                     ((((uintptr_t)out) & 15) == 0) && (!residual || (((uintptr_t)residual) & 15) == 0);
+    __syncthreads();                                       // stage buffers free, epilogue constants visible
+    if (vec) {
+        float* ep = reinterpret_cast<float*>(smem) + wave * (32 * EST);
+        constexpr int C4 = TN * 8;
+        constexpr int NIT = C4 / 2;                        // 32*C4 float4 per slab / 64 lanes
+        const int64_t b0 = m0 / rows_per_batch;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ep[((r & 3) + 8 * (r >> 2) + 4 * fh) * EST + j * 32 + fr] = (float)acc[i][j][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            constexpr int GRP = NIT / HG;                  // residual loads in flight per lane (HG rounds per slab)
+#pragma unroll
+            for (int h = 0; h < HG; ++h) {
+                float4 rr[GRP];
+#pragma unroll
+                for (int u = 0; u < GRP; ++u) {            // every residual load of the round before its first store
+                    const int idx = lane + 64 * (h * GRP + u);
+                    const int rl = idx / C4, c4 = idx - rl * C4;
+                    const int64_t row = row0 + i * 32 + rl, col = col0 + c4 * 4;
+                    rr[u] = make_float4(0, 0, 0, 0);
+                    if (residual && row < M && col < N)
+                        rr[u] = *reinterpret_cast<const float4*>(residual + row * ldr + col);
+                }
+#pragma unroll
+                for (int u = 0; u < GRP; ++u) {
+                    const int idx = lane + 64 * (h * GRP + u);
+                    const int rl = idx / C4, c4 = idx - rl * C4;
+                    const int64_t row = row0 + i * 32 + rl, col = col0 + c4 * 4;
+                    if (row >= M || col >= N) continue;
+                    const int ecol = ecol0 + c4 * 4;
+                    float4 v = *reinterpret_cast<const float4*>(ep + rl * EST + c4 * 4);
+                    const float4 sc4 = *reinterpret_cast<const float4*>(ec + ecol);
+                    const float4 b4 = *reinterpret_cast<const float4*>(ec + BN + ecol);
+                    v.x = v.x * sc4.x + b4.x; v.y = v.y * sc4.y + b4.y; v.z = v.z * sc4.z + b4.z; v.w = v.w * sc4.w + b4.w;
+                    if (has_rowadd) {
+                        const int bj = (int)(row / rows_per_batch - b0);
+                        const float4 a4 = *reinterpret_cast<const float4*>(ec + (2 + bj) * BN + ecol);
+                        v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w;
+                    }
+                    v.x += rr[u].x; v.y += rr[u].y; v.z += rr[u].z; v.w += rr[u].w;
+                    *reinterpret_cast<float4*>(out + row * ldo + col) = v;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        return;
+    }
+    const int64_t b0 = m0 / rows_per_batch;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int64_t col = col0 + j * 32 + fr;
+        if (col >= N) continue;
+        const int ecol = ecol0 + j * 32 + fr;
+        const float s = ec[ecol], bs = ec[BN + ecol];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (row >= M) continue;
+                float v = (float)acc[i][j][r] * s + bs;
+                if (has_rowadd) v += ec[(2 + (int)(row / rows_per_batch - b0)) * BN + ecol];
+                if (residual) v += residual[row * ldr + col];
+                out[row * ldo + col] = v;
+            }
+        }
+    }
+}
+
 // Source rows for everything that is not real data (convolution padding, M/N/K tails): row v holds
 // 64 bytes of value v, so a direct-to-LDS load can fetch "padding" like any other address.
 __device__ uint8_t g_pad_rows[256 * 64];
@@ -65,12 +175,16 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int NA = BM / 64, NB = BN / 64;   // 16-byte direct-to-LDS loads per thread per K-step
     constexpr int LPT = NA + NB;
+    constexpr int KSTEP = 64;
     constexpr int STAGES = EDADM_GEMM_STAGES;
     constexpr int TILE = (BM + BN) * 64;
     constexpr int EST = TN * 32 + 4;                       // epilogue staging row stride (floats)
     constexpr int EPI_BYTES = 4 * 32 * EST * 4;
-    constexpr int SMEM_BYTES = STAGES * TILE > EPI_BYTES ? STAGES * TILE : EPI_BYTES;
+    constexpr int RA = BM / 16 + 1;                        // batch entries a tile can span (rows_per_batch >= 16)
+    constexpr int MAIN_BYTES = STAGES * TILE > EPI_BYTES ? STAGES * TILE : EPI_BYTES;
+    constexpr int SMEM_BYTES = MAIN_BYTES + (2 + RA) * BN * 4;
     __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM_BYTES];
+    float* ec = reinterpret_cast<float*>(smem + MAIN_BYTES);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -118,6 +232,15 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
     }
     int tap_c = 0, ci_c = 0;
     if (g.mode != 0) { tap_c = (sc * 16) / g.Cin; ci_c = (sc * 16) % g.Cin; }
+    const bool uniform_tap = g.mode != 0 && !g.ups && (g.Cin % KSTEP) == 0;
+    int tap_s = 0, ci_s = 0;                        // wave-uniform (tap, channel) of the K-step, fast path
+    int a_y0[NA], a_x0[NA], a_off[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        a_y0[i] = a_y[i] * g.stride - g.pad0;
+        a_x0[i] = a_x[i] * g.stride - g.pad0;
+        a_off[i] = (int)((a_base[i] + (int64_t)a_y0[i] * g.W + a_x0[i]) * g.Cin) + sc * 16;
+    }
 
     auto issue_tile = [&](int stage, int64_t kb) {  // kb = byte offset along K
         const int64_t off = kb + sc * 16;
@@ -126,6 +249,18 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
         if (g.mode == 0) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) src[i] = (a_ok[i] && kin) ? A + a_base[i] + off : zero_row;
+        } else if (uniform_tap) {
+            // Cin % 64 == 0: the whole K-step lies in one tap -> tap arithmetic is scalar, a load costs
+            // one 32-bit add, two compares and the pointer select
+            const int ky = tap_s / g.KW, kx = tap_s - ky * g.KW;
+            const int dlt = (ky * g.W + kx) * g.Cin + ci_s;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const bool in = (unsigned)(a_y0[i] + ky) < (unsigned)g.H && (unsigned)(a_x0[i] + kx) < (unsigned)g.W;
+                src[i] = !(a_ok[i] && kin) ? zero_row : in ? A + (int64_t)(a_off[i] + dlt) : pad_row;
+            }
+            ci_s += 64;
+            if (ci_s >= g.Cin) { ci_s = 0; ++tap_s; }
         } else {
             // this thread's chunk sits at k = kb + 16*sc: tap/ci tracked incrementally (Cin % 16 == 0 keeps a
             // chunk inside one tap)
@@ -152,6 +287,9 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
             glds16(s, lds0 + (uint32_t)(stage * TILE + BM * 64 + i * 4096 + wave * 1024));
         }
     };
+
+    stage_epilogue_consts<BN, RA>(ec, tid, (int)blockDim.x, m0, n0, M, N, scale, bias, rowadd, rows_per_batch, alpha);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // keep the pipeline's vmcnt bookkeeping to LDS-DMA only
 
     typename Acc<I8>::type acc[TM][TN];
 #pragma unroll
@@ -208,84 +346,182 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
         }
     }
 
-    // ---- epilogue.  The accumulator layout puts one column on a lane (4-byte stores, two 128-B row pieces
-    // per instruction); staging each wave's 32 x (32*TN) slab through LDS turns that into 16-byte
-    // row-contiguous stores (and 16-byte residual / row-add loads).
-    const bool vec = ((N & 3) == 0) && ((ldo & 3) == 0) && (!residual || (ldr & 3) == 0) &&
-                     (!rowadd || true) && ((((uintptr_t)out) & 15) == 0) &&
-                     (!residual || (((uintptr_t)residual) & 15) == 0);
-    if (vec) {
-        __syncthreads();                                   // every wave is done reading the stage buffers
-        float* ep = reinterpret_cast<float*>(smem) + wave * (32 * EST);
-        constexpr int C4 = TN * 8;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    ep[((r & 3) + 8 * (r >> 2) + 4 * fh) * EST + j * 32 + fr] = (float)acc[i][j][r];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            constexpr int NIT = C4 / 2;                    // 32*C4 float4 per slab / 64 lanes
-            constexpr int GRP = 4;                         // global loads kept in flight per lane
-            static_assert(NIT % GRP == 0, "slab iterations must split into groups");
-#pragma unroll 1
-            for (int g0 = 0; g0 < NIT; g0 += GRP) {
-                float4 rr[GRP], ra4[GRP];
-                int64_t rows[GRP], cols[GRP];
-                bool ok[GRP];
-#pragma unroll
-                for (int u = 0; u < GRP; ++u) {
-                    const int idx = lane + 64 * (g0 + u);
-                    const int rl = idx / C4, c4 = idx - rl * C4;
-                    rows[u] = m0 + wm * (TM * 32) + i * 32 + rl;
-                    cols[u] = n0 + wn * (TN * 32) + c4 * 4;
-                    ok[u] = rows[u] < M && cols[u] < N;
-                    rr[u] = ra4[u] = make_float4(0, 0, 0, 0);
-                    if (ok[u] && residual) rr[u] = *reinterpret_cast<const float4*>(residual + rows[u] * ldr + cols[u]);
-                    if (ok[u] && rowadd)
-                        ra4[u] = *reinterpret_cast<const float4*>(rowadd + (rows[u] / rows_per_batch) * N + cols[u]);
-                }
-#pragma unroll
-                for (int u = 0; u < GRP; ++u) {
-                    if (!ok[u]) continue;
-                    const int idx = lane + 64 * (g0 + u);
-                    const int rl = idx / C4, c4 = idx - rl * C4;
-                    float4 v = *reinterpret_cast<const float4*>(ep + rl * EST + c4 * 4);
-                    const int64_t col = cols[u];
-                    float4 sc4 = scale ? *reinterpret_cast<const float4*>(scale + col)
-                                       : make_float4(alpha, alpha, alpha, alpha);
-                    float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + col) : make_float4(0, 0, 0, 0);
-                    v.x = v.x * sc4.x + b4.x + ra4[u].x + rr[u].x;
-                    v.y = v.y * sc4.y + b4.y + ra4[u].y + rr[u].y;
-                    v.z = v.z * sc4.z + b4.z + ra4[u].z + rr[u].z;
-                    v.w = v.w * sc4.w + b4.w + ra4[u].w + rr[u].w;
-                    *reinterpret_cast<float4*>(out + rows[u] * ldo + col) = v;
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        return;
+    gemm_epilogue<I8, TM, TN, BN, RA, 2>(acc, smem, ec, wave, lane, m0, m0 + wm * (TM * 32), n0 + wn * (TN * 32),
+                                      wn * (TN * 32), M, N, rows_per_batch, rowadd != nullptr, residual, ldr, out, ldo);
+}
+
+// ---- 8-wave variant for the large-M layers: 256 x (64*TN) tile, 128-byte K rows (full cache lines per
+// request, half the L2->LDS bytes per flop of the 128-row tile), two LDS stages, 24 MFMAs per wave per
+// barrier.  Same gather / padding / epilogue contract as k_gemm_nt.
+template <bool I8, int TN>
+__global__ void __launch_bounds__(512)
+k_gemm_nt8(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const uint8_t* __restrict__ Bm,
+           int64_t ldb_b, int64_t strideB_b, int64_t M, int64_t N, int64_t Kb, ConvGeom g,
+           const float* __restrict__ scale, const float* __restrict__ bias, const float* __restrict__ rowadd,
+           int64_t rows_per_batch, const float* __restrict__ residual, int64_t ldr, float* __restrict__ out,
+           int64_t ldo, int64_t strideC, float alpha, int inner, int64_t strideA_i, int64_t strideB_i,
+           int64_t strideC_i) {
+    constexpr int TM = 2;
+    constexpr int BM = 256, BN = 64 * TN;
+    constexpr int NA = 4, NB = TN;                 // 64-row passes per operand (512 threads x 16 B = 64 rows x 128 B)
+    constexpr int STAGES = 2;
+    constexpr int KSTEP = 128;
+    constexpr int TILE = (BM + BN) * 128;
+    constexpr int EST = TN * 32 + 4;
+    constexpr int EPI_BYTES = 8 * 32 * EST * 4;
+    constexpr int RA = BM / 16 + 1;
+    constexpr int MAIN_BYTES = STAGES * TILE > EPI_BYTES ? STAGES * TILE : EPI_BYTES;
+    constexpr int SMEM_BYTES = MAIN_BYTES + (2 + RA) * BN * 4;
+    __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM_BYTES];
+    float* ec = reinterpret_cast<float*>(smem + MAIN_BYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+    {
+        const int64_t zo = blockIdx.z / inner, zi = blockIdx.z % inner;
+        A += zo * strideA_b + zi * strideA_i;
+        Bm += zo * strideB_b + zi * strideB_i;
+        out += zo * strideC + zi * strideC_i;
     }
+    const int sr = tid >> 3;
+    const int sc = (tid & 7) ^ ((tid >> 4) & 7);      // source chunk = physical chunk ^ ((row >> 1) & 7)
+    const uint8_t* zero_row = g_pad_rows;
+    const uint8_t* pad_row = g_pad_rows + (int)(uint8_t)g.padval * 64;
+    int64_t a_base[NA];
+    int a_y[NA], a_x[NA];
+    bool a_ok[NA];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int64_t col = n0 + wn * (TN * 32) + j * 32 + fr;
-        if (col >= N) continue;
-        const float s = scale ? scale[col] : alpha;
-        const float bs = bias ? bias[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t row = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (row >= M) continue;
-                float v = (float)acc[i][j][r] * s + bs;
-                if (rowadd) v += rowadd[(row / rows_per_batch) * N + col];
-                if (residual) v += residual[row * ldr + col];
-                out[row * ldo + col] = v;
-            }
+    for (int i = 0; i < NA; ++i) {
+        const int64_t m = m0 + sr + 64 * i;
+        a_ok[i] = m < M;
+        if (g.mode == 0) {
+            a_base[i] = m * lda_b;
+            a_y[i] = a_x[i] = 0;
+        } else {
+            const int64_t hw = (int64_t)g.Ho * g.Wo;
+            const int64_t b = m / hw, r = m - b * hw;
+            a_y[i] = (int)(r / g.Wo);
+            a_x[i] = (int)(r - (int64_t)a_y[i] * g.Wo);
+            a_base[i] = b * (int64_t)g.H * g.W;
         }
     }
+    const uint8_t* b_row[NB];
+    bool b_ok[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int64_t n = n0 + sr + 64 * i;
+        b_ok[i] = n < N;
+        b_row[i] = Bm + (b_ok[i] ? n : 0) * ldb_b;
+    }
+    int tap_c = 0, ci_c = 0;
+    if (g.mode != 0) { tap_c = (sc * 16) / g.Cin; ci_c = (sc * 16) % g.Cin; }
+    const bool uniform_tap = g.mode != 0 && !g.ups && (g.Cin % KSTEP) == 0;
+    int tap_s = 0, ci_s = 0;                        // wave-uniform (tap, channel) of the K-step, fast path
+    int a_y0[NA], a_x0[NA], a_off[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        a_y0[i] = a_y[i] * g.stride - g.pad0;
+        a_x0[i] = a_x[i] * g.stride - g.pad0;
+        a_off[i] = (int)((a_base[i] + (int64_t)a_y0[i] * g.W + a_x0[i]) * g.Cin) + sc * 16;
+    }
+
+    auto issue_tile = [&](int stage, int64_t kb) {
+        const int64_t off = kb + sc * 16;
+        const bool kin = off < Kb;
+        const uint8_t* src[NA];
+        if (g.mode == 0) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) src[i] = (a_ok[i] && kin) ? A + a_base[i] + off : zero_row;
+        } else if (uniform_tap) {
+            // Cin % 128 == 0: the whole K-step lies in one tap -> tap arithmetic is scalar, a load costs
+            // one 32-bit add, two compares and the pointer select
+            const int ky = tap_s / g.KW, kx = tap_s - ky * g.KW;
+            const int dlt = (ky * g.W + kx) * g.Cin + ci_s;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const bool in = (unsigned)(a_y0[i] + ky) < (unsigned)g.H && (unsigned)(a_x0[i] + kx) < (unsigned)g.W;
+                src[i] = !(a_ok[i] && kin) ? zero_row : in ? A + (int64_t)(a_off[i] + dlt) : pad_row;
+            }
+            ci_s += 128;
+            if (ci_s >= g.Cin) { ci_s = 0; ++tap_s; }
+        } else {
+            const int ky = tap_c / g.KW, kx = tap_c - ky * g.KW;
+            const int Hl = g.ups ? 2 * g.H : g.H, Wl = g.ups ? 2 * g.W : g.W;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                int iy = a_y[i] * g.stride + ky - g.pad0, ix = a_x[i] * g.stride + kx - g.pad0;
+                const bool in = iy >= 0 && iy < Hl && ix >= 0 && ix < Wl;
+                if (g.ups) { iy >>= 1; ix >>= 1; }
+                src[i] = !(a_ok[i] && kin) ? zero_row
+                         : in ? A + ((a_base[i] + (int64_t)iy * g.W + ix) * g.Cin + ci_c)
+                              : pad_row;
+            }
+            ci_c += 128;
+            while (ci_c >= g.Cin) { ci_c -= g.Cin; ++tap_c; }
+        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i) glds16(src[i], lds0 + (uint32_t)(stage * TILE + i * 8192 + wave * 1024));
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const uint8_t* s = (b_ok[i] && kin) ? b_row[i] + off : zero_row;
+            glds16(s, lds0 + (uint32_t)(stage * TILE + BM * 128 + i * 8192 + wave * 1024));
+        }
+    };
+
+    stage_epilogue_consts<BN, RA>(ec, tid, (int)blockDim.x, m0, n0, M, N, scale, bias, rowadd, rows_per_batch, alpha);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // keep the pipeline's vmcnt bookkeeping to LDS-DMA only
+
+    typename Acc<I8>::type acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+
+    const int64_t nk = (Kb + 127) / 128;
+    const int fr = lane & 31, fh = lane >> 5;
+    issue_tile(0, 0);
+    for (int64_t kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + 1 < nk) issue_tile((int)((kt + 1) & 1), (kt + 1) * 128);
+        const uint8_t* As = smem + (int)(kt & 1) * TILE;
+        const uint8_t* Bs = As + BM * 128;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int c = 2 * ks + fh;
+            uint4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int r = wm * 64 + i * 32 + fr;
+                fa[i] = *reinterpret_cast<const uint4*>(As + r * 128 + ((c ^ ((r >> 1) & 7)) * 16));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int r = wn * (TN * 32) + j * 32 + fr;
+                fb[j] = *reinterpret_cast<const uint4*>(Bs + r * 128 + ((c ^ ((r >> 1) & 7)) * 16));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (I8) {
+                        acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(
+                            *reinterpret_cast<v4i*>(&fa[i]), *reinterpret_cast<v4i*>(&fb[j]), acc[i][j], 0, 0, 0);
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                            *reinterpret_cast<v8h*>(&fa[i]), *reinterpret_cast<v8h*>(&fb[j]), acc[i][j], 0, 0, 0);
+                    }
+                }
+        }
+    }
+    gemm_epilogue<I8, TM, TN, BN, RA, 1>(acc, smem, ec, wave, lane, m0, m0 + wm * 64, n0 + wn * (TN * 32), wn * (TN * 32),
+                                      M, N, rows_per_batch, rowadd != nullptr, residual, ldr, out, ldo);
 }
 
 template <bool I8>
@@ -294,6 +530,7 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
                        const float* rowadd, int64_t rpb, const float* residual, int64_t ldr, float* out, int64_t ldo,
                        int64_t sC, int64_t batch, float alpha, hipStream_t st, int inner = 1, int64_t sAi = 0,
                        int64_t sBi = 0, int64_t sCi = 0) {
+    if (!rowadd) rpb = M;                                    // one (unused) batch entry
     static bool pad_ready = false;
     if (!pad_ready) {       // stream-ordered ahead of the first GEMM; idempotent if it lands inside a captured graph
         hipLaunchKernelGGL(k_init_pad_rows, dim3(1), dim3(256), 0, st);
@@ -305,6 +542,24 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
     else if (N <= 64) tn = 1;
     int tm = 2;
     if (M <= 64) tm = 1;
+    // large-M layers: 256-row, 8-wave tile when it still fills the 256 CUs
+    const int64_t tiles8 = ((M + 255) / 256) * ((N + 64 * tn - 1) / (64 * tn)) * batch;
+    // convolutions whose Cin is a multiple of 64 but not of 128 keep scalar tap arithmetic only with 64-byte K-steps
+    const bool nt8_gather_ok = true;
+    if (EDADM_USE_NT8 && tiles8 >= 224 && Kb >= 256 && nt8_gather_ok) {
+        const dim3 grid8((unsigned)((N + 64 * tn - 1) / (64 * tn)), (unsigned)((M + 255) / 256), (unsigned)batch);
+#define EDADM_GEMM8_CASE(TN_)                                                                                  \
+        if (tn == TN_) {                                                                                       \
+            hipLaunchKernelGGL((k_gemm_nt8<I8, TN_>), grid8, dim3(512), 0, st, (const uint8_t*)A, lda_b, sA,   \
+                               (const uint8_t*)Bm, ldb_b, sB, M, N, Kb, g, scale, bias, rowadd, rpb, residual, \
+                               ldr, out, ldo, sC, alpha, inner, sAi, sBi, sCi);                                \
+            return edadm_launch_status();                                                                      \
+        }
+        EDADM_GEMM8_CASE(3)
+        EDADM_GEMM8_CASE(2)
+        EDADM_GEMM8_CASE(1)
+#undef EDADM_GEMM8_CASE
+    }
     const dim3 blk(256);
 #define EDADM_GEMM_CASE(TM_, TN_)                                                                              \
     if (tm == TM_ && tn == TN_) {                                                                              \
@@ -345,7 +600,7 @@ extern "C" int edadm_qgemm_i8(const int8_t* A, int64_t lda, const int8_t* Wt, in
             (int64_t)g.B * g.Ho * g.Wo != M)
             return EDADM_EINVAL;
     }
-    if (rowadd && rows_per_batch <= 0) return EDADM_EINVAL;
+    if (rowadd && rows_per_batch < 16) return EDADM_EINVAL;   // the epilogue stages <= BM/16+1 row-add rows in LDS
     return launch_gemm<true>(A, lda, 0, Wt, ldw, 0, M, N, K, g, scale, bias, rowadd, rows_per_batch, residual, ldr,
                              out, ldo, 0, 1, 1.0f, (hipStream_t)stream);
 }
@@ -382,7 +637,7 @@ extern "C" int edadm_qgemm_f16(const void* A, int64_t lda, const void* Wt, int64
     } else if (lda & 7) {
         return EDADM_EINVAL;
     }
-    if (rowadd && rows_per_batch <= 0) return EDADM_EINVAL;
+    if (rowadd && rows_per_batch < 16) return EDADM_EINVAL;   // the epilogue stages <= BM/16+1 row-add rows in LDS
     return launch_gemm<false>(A, lda * 2, 0, Wt, ldw * 2, 0, M, N, K * 2, g, scale, bias, rowadd, rows_per_batch,
                               residual, ldr, out, ldo, 0, 1, 1.0f, (hipStream_t)stream);
 }

@@ -151,7 +151,7 @@ int edadm_upsample2_nhwc(const float* x, float* out, int64_t B, int64_t H, int64
 
 /* ---- K4: quantised conv / linear on int8 MFMA ---------------------------------------------------
  * qdiff/quant_layer.py:406-437 at inference: out[m][n] = scale[n]*sum_k a[m][k]*w[n][k] + bias[n]
- * (+ rowadd[m / rows_per_batch][n]) (+ residual[m][n]) with a = code-128 (int8), w = wcode-zp_w
+ * (+ rowadd[m / rows_per_batch][n], rows_per_batch >= 16) (+ residual[m][n]) with a = code-128 (int8), w = wcode-zp_w
  * (int8); the (128-zp_x)*sum_k w term and delta_x*delta_w[n] are folded into bias/scale by the
  * host.  geom (device-independent ints, 16 of them):
  *  {mode, B, H, W, Cin, Ho, Wo, KH, KW, stride, pad0, upsample, padval, 0,0,0}

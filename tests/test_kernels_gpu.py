@@ -333,13 +333,13 @@ def test_qgemm_dense_exact(ops, M, N, K):
     scale = torch.rand(N, generator=gen) * 1e-3 + 1e-4
     bias = torch.randn(N, generator=gen)
     res = torch.randn(M, N, generator=gen)
-    rowadd = torch.randn((M + 49) // 50, N, generator=gen)
+    rowadd = torch.randn((M + 47) // 48, N, generator=gen)
     out = torch.empty(M, N, device="cuda")
     ops.qgemm_i8(A.cuda(), W.cuda(), M, N, K, torch.ones(N).cuda(), torch.zeros(N).cuda(), out)
     exact(out.cpu().double(), _int_ref_dense(A, W))        # integer accumulation: bit-exact
     ops.qgemm_i8(A.cuda(), W.cuda(), M, N, K, scale.cuda(), bias.cuda(), out, rowadd=rowadd.cuda(),
-                 rows_per_batch=50, residual=res.cuda())
-    ref = _int_ref_dense(A, W) * scale.double() + bias.double() + rowadd.double()[torch.arange(M) // 50] + res.double()
+                 rows_per_batch=48, residual=res.cuda())
+    ref = _int_ref_dense(A, W) * scale.double() + bias.double() + rowadd.double()[torch.arange(M) // 48] + res.double()
     close(out, ref, rtol=1e-5, atol=1e-5)
 
 
