@@ -15,6 +15,7 @@
 #include "common.h"
 #include "../../include/edadm.h"
 #include <hip/hip_fp16.h>
+#include <stdlib.h>
 #ifndef EDADM_USE_NT8
 #define EDADM_USE_NT8 1
 #endif
@@ -50,6 +51,16 @@ struct Acc<true> { typedef v16i type; };
 template <>
 struct Acc<false> { typedef v16f type; };
 
+// round(v / d) with the reference's true-division result at the cost of a multiply: t = v * (1/d) differs from
+// v / d by a couple of ulp, which can only change the rounded integer when t sits within 1e-3 of a .5
+// boundary; those (rare) lanes redo the IEEE division.
+__device__ __forceinline__ float rint_div(float v, float d, float inv_d) {
+    float t = v * inv_d;
+    const float f = t - floorf(t);
+    if (fabsf(f - 0.5f) < 1e-3f) t = v / d;
+    return rintf(t);
+}
+
 // Per-column epilogue constants live in LDS (scale, bias, and the time-embedding rows of the few batch
 // entries a tile spans), so the store phase issues no global load except the residual, and all residual
 // loads of a slab are issued before its first store: on gfx950 vmcnt counts stores too and retires in
@@ -59,7 +70,8 @@ __device__ __forceinline__ void stage_epilogue_consts(float* ec, int tid, int nt
                                                       int64_t M, int64_t N, const float* __restrict__ scale,
                                                       const float* __restrict__ bias,
                                                       const float* __restrict__ rowadd, int64_t rows_per_batch,
-                                                      float alpha) {
+                                                      float alpha, const float* __restrict__ oqp) {
+    if (tid < 3) ec[(2 + RA) * BN + tid] = oqp ? oqp[tid] : 0.f;
     for (int c = tid; c < BN; c += nthreads) {
         const int64_t col = n0 + c;
         const bool in = col < N;
@@ -79,7 +91,7 @@ __device__ __forceinline__ void gemm_epilogue(typename Acc<I8>::type (&acc)[TM][
                                               int wave, int lane, int64_t m0, int64_t row0, int64_t col0, int ecol0,
                                               int64_t M, int64_t N, int64_t rows_per_batch, bool has_rowadd,
                                               const float* __restrict__ residual, int64_t ldr,
-                                              float* __restrict__ out, int64_t ldo) {
+                                              float* __restrict__ out, int64_t ldo, int out_mode) {
     constexpr int EST = TN * 32 + 4;
     const int fr = lane & 31, fh = lane >> 5;
     const bool vec = ((N & 3) == 0) && ((ldo & 3) == 0) && (!residual || (ldr & 3) == 0) &&
@@ -128,7 +140,38 @@ __device__ __forceinline__ void gemm_epilogue(typename Acc<I8>::type (&acc)[TM][
                         v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w;
                     }
                     v.x += rr[u].x; v.y += rr[u].y; v.z += rr[u].z; v.w += rr[u].w;
-                    *reinterpret_cast<float4*>(out + row * ldo + col) = v;
+                    if (out_mode == 0) {
+                        *reinterpret_cast<float4*>(out + row * ldo + col) = v;
+                    } else {
+                        // quantised outputs: the only consumer is an activation quantizer with fixed (delta, zp)
+                        const float od = ec[(2 + RA) * BN], oz = ec[(2 + RA) * BN + 1], oq = ec[(2 + RA) * BN + 2];
+                        const float oi = 1.0f / od;
+                        if (out_mode == 3) {               // GEGLU on interleaved (a, gate) columns -> int8 operand
+                            const float y0 = v.x * (0.5f * v.y * (1.0f + erff(v.y * 0.70710678118654752440f)));
+                            const float y1 = v.z * (0.5f * v.w * (1.0f + erff(v.w * 0.70710678118654752440f)));
+                            const int c0 = (int)fminf(fmaxf(rint_div(y0, od, oi) + oz, 0.f), oq) - 128;
+                            const int c1 = (int)fminf(fmaxf(rint_div(y1, od, oi) + oz, 0.f), oq) - 128;
+                            *reinterpret_cast<uint16_t*>(reinterpret_cast<int8_t*>(out) + row * ldo + (col >> 1)) =
+                                (uint16_t)((c0 & 0xff) | ((c1 & 0xff) << 8));
+                        } else {
+                            const float q0 = fminf(fmaxf(rint_div(v.x, od, oi) + oz, 0.f), oq);
+                            const float q1 = fminf(fmaxf(rint_div(v.y, od, oi) + oz, 0.f), oq);
+                            const float q2 = fminf(fmaxf(rint_div(v.z, od, oi) + oz, 0.f), oq);
+                            const float q3 = fminf(fmaxf(rint_div(v.w, od, oi) + oz, 0.f), oq);
+                            if (out_mode == 1) {           // f16 operand code - zp (attention products)
+                                __half2 h0 = __floats2half2_rn(q0 - oz, q1 - oz), h1 = __floats2half2_rn(q2 - oz, q3 - oz);
+                                uint2 pk;
+                                pk.x = *reinterpret_cast<uint32_t*>(&h0);
+                                pk.y = *reinterpret_cast<uint32_t*>(&h1);
+                                *reinterpret_cast<uint2*>(reinterpret_cast<__half*>(out) + row * ldo + col) = pk;
+                            } else {                       // int8 operand code - 128
+                                const int a = (int)q0 - 128, b = (int)q1 - 128, c = (int)q2 - 128, d = (int)q3 - 128;
+                                *reinterpret_cast<uint32_t*>(reinterpret_cast<int8_t*>(out) + row * ldo + col) =
+                                    (uint32_t)(a & 0xff) | ((uint32_t)(b & 0xff) << 8) | ((uint32_t)(c & 0xff) << 16) |
+                                    ((uint32_t)(d & 0xff) << 24);
+                            }
+                        }
+                    }
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -171,7 +214,7 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
           const float* __restrict__ scale, const float* __restrict__ bias, const float* __restrict__ rowadd,
           int64_t rows_per_batch, const float* __restrict__ residual, int64_t ldr, float* __restrict__ out,
           int64_t ldo, int64_t strideC, float alpha, int inner, int64_t strideA_i, int64_t strideB_i,
-          int64_t strideC_i) {
+          int64_t strideC_i, int out_mode, const float* __restrict__ oqp) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int NA = BM / 64, NB = BN / 64;   // 16-byte direct-to-LDS loads per thread per K-step
     constexpr int LPT = NA + NB;
@@ -182,7 +225,7 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
     constexpr int EPI_BYTES = 4 * 32 * EST * 4;
     constexpr int RA = BM / 16 + 1;                        // batch entries a tile can span (rows_per_batch >= 16)
     constexpr int MAIN_BYTES = STAGES * TILE > EPI_BYTES ? STAGES * TILE : EPI_BYTES;
-    constexpr int SMEM_BYTES = MAIN_BYTES + (2 + RA) * BN * 4;
+    constexpr int SMEM_BYTES = MAIN_BYTES + (2 + RA) * BN * 4 + 16;
     __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM_BYTES];
     float* ec = reinterpret_cast<float*>(smem + MAIN_BYTES);
 
@@ -195,7 +238,10 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
         const int64_t zo = blockIdx.z / inner, zi = blockIdx.z % inner;
         A += zo * strideA_b + zi * strideA_i;
         Bm += zo * strideB_b + zi * strideB_i;
-        out += zo * strideC + zi * strideC_i;
+        const int64_t coff = zo * strideC + zi * strideC_i;      // in output elements
+        out = out_mode == 0 ? out + coff
+              : out_mode == 1 ? reinterpret_cast<float*>(reinterpret_cast<__half*>(out) + coff)
+                              : reinterpret_cast<float*>(reinterpret_cast<int8_t*>(out) + coff);
     }
 
     // ---- staging coordinates.  LDS image is lane-linear (thread t writes bytes [16t, 16t+16) of each
@@ -288,7 +334,7 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
         }
     };
 
-    stage_epilogue_consts<BN, RA>(ec, tid, (int)blockDim.x, m0, n0, M, N, scale, bias, rowadd, rows_per_batch, alpha);
+    stage_epilogue_consts<BN, RA>(ec, tid, (int)blockDim.x, m0, n0, M, N, scale, bias, rowadd, rows_per_batch, alpha, oqp);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // keep the pipeline's vmcnt bookkeeping to LDS-DMA only
 
     typename Acc<I8>::type acc[TM][TN];
@@ -346,8 +392,8 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
         }
     }
 
-    gemm_epilogue<I8, TM, TN, BN, RA, 2>(acc, smem, ec, wave, lane, m0, m0 + wm * (TM * 32), n0 + wn * (TN * 32),
-                                      wn * (TN * 32), M, N, rows_per_batch, rowadd != nullptr, residual, ldr, out, ldo);
+    gemm_epilogue<I8, TM, TN, BN, RA, (TN % 2 == 0 || TN == 3) ? 4 : 2>(acc, smem, ec, wave, lane, m0, m0 + wm * (TM * 32), n0 + wn * (TN * 32),
+                                      wn * (TN * 32), M, N, rows_per_batch, rowadd != nullptr, residual, ldr, out, ldo, out_mode);
 }
 
 // ---- 8-wave variant for the large-M layers: 256 x (64*TN) tile, 128-byte K rows (full cache lines per
@@ -360,7 +406,7 @@ k_gemm_nt8(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, cons
            const float* __restrict__ scale, const float* __restrict__ bias, const float* __restrict__ rowadd,
            int64_t rows_per_batch, const float* __restrict__ residual, int64_t ldr, float* __restrict__ out,
            int64_t ldo, int64_t strideC, float alpha, int inner, int64_t strideA_i, int64_t strideB_i,
-           int64_t strideC_i) {
+           int64_t strideC_i, int out_mode, const float* __restrict__ oqp) {
     constexpr int TM = 2;
     constexpr int BM = 256, BN = 64 * TN;
     constexpr int NA = 4, NB = TN;                 // 64-row passes per operand (512 threads x 16 B = 64 rows x 128 B)
@@ -371,7 +417,7 @@ k_gemm_nt8(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, cons
     constexpr int EPI_BYTES = 8 * 32 * EST * 4;
     constexpr int RA = BM / 16 + 1;
     constexpr int MAIN_BYTES = STAGES * TILE > EPI_BYTES ? STAGES * TILE : EPI_BYTES;
-    constexpr int SMEM_BYTES = MAIN_BYTES + (2 + RA) * BN * 4;
+    constexpr int SMEM_BYTES = MAIN_BYTES + (2 + RA) * BN * 4 + 16;
     __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM_BYTES];
     float* ec = reinterpret_cast<float*>(smem + MAIN_BYTES);
 
@@ -384,7 +430,10 @@ k_gemm_nt8(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, cons
         const int64_t zo = blockIdx.z / inner, zi = blockIdx.z % inner;
         A += zo * strideA_b + zi * strideA_i;
         Bm += zo * strideB_b + zi * strideB_i;
-        out += zo * strideC + zi * strideC_i;
+        const int64_t coff = zo * strideC + zi * strideC_i;      // in output elements
+        out = out_mode == 0 ? out + coff
+              : out_mode == 1 ? reinterpret_cast<float*>(reinterpret_cast<__half*>(out) + coff)
+                              : reinterpret_cast<float*>(reinterpret_cast<int8_t*>(out) + coff);
     }
     const int sr = tid >> 3;
     const int sc = (tid & 7) ^ ((tid >> 4) & 7);      // source chunk = physical chunk ^ ((row >> 1) & 7)
@@ -471,7 +520,7 @@ k_gemm_nt8(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, cons
         }
     };
 
-    stage_epilogue_consts<BN, RA>(ec, tid, (int)blockDim.x, m0, n0, M, N, scale, bias, rowadd, rows_per_batch, alpha);
+    stage_epilogue_consts<BN, RA>(ec, tid, (int)blockDim.x, m0, n0, M, N, scale, bias, rowadd, rows_per_batch, alpha, oqp);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // keep the pipeline's vmcnt bookkeeping to LDS-DMA only
 
     typename Acc<I8>::type acc[TM][TN];
@@ -521,7 +570,7 @@ k_gemm_nt8(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, cons
         }
     }
     gemm_epilogue<I8, TM, TN, BN, RA, 1>(acc, smem, ec, wave, lane, m0, m0 + wm * 64, n0 + wn * (TN * 32), wn * (TN * 32),
-                                      M, N, rows_per_batch, rowadd != nullptr, residual, ldr, out, ldo);
+                                      M, N, rows_per_batch, rowadd != nullptr, residual, ldr, out, ldo, out_mode);
 }
 
 template <bool I8>
@@ -529,7 +578,8 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
                        int64_t M, int64_t N, int64_t Kb, const ConvGeom& g, const float* scale, const float* bias,
                        const float* rowadd, int64_t rpb, const float* residual, int64_t ldr, float* out, int64_t ldo,
                        int64_t sC, int64_t batch, float alpha, hipStream_t st, int inner = 1, int64_t sAi = 0,
-                       int64_t sBi = 0, int64_t sCi = 0) {
+                       int64_t sBi = 0, int64_t sCi = 0, int out_mode = 0, const float* oqp = nullptr) {
+    if (out_mode != 0 && (!oqp || (N & 3) || (ldo & 3))) return EDADM_EINVAL;   // quantised outputs use the 16-byte path
     if (!rowadd) rpb = M;                                    // one (unused) batch entry
     static bool pad_ready = false;
     if (!pad_ready) {       // stream-ordered ahead of the first GEMM; idempotent if it lands inside a captured graph
@@ -546,13 +596,14 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
     const int64_t tiles8 = ((M + 255) / 256) * ((N + 64 * tn - 1) / (64 * tn)) * batch;
     // convolutions whose Cin is a multiple of 64 but not of 128 keep scalar tap arithmetic only with 64-byte K-steps
     const bool nt8_gather_ok = true;
-    if (EDADM_USE_NT8 && tiles8 >= 224 && Kb >= 256 && nt8_gather_ok) {
+    static const int force = getenv("EDADM_GEMM_FORCE") ? atoi(getenv("EDADM_GEMM_FORCE")) : 0;   // diagnostics only
+    if (force != 2 && EDADM_USE_NT8 && (force == 3 || (tiles8 >= 224 && Kb >= 256)) && nt8_gather_ok) {
         const dim3 grid8((unsigned)((N + 64 * tn - 1) / (64 * tn)), (unsigned)((M + 255) / 256), (unsigned)batch);
 #define EDADM_GEMM8_CASE(TN_)                                                                                  \
         if (tn == TN_) {                                                                                       \
             hipLaunchKernelGGL((k_gemm_nt8<I8, TN_>), grid8, dim3(512), 0, st, (const uint8_t*)A, lda_b, sA,   \
                                (const uint8_t*)Bm, ldb_b, sB, M, N, Kb, g, scale, bias, rowadd, rpb, residual, \
-                               ldr, out, ldo, sC, alpha, inner, sAi, sBi, sCi);                                \
+                               ldr, out, ldo, sC, alpha, inner, sAi, sBi, sCi, out_mode, oqp);                 \
             return edadm_launch_status();                                                                      \
         }
         EDADM_GEMM8_CASE(3)
@@ -567,7 +618,7 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
                         (unsigned)batch);                                                                      \
         hipLaunchKernelGGL((k_gemm_nt<I8, TM_, TN_>), grid, blk, 0, st, (const uint8_t*)A, lda_b, sA,          \
                            (const uint8_t*)Bm, ldb_b, sB, M, N, Kb, g, scale, bias, rowadd, rpb, residual, ldr, \
-                           out, ldo, sC, alpha, inner, sAi, sBi, sCi);                                         \
+                           out, ldo, sC, alpha, inner, sAi, sBi, sCi, out_mode, oqp);                          \
         return edadm_launch_status();                                                                          \
     }
     EDADM_GEMM_CASE(2, 3)
@@ -640,4 +691,45 @@ extern "C" int edadm_qgemm_f16(const void* A, int64_t lda, const void* Wt, int64
     if (rowadd && rows_per_batch < 16) return EDADM_EINVAL;   // the epilogue stages <= BM/16+1 row-add rows in LDS
     return launch_gemm<false>(A, lda * 2, 0, Wt, ldw * 2, 0, M, N, K * 2, g, scale, bias, rowadd, rows_per_batch,
                               residual, ldr, out, ldo, 0, 1, 1.0f, (hipStream_t)stream);
+}
+
+// ---- variants whose epilogue feeds an activation quantizer directly (no fp32 round trip through HBM):
+// out_mode 1: f16 operand (code - zp), 2: int8 operand (code - 128), 3: GEGLU over interleaved (a, gate)
+// output columns then int8 operand [M][N/2] (attention.py:37-45 + the consumer's quantizer,
+// quant_layer.py:266-269).  oqp = device float[3] {delta, zp, qmax} of the consuming quantizer.
+extern "C" int edadm_qgemm_i8_q(const int8_t* A, int64_t lda, const int8_t* Wt, int64_t ldw, int64_t M, int64_t N,
+                                int64_t K, const int32_t* geom, const float* scale, const float* bias,
+                                const float* rowadd, int64_t rows_per_batch, const float* residual, int64_t ldr,
+                                void* out, int64_t ldo, int out_mode, const float* oqp, void* stream) {
+    if (!A || !Wt || !out || !scale || M <= 0 || N <= 0 || K <= 0 || (K & 15) || (ldw & 15)) return EDADM_EINVAL;
+    if (out_mode < 1 || out_mode > 3 || !oqp) return EDADM_EINVAL;
+    if (((uintptr_t)A & 15) || ((uintptr_t)Wt & 15)) return EDADM_EINVAL;
+    ConvGeom g{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (geom) {
+        const int32_t* p = geom;
+        g = ConvGeom{p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[9], p[10], p[11], p[12], 0, 0, 0};
+        if (g.mode != 1 || (g.Cin & 15) || (int64_t)g.KH * g.KW * g.Cin != K || g.stride < 1 ||
+            (int64_t)g.B * g.Ho * g.Wo != M)
+            return EDADM_EINVAL;
+    } else if (lda & 15) {
+        return EDADM_EINVAL;
+    }
+    if (rowadd && rows_per_batch < 16) return EDADM_EINVAL;
+    return launch_gemm<true>(A, lda, 0, Wt, ldw, 0, M, N, K, g, scale, bias, rowadd, rows_per_batch, residual, ldr,
+                             (float*)out, ldo, 0, 1, 1.0f, (hipStream_t)stream, 1, 0, 0, 0, out_mode, oqp);
+}
+
+extern "C" int edadm_gemm_f16_nt_q(const void* A, int64_t lda, int64_t strideA, int64_t strideA_i, const void* Bm,
+                                   int64_t ldb, int64_t strideB, int64_t strideB_i, void* C, int64_t ldc,
+                                   int64_t strideC, int64_t strideC_i, int64_t batch, int64_t inner, int64_t M,
+                                   int64_t N, int64_t K, float alpha, int out_mode, const float* oqp, void* stream) {
+    if (!A || !Bm || !C || batch <= 0 || inner <= 0 || M <= 0 || N <= 0 || K <= 0 || (K & 7) || (lda & 7) ||
+        (ldb & 7) || (strideA & 7) || (strideB & 7) || (strideA_i & 7) || (strideB_i & 7))
+        return EDADM_EINVAL;
+    if (out_mode < 1 || out_mode > 2 || !oqp) return EDADM_EINVAL;
+    if (((uintptr_t)A & 15) || ((uintptr_t)Bm & 15)) return EDADM_EINVAL;
+    ConvGeom g{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    return launch_gemm<false>(A, lda * 2, strideA * 2, Bm, ldb * 2, strideB * 2, M, N, K * 2, g, nullptr, nullptr,
+                              nullptr, 1, nullptr, 0, (float*)C, ldc, strideC, batch * inner, alpha, (hipStream_t)stream,
+                              (int)inner, strideA_i * 2, strideB_i * 2, strideC_i, out_mode, oqp);
 }

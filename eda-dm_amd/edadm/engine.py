@@ -111,6 +111,18 @@ class Engine:
         self._attn_cache = {}
         self.graph = None
         self.prof = None
+        # GEGLU is computed in the ff.net[0].proj epilogue: its output channels are re-ordered so that
+        # (a_j, gate_j) sit in adjacent columns (attention.py:37-45: x, gate = proj(x).chunk(2))
+        for m in self.net.modules():
+            if isinstance(m, ldm_unet.GEGLU) and isinstance(m.proj, QuantModule):
+                L0 = self.L(m.proj)
+                if L0.mode == "i8" and len(L0.segs) == 1 and L0.N % 8 == 0:
+                    inner = L0.N // 2
+                    order = torch.stack([torch.arange(inner), torch.arange(inner) + inner], 1).reshape(-1).to(self.dev)
+                    s0 = L0.segs[0]
+                    s0["w"], s0["scale"] = s0["w"][order].contiguous(), s0["scale"][order].contiguous()
+                    L0.bias = L0.bias[order].contiguous()
+                    L0.geglu_interleaved = True
 
     # ------------------------------------------------------------------ primitives
     def _sinusoid(self, t, dim, ddpm):
@@ -139,26 +151,34 @@ class Engine:
             return ops.quant_f16(x2d, L.qp)
         return x2d
 
-    def _gemm(self, L, a, M, geom=None, rowadd=None, rpb=1, residual=None):
+    def _gemm(self, L, a, M, geom=None, rowadd=None, rpb=1, residual=None, out_mode=0, oqp=None):
+        if out_mode:
+            # the only consumer is an activation quantizer: emit its operand from the epilogue
+            assert L.mode == "i8" and len(L.segs) == 1 and geom is None and residual is None
+            s0 = L.segs[0]
+            run = lambda: ops.qgemm_i8_q(a, s0["w"], M, L.N, s0["K"], s0["scale"], L.bias, out_mode, oqp, lda=a.shape[-1])
+            if self.prof is not None:       # bench.py's roofline pass re-launches each recorded GEMM under HIP events
+                self.prof.append((L.mode, L.name, M, L.N, L.K, 2.0 * M * L.N * L.K, run))
+            return run()
         out = torch.empty(M, L.N, dtype=torch.float32, device=self.dev)
         fn = ops.qgemm_i8 if L.mode == "i8" else ops.qgemm_f16
-        ev = None
-        if self.prof is not None:            # bench.py's roofline pass: HIP events on the launch stream
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            ev[0].record()
         if geom is not None:
             s = L.segs[0]
-            fn(a, s["w"], M, L.N, s["K"], s["scale"], L.bias, out, geom=geom, rowadd=rowadd, rows_per_batch=rpb,
-               residual=residual)
+
+            def run():
+                fn(a, s["w"], M, L.N, s["K"], s["scale"], L.bias, out, geom=geom, rowadd=rowadd, rows_per_batch=rpb,
+                   residual=residual)
         else:
             ctot = a.shape[-1]
-            for i, s in enumerate(L.segs):
-                av = a if len(L.segs) == 1 else a[:, s["lo"]:s["hi"]]
-                fn(av, s["w"], M, L.N, s["K"], s["scale"], L.bias if i == 0 else None, out, lda=ctot,
-                   rowadd=rowadd if i == 0 else None, rows_per_batch=rpb, residual=residual if i == 0 else out)
-        if ev is not None:
-            ev[1].record()
-            self.prof.append((L.mode, L.name, M, L.N, L.K, 2.0 * M * L.N * L.K, ev))
+
+            def run():
+                for i, s in enumerate(L.segs):
+                    av = a if len(L.segs) == 1 else a[:, s["lo"]:s["hi"]]
+                    fn(av, s["w"], M, L.N, s["K"], s["scale"], L.bias if i == 0 else None, out, lda=ctot,
+                       rowadd=rowadd if i == 0 else None, rows_per_batch=rpb, residual=residual if i == 0 else out)
+        if self.prof is not None:
+            self.prof.append((L.mode, L.name, M, L.N, L.K, 2.0 * M * L.N * L.K, run))
+        run()
         return out
 
     def lin(self, qm, x2d, rowadd=None, rpb=1, residual=None, pre=None):
@@ -217,9 +237,10 @@ class Engine:
         return self._attn_cache[key]
 
     def attention(self, q2d, k2d, v2d, B, Nq, Nk, heads, d, aq_q, aq_k, aq_v, aq_w, scale, premul=1.0,
-                  qcols=None, kcols=None, vcols=None):
-        """q2d [B*Nq][*], k2d/v2d [B*Nk][*] fp32; head h of q lives at columns qcols[h]..+d.
-        Returns fp32 [B*Nq][heads*d] (heads concatenated)."""
+                  qcols=None, kcols=None, vcols=None, coded=False, out_qp=None):
+        """q2d [B*Nq][*], k2d/v2d [B*Nk][*]: fp32 (quantised here) or, with coded=True, the f16 operands
+        already emitted by the projection epilogues.  Head h of q lives at columns qcols[h]..+d.
+        Returns fp32 [B*Nq][heads*d], or the int8 operand of the consumer when out_qp is given."""
         hd = heads * d
         qcols = qcols or [h * d for h in range(heads)]
         kcols = kcols or [h * d for h in range(heads)]
@@ -236,11 +257,13 @@ class Engine:
                     ops.quant_f16(x2d[:, c:c + d], qp, premul=pm, out=out[:, h * d:(h + 1) * d])
             return out
 
-        qh = codes(q2d, qcols, qpq, B * Nq, premul)
-        kh = codes(k2d, kcols, qpk, B * Nk, premul)
-        vh = codes(v2d, vcols, qpv, B * Nk, 1.0)
-        dpad = (d + 7) // 8 * 8
-        assert dpad == d, "head dim must be a multiple of 8"
+        if coded:
+            qh, kh, vh = q2d, k2d, v2d
+        else:
+            qh = codes(q2d, qcols, qpq, B * Nq, premul)
+            kh = codes(k2d, kcols, qpk, B * Nk, premul)
+            vh = codes(v2d, vcols, qpv, B * Nk, 1.0)
+        assert d % 8 == 0, "head dim must be a multiple of 8"
         s = ops.gemm_f16_nt(qh, hd, Nq * hd, kh, hd, Nk * hd, B, Nq, Nk, d, dq * dk * scale, inner=heads,
                             strideA_i=d, strideB_i=d)
         nkp = (Nk + 7) // 8 * 8
@@ -248,9 +271,13 @@ class Engine:
         vt = torch.empty(B, heads, d, nkp, dtype=torch.float16, device=self.dev)
         for h in range(heads):
             ops.transpose_f16(vh[:, h * d:], hd, Nk * hd, B, Nk, d, nkp, out=vt[:, h], strideO=heads * d * nkp)
+        kw = dict(inner=heads, strideA_i=Nq * nkp, strideB_i=d * nkp, ldc=hd, strideC=Nq * hd, strideC_i=d)
+        if out_qp is not None and hd % 4 == 0:
+            out = torch.empty(B * Nq, hd, dtype=torch.int8, device=self.dev)
+            return ops.gemm_f16_nt_q(p, nkp, heads * Nq * nkp, vt, nkp, heads * d * nkp, B, Nq, d, nkp, dw * dv, out, 2,
+                                     out_qp, **kw)
         out = torch.empty(B * Nq, hd, dtype=torch.float32, device=self.dev)
-        ops.gemm_f16_nt(p, nkp, heads * Nq * nkp, vt, nkp, heads * d * nkp, B, Nq, d, nkp, dw * dv, out=out,
-                        inner=heads, strideA_i=Nq * nkp, strideB_i=d * nkp, ldc=hd, strideC=Nq * hd, strideC_i=d)
+        ops.gemm_f16_nt(p, nkp, heads * Nq * nkp, vt, nkp, heads * d * nkp, B, Nq, d, nkp, dw * dv, out=out, **kw)
         return out
 
     # ------------------------------------------------------------------ DDPM (CIFAR) graph
@@ -275,12 +302,15 @@ class Engine:
         B, H, W, C = x.shape
         N = H * W
         _, (aq, ak, av) = self.gn(blk.norm, x, False, (blk.q, blk.k, blk.v))
-        q = self._gemm(self.L(blk.q), aq.reshape(B * N, C), B * N)
-        k = self._gemm(self.L(blk.k), ak.reshape(B * N, C), B * N)
-        v = self._gemm(self.L(blk.v), av.reshape(B * N, C), B * N)
+        q = self._gemm(self.L(blk.q), aq.reshape(B * N, C), B * N, out_mode=1, oqp=self._aq(blk.act_quantizer_q)[0])
+        k = self._gemm(self.L(blk.k), ak.reshape(B * N, C), B * N, out_mode=1, oqp=self._aq(blk.act_quantizer_k)[0])
+        v = self._gemm(self.L(blk.v), av.reshape(B * N, C), B * N, out_mode=1, oqp=self._aq(blk.act_quantizer_v)[0])
+        Lp = self.L(blk.proj_out)
+        fuse = Lp.mode == "i8" and not Lp.split
         o = self.attention(q, k, v, B, N, N, 1, C, blk.act_quantizer_q, blk.act_quantizer_k, blk.act_quantizer_v,
-                           blk.act_quantizer_w, int(C) ** (-0.5))
-        return self.lin(blk.proj_out, o, residual=x.reshape(B * N, C)).reshape(B, H, W, C)
+                           blk.act_quantizer_w, int(C) ** (-0.5), coded=True, out_qp=Lp.qp if fuse else None)
+        return self.lin(blk.proj_out, None if fuse else o, residual=x.reshape(B * N, C),
+                        pre=o if fuse else None).reshape(B, H, W, C)
 
     def forward_ddpm(self, x, t, context=None):
         net = self.net
@@ -380,14 +410,17 @@ class Engine:
 
     def ldm_cross_attn(self, attn, x2d_q, ctx_ops, B, Nq, Nk, residual):
         """x2d_q: int8 operand for to_q; ctx_ops: (operand for to_k, operand for to_v)."""
-        q = self._gemm(self.L(attn.to_q), x2d_q, B * Nq)
-        k = self._gemm(self.L(attn.to_k), ctx_ops[0], B * Nk)
-        v = self._gemm(self.L(attn.to_v), ctx_ops[1], B * Nk)
+        q = self._gemm(self.L(attn.to_q), x2d_q, B * Nq, out_mode=1, oqp=self._aq(attn.act_quantizer_q)[0])
+        k = self._gemm(self.L(attn.to_k), ctx_ops[0], B * Nk, out_mode=1, oqp=self._aq(attn.act_quantizer_k)[0])
+        v = self._gemm(self.L(attn.to_v), ctx_ops[1], B * Nk, out_mode=1, oqp=self._aq(attn.act_quantizer_v)[0])
         heads = attn.heads
         d = q.shape[1] // heads
+        Lo = self.L(attn.to_out[0])
+        fuse = Lo.mode == "i8" and not Lo.split
         o = self.attention(q, k, v, B, Nq, Nk, heads, d, attn.act_quantizer_q, attn.act_quantizer_k,
-                           attn.act_quantizer_v, attn.act_quantizer_w, attn.scale)
-        return self.lin(attn.to_out[0], o, residual=residual)
+                           attn.act_quantizer_v, attn.act_quantizer_w, attn.scale, coded=True,
+                           out_qp=Lo.qp if fuse else None)
+        return self.lin(attn.to_out[0], None if fuse else o, residual=residual, pre=o if fuse else None)
 
     def ldm_transformer(self, st, x, context):
         B, H, W, C = x.shape
@@ -410,9 +443,11 @@ class Engine:
             t = self.ldm_cross_attn(a2, oq, (ok, ov), B, N, nk, residual=t)
             ff0, ff2 = blk.ff.net[0].proj, blk.ff.net[2]
             (of,) = self.ln(blk.norm3, t, (ff0,))
-            hdn = self._gemm(self.L(ff0), of, B * N)
-            L2 = self.L(ff2)
-            t = self._gemm(L2, ops.geglu_quant_i8(hdn, L2.qp), B * N, residual=t)
+            L0, L2 = self.L(ff0), self.L(ff2)
+            if getattr(L0, "geglu_interleaved", False):
+                t = self._gemm(L2, self._gemm(L0, of, B * N, out_mode=3, oqp=L2.qp), B * N, residual=t)
+            else:
+                t = self._gemm(L2, ops.geglu_quant_i8(self._gemm(L0, of, B * N), L2.qp), B * N, residual=t)
         return self.lin(st.proj_out, t, residual=x.reshape(B * N, C)).reshape(B, H, W, C)
 
     def ldm_legacy_attn(self, ab, x):

@@ -341,6 +341,35 @@ def qgemm_f16(A, Wt, M, N, K, scale, bias, out, geom=None, lda=None, ldw=None, r
     return out
 
 
+_OUT_DT = {1: torch.float16, 2: torch.int8, 3: torch.int8}
+
+
+def qgemm_i8_q(A, Wt, M, N, K, scale, bias, out_mode, oqp, geom=None, lda=None, ldw=None, rowadd=None,
+               rows_per_batch=1, residual=None):
+    """Quantised-output form of qgemm_i8: returns the consumer's MFMA operand directly
+    (1: f16 code-zp [M][N], 2: int8 code-128 [M][N], 3: GEGLU + int8 [M][N/2])."""
+    lda = K if lda is None else lda
+    ldw = K if ldw is None else ldw
+    ncol = N // 2 if out_mode == 3 else N
+    out = torch.empty(M, ncol, dtype=_OUT_DT[out_mode], device=A.device)
+    gptr = ctypes.cast(geom, ctypes.c_void_p) if geom is not None else None
+    lib.call("edadm_qgemm_i8_q", ctypes.c_void_p(A.data_ptr()), int(lda), ctypes.c_void_p(Wt.data_ptr()), int(ldw),
+             int(M), int(N), int(K), gptr, _pf(scale), _pf(bias), _pf(rowadd), int(rows_per_batch), _pf(residual),
+             int(N), ctypes.c_void_p(out.data_ptr()), int(ncol), int(out_mode), _pf(oqp), _stream())
+    return out
+
+
+def gemm_f16_nt_q(A, lda, strideA, Bm, ldb, strideB, batch, M, N, K, alpha, out, out_mode, oqp, inner=1,
+                  strideA_i=0, strideB_i=0, ldc=None, strideC=None, strideC_i=0):
+    ldc = N if ldc is None else ldc
+    strideC = M * N * inner if strideC is None else strideC
+    lib.call("edadm_gemm_f16_nt_q", ctypes.c_void_p(A.data_ptr()), int(lda), int(strideA), int(strideA_i),
+             ctypes.c_void_p(Bm.data_ptr()), int(ldb), int(strideB), int(strideB_i), ctypes.c_void_p(out.data_ptr()),
+             int(ldc), int(strideC), int(strideC_i), int(batch), int(inner), int(M), int(N), int(K), float(alpha),
+             int(out_mode), _pf(oqp), _stream())
+    return out
+
+
 def conv3x3_f32_smalln(x_nhwc, w, bias):
     B, H, W, C = x_nhwc.shape
     N = w.shape[0]

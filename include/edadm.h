@@ -175,6 +175,19 @@ int edadm_qgemm_f16(const void* A, int64_t lda, const void* Wt, int64_t ldw, int
                     int64_t K, const int32_t* geom, const float* scale, const float* bias,
                     const float* rowadd, int64_t rows_per_batch, const float* residual, int64_t ldr,
                     float* out, int64_t ldo, void* stream);
+/* Variants whose epilogue feeds the consuming activation quantizer directly (no fp32 round trip through
+ * HBM): out_mode 1 -> f16 operand (code - zp) [M][N]; 2 -> int8 operand (code - 128) [M][N]; 3 (i8 only)
+ * -> GEGLU a*gelu(gate) over INTERLEAVED (a_j, gate_j) output columns, then int8 operand [M][N/2]
+ * (ldm/modules/attention.py:37-45 followed by quant_layer.py:266-269).  oqp = device float[3]
+ * {delta, zero_point, qmax} of that quantizer; ldo counts output elements. */
+int edadm_qgemm_i8_q(const int8_t* A, int64_t lda, const int8_t* Wt, int64_t ldw, int64_t M, int64_t N,
+                     int64_t K, const int32_t* geom, const float* scale, const float* bias,
+                     const float* rowadd, int64_t rows_per_batch, const float* residual, int64_t ldr,
+                     void* out, int64_t ldo, int out_mode, const float* oqp, void* stream);
+int edadm_gemm_f16_nt_q(const void* A, int64_t lda, int64_t strideA, int64_t strideA_i, const void* Bm,
+                        int64_t ldb, int64_t strideB, int64_t strideB_i, void* C, int64_t ldc,
+                        int64_t strideC, int64_t strideC_i, int64_t batch, int64_t inner, int64_t M,
+                        int64_t N, int64_t K, float alpha, int out_mode, const float* oqp, void* stream);
 /* fp32 3x3 / pad-1 convolution with few output channels (the network's last layer, whose
  * activation quantizer is disabled, quant_model.py:90-95): x NHWC fp32, w [N][3][3][C] fp32. */
 int edadm_conv3x3_f32_smalln(const float* x, const float* w, const float* bias, float* out, int64_t B,

@@ -52,3 +52,20 @@ dense_case(102400, 384, 384, residual=True)
 dense_case(102400, 3072, 384)
 dense_case(8192, 8192, 8192)
 dense_case(4096, 4096, 4096)
+
+def dense_q(M, N, K, mode):
+    a = torch.randint(-128, 128, (M, K), dtype=torch.int8, device=dev)
+    w = torch.randint(-8, 9, (N, K), dtype=torch.int8, device=dev)
+    sc, bs = torch.rand(N, device=dev) * 1e-3, torch.randn(N, device=dev)
+    oqp = torch.tensor([0.05, 128.0, 255.0, 0.0], device=dev)
+    ms = timeit(lambda: ops.qgemm_i8_q(a, w, M, N, K, sc, bs, mode, oqp))
+    print("dense_q mode%d M=%d N=%d K=%d : %.3f ms  %.1f TF/s" % (mode, M, N, K, ms, 2.0 * M * N * K / ms / 1e9))
+
+dense_q(102400, 384, 384, 1)
+dense_q(102400, 384, 384, 2)
+dense_q(102400, 3072, 384, 3)
+dense_case(102400, 3072, 384)
+dense_case(25600, 576, 576)
+dense_case(25600, 576, 576, residual=True)
+dense_case(6400, 960, 960, residual=True)
+dense_case(100, 960, 768)

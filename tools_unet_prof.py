@@ -1,0 +1,21 @@
+"""Diagnostic: 3 eager UNet calls of the frozen LDM-4 engine (for rocprofv3 --kernel-trace --stats)."""
+import sys, os
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "eda-dm_amd"))
+import torch, bench
+dev = torch.device("cuda", 0)
+qnn, sd, calib = bench.build_quantised_unet(dev)
+eng = qnn.freeze()
+B = 50
+x = torch.randn(2 * B, 3, 64, 64, device=dev); t = torch.full((2 * B,), 501, dtype=torch.long, device=dev)
+c = torch.randn(2 * B, 1, 512, device=dev)
+torch.cuda.synchronize()
+import ctypes
+hip = ctypes.CDLL("libamdhip64.so")
+for _ in range(2):
+    eng(x, t, c)
+torch.cuda.synchronize()
+print("MARK")
+for _ in range(10):
+    eng(x, t, c)
+torch.cuda.synchronize()
