@@ -1,0 +1,74 @@
+"""TDAC calibration-set generators — entry points of the reference's scripts/calibration.py
+(`TDAC_cifar_calib_data_generator` :12, `TDAC_imagenet_calib_data_generator` :371; the bedroom / church /
+coco generators are the same recipe over other samplers and return tuples, :156,263,502)."""
+import torch
+
+from ddim.functions.denoising import cali_generalized_steps
+from qdiff.utils import AttentionMap
+from edadm.tdac import tdac_allocate, shuffled_step_list, pick_by_step
+
+
+def TDAC_cifar_calib_data_generator(model, config, lamda, calib_num_samples, num_samples, device, diffusion,
+                                    class_cond=True):
+    """-> (calib_x[N,3,H,W], t[N] (+ cls)): one FP trajectory batch of `num_samples`, features = input of
+    mid.attn_1 at every step, density radius 3.0."""
+    seq = diffusion.seq
+    shape = (num_samples, 3, config.data.image_size, config.data.image_size)
+    img = torch.randn(*shape, device=device)
+    hook = AttentionMap(model.mid.attn_1)
+    feature_map, all_sample = [], None
+    for now_rt, sample_t in enumerate(cali_generalized_steps(model=model, seq=seq, x=img, b=diffusion.betas,
+                                                             eta=diffusion.args.eta, args=diffusion.args)):
+        if now_rt == 0:
+            continue
+        feature_map.append(hook.feature[0])
+        if now_rt == len(seq):
+            all_sample = sample_t[:-1]
+            break
+    hook.remove()
+    _, _, _, t_num = tdac_allocate(feature_map, lamda, calib_num_samples, 3.0)
+    t = shuffled_step_list(t_num, device)
+    parts = [pick_by_step(all_sample, t[i * num_samples:(i + 1) * num_samples])
+             for i in range(int(calib_num_samples / num_samples))]
+    calib_data = torch.cat(parts).to(device)
+    calib_t = torch.tensor([seq[(len(seq) - 1) - int(s)] for s in t]).to(device)
+    if class_cond:
+        return calib_data, calib_t, torch.tensor([1] * num_samples, device=device).long()
+    return calib_data, calib_t
+
+
+def TDAC_imagenet_calib_data_generator(model, args, calib_num_samples, num_samples, device, num_timesteps):
+    """-> (calib_x, t, index, cond, uncond) for class-conditional LDM with classifier-free guidance."""
+    from ldm.models.diffusion.ddim_control import DDIMSampler_control
+    uc = None
+    if args.scale != 1.0:
+        uc = model.get_learned_conditioning({model.cond_stage_key: torch.tensor(calib_num_samples * [1000]).to(model.device)})
+    c = model.get_learned_conditioning({model.cond_stage_key: args.data[:calib_num_samples].to(model.device)})
+    shape = list(getattr(args, "latent_shape", [3, 64, 64]))
+    sampler = DDIMSampler_control(model)
+    unet = model.model.diffusion_model
+    hook = AttentionMap(getattr(unet, "model", unet).middle_block[1])
+    samples, cond, uncond, feature_map, ts = [], [], [], None, None
+    with torch.no_grad():
+        for i in range(int(calib_num_samples / num_samples)):
+            sl = slice(i * num_samples, (i + 1) * num_samples)
+            out = sampler.sample(S=args.custom_steps, conditioning=c[sl], batch_size=num_samples, shape=shape,
+                                 verbose=False, unconditional_guidance_scale=args.scale,
+                                 unconditional_conditioning=None if uc is None else uc[sl], eta=args.ddim_eta,
+                                 hooks=[hook] if i == 0 else None)
+            intermediates = out[1]
+            if i == 0:
+                feature_map = out[2]
+            samples.append(intermediates['x_inter'][:-1])
+            ts = intermediates['ts']
+            cond.append(intermediates['cond'][0])
+            if uc is not None:
+                uncond.append(intermediates['uncond'][0])
+    hook.remove()
+    all_samples = [torch.cat([s[k] for s in samples]) for k in range(num_timesteps)]
+    _, _, _, t_num = tdac_allocate(feature_map, args.lamda, calib_num_samples, 3.0)
+    t = shuffled_step_list(t_num, device)
+    index = (num_timesteps - 1) - t
+    calib_data = pick_by_step(all_samples, t)
+    calib_t = torch.stack([ts[int(s)][0] for s in t]).to(device)
+    return calib_data, calib_t, index, torch.cat(cond), (torch.cat(uncond) if uncond else None)

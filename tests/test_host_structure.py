@@ -105,3 +105,17 @@ def test_schedule_helpers(golden):
         np.testing.assert_array_equal(al, g["ldm/S%d/alphas" % S])
         np.testing.assert_array_equal(alp, g["ldm/S%d/alphas_prev" % S])
         assert ddim_coef_table(al, alp, sig).shape == (S, 5)
+
+
+def test_tdac_allocation_matches_reference(golden):
+    """G9: density / variety scores and the integer allocation with both fix-up variants."""
+    from edadm.tdac import tdac_allocate
+    g = golden("g9_tdac")
+    for key in sorted({k.split("/")[0] for k in g.files}):
+        fm = list(torch.as_tensor(g[key + "/fm"]))
+        for variant in ("gt", "ge"):
+            dense, cd, w, t_num = tdac_allocate(fm, float(g[key + "/lam"]), int(g[key + "/N"]), float(g[key + "/r"]),
+                                                fixup_ge=(variant == "ge"))
+            np.testing.assert_array_equal(dense.numpy(), g[key + "/dense_num"])
+            np.testing.assert_allclose(cd.numpy(), g[key + "/cos_dis"], rtol=1e-5)
+            np.testing.assert_array_equal(t_num.numpy(), g[key + "/t_num_" + variant])

@@ -1,0 +1,110 @@
+"""-m gpu: the reference's script flow end to end on tiny networks through the product API
+(scripts/sample_diffusion_ddim.py:265-323 and sample_diffusion_ldm_imagenet.py:142-249):
+TDAC calibration set -> scale init -> block reconstruction walk -> freeze -> quantised DDIM sampling."""
+import random
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import build_cifar, build_ldm, WQ4, AQ8
+
+pytestmark = pytest.mark.gpu
+
+
+def _recon_kwargs(cali, bs):
+    return dict(cali_data=cali, iters=3, act_quant=True, asym=True, opt_mode='mse', lr_a=1e-4, lr_w=5e-1, p=2.0,
+                weight=0.0001, b_range=(20, 2), warmup=0.2, batch_size=bs, input_prob=0.5, add_loss=0.8,
+                recon_w=True, recon_a=True, keep_gpu=False)
+
+
+def test_cifar_flow(golden):
+    from qdiff import QuantModel, set_weight_quantize_params, set_act_quantize_params, recon_block_Qmodel
+    from qdiff.utils import seed_everything
+    from qdiff.adaptive_rounding import AdaRoundQuantizer
+    from scripts.calibration import TDAC_cifar_calib_data_generator
+    from ddim.functions.denoising import generalized_steps
+    g = golden("g13_cifar_unet")
+    seed_everything(1234)
+    model = build_cifar(g).cuda()
+    qnn = QuantModel(model, WQ4, AQ8, sm_abit=8).cuda().eval()
+    qnn.set_quant_state(False, False)
+    qnn.set_first_last_layer_to_8bit()
+    qnn.disable_network_output_quantization()
+    betas = torch.linspace(1e-4, 0.02, 1000).cuda()
+    seq = [int(s) for s in (np.linspace(0, np.sqrt(1000 * 0.8), 10) ** 2)]
+    diffusion = SimpleNamespace(seq=seq, betas=betas, args=SimpleNamespace(eta=0.0))
+    cali = TDAC_cifar_calib_data_generator(qnn.model, qnn.model.config, 1.2, 64, 32, torch.device("cuda"), diffusion,
+                                           class_cond=False)
+    assert cali[0].shape == (64, 3, 16, 16) and cali[1].shape == (64,)
+    assert set(int(v) for v in cali[1].cpu()) <= set(seq)
+    qnn.model.config.split_shortcut = True
+    set_weight_quantize_params(qnn, cali)
+    set_act_quantize_params(qnn, cali, batch_size=32)
+    qnn = recon_block_Qmodel(None, qnn, cali, _recon_kwargs(cali, 32)).recon()
+    assert qnn.block_count == len(g["units"])
+    n_ada = sum(isinstance(m, AdaRoundQuantizer) and not m.soft_targets for m in qnn.modules())
+    assert n_ada >= len(g["units"])
+    qnn.set_quant_state(True, True)
+    x = torch.randn(4, 3, 16, 16, device="cuda")
+    with torch.no_grad():
+        ref = qnn(x, torch.full((4,), 500.0, device="cuda"))        # fake-quant graph
+    qnn.freeze()
+    with torch.no_grad():
+        out = qnn(x, torch.full((4,), 500.0, device="cuda"))        # int8 engine
+    err = (out - ref).abs()
+    print('cifar flow: engine vs fake-quant graph max %.3f mean %.4f of range %.3f' % (err.max(), err.mean(), ref.abs().max()))
+    assert err.max() < 0.2 * ref.abs().max() and err.mean() < 0.02 * ref.abs().max()
+    xs, x0 = generalized_steps(x, seq, qnn, betas, eta=0.0)
+    assert len(xs) == len(seq) + 1 and torch.isfinite(xs[-1]).all()
+
+
+def test_ldm_conditional_flow(golden):
+    from qdiff import QuantModel
+    from qdiff.utils import seed_everything
+    from qdiff_control import (set_weight_quantize_params_Conditional, set_act_quantize_params_Conditional,
+                               recon_block_Qmodel)
+    from edadm.latent import LatentDiffusionLite, ClassEmbedder
+    from ldm.models.diffusion.ddim_control import DDIMSampler_control
+    from scripts.calibration import TDAC_imagenet_calib_data_generator
+    from edadm.state import quant_state_dict, load_quant_state
+    g = golden("g13_ldm_imagenet")
+    seed_everything(1234)
+    unet = build_ldm(g)
+    ld = LatentDiffusionLite(unet, linear_start=0.0015, linear_end=0.0195, conditioning_key="crossattn",
+                             cond_stage_model=ClassEmbedder(16, n_classes=1001)).cuda().eval()
+    qnn = QuantModel(ld.model.diffusion_model, WQ4, AQ8, act_quant_mode="qdiff", sm_abit=8).cuda().eval()
+    qnn.set_quant_state(False, False)
+    qnn.set_first_last_layer_to_8bit()
+    qnn.disable_network_output_quantization()
+    qnn.set_grad_ckpt(False)
+    ld.model.diffusion_model = qnn
+    args = SimpleNamespace(scale=3.0, custom_steps=10, ddim_eta=0.0, lamda=1.2, latent_shape=[3, 8, 8],
+                           data=torch.randint(0, 1000, (64,)).cuda())
+    cali = TDAC_imagenet_calib_data_generator(ld, args, 64, 32, torch.device("cuda"), 10)
+    assert cali[0].shape == (64, 3, 8, 8) and cali[3].shape == (64, 1, 16) and cali[4].shape == (64, 1, 16)
+    qnn.model.split_shortcut = True
+    set_weight_quantize_params_Conditional(ld, cali, args)
+    set_act_quantize_params_Conditional(ld, cali, args)
+    qnn.set_quant_state(True, True)
+    rq = recon_block_Qmodel(args, qnn, cali, _recon_kwargs(cali, 32)).recon()
+    assert rq is qnn and qnn.block_count == len(g["units"])
+    state = quant_state_dict(qnn)
+    assert any(k.endswith("/alpha") for k in state) and any(k.endswith("/split") for k in state)
+    qnn.set_quant_state(True, True)
+    qnn.freeze()
+    sampler = DDIMSampler_control(ld)
+    c = ld.get_learned_conditioning({"class_label": args.data[:4]})
+    uc = ld.get_learned_conditioning({"class_label": torch.full((4,), 1000).cuda()})
+    samples, _ = sampler.sample(S=10, conditioning=c, batch_size=4, shape=[3, 8, 8], verbose=False,
+                                unconditional_guidance_scale=3.0, unconditional_conditioning=uc, eta=0.0)
+    assert samples.shape == (4, 3, 8, 8) and torch.isfinite(samples).all()
+    # the compiled sampling loop (HIP-graph replay) gives the same latents as the sampler class
+    from edadm.sampling import DDIMLoop
+    x_T = torch.randn(4, 3, 8, 8, device="cuda")
+    a, _ = sampler.sample(S=10, conditioning=c, batch_size=4, shape=[3, 8, 8], verbose=False, x_T=x_T,
+                          unconditional_guidance_scale=3.0, unconditional_conditioning=uc, eta=0.0)
+    loop = DDIMLoop(qnn.engine, (3, 8, 8), 4, steps=10, scale=3.0, context_shape=(1, 16))
+    b = loop.sample(x_T, c, uc)
+    assert (a - b).abs().max() < 1e-4 * max(1.0, float(a.abs().max()))
