@@ -175,6 +175,12 @@ def main():
     torch.cuda.synchronize()
     unet_ms = ev0.elapsed_time(ev1)
 
+    traffic = None
+    try:        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+        with open(os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")) as fh:
+            traffic = json.load(fh)["hbm_bytes_per_launch"]
+    except Exception:
+        pass
     if rank == 0:
         images = B * args.steps * world
         achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12
@@ -189,7 +195,7 @@ def main():
                                    "first-stage VQ decode outside the hot path (SURVEY 8f-3)",
                        "images_per_step": B, "ddim_steps": 20, "cfg_scale": 3.0, "parallelism": "dp%d (independent batches, no collective)" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": I8_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / I8_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / I8_PEAK_TFLOPS, "traffic": traffic,
                          "kernel": "k_gemm_nt<int8> (edadm_qgemm_i8): %d launches per UNet call, %.1f GFLOP, %.2f ms summed"
                                    % (len(i8), gemm_flop / 1e9, gemm_ms),
                          "unet_call_ms": unet_ms,
