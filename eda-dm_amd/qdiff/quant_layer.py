@@ -218,6 +218,24 @@ class UniformAffineQuantizer(nn.Module):
                ' leaf_param={leaf_param}'.format(**self.__dict__)
 
 
+def _contract(fwd_func, x, weight, bias, kw):
+    if fwd_func is F.conv2d and x.is_cuda and kw.get("groups", 1) == 1 and tuple(kw.get("dilation", (1, 1))) == (1, 1):
+        kh, kw_ = weight.shape[2], weight.shape[3]
+        if kh == 1 and kw_ == 1 and tuple(kw["stride"]) == (1, 1) and tuple(kw["padding"]) == (0, 0):
+            out = torch.einsum("oc,bchw->bohw", weight[:, :, 0, 0], x)
+        else:
+            B, C, H, W = x.shape
+            cols = F.unfold(x, (kh, kw_), padding=kw["padding"], stride=kw["stride"])      # [B, C*kh*kw, L]
+            out = torch.matmul(weight.reshape(weight.shape[0], -1), cols)                 # [B, O, L]
+            Ho = (H + 2 * kw["padding"][0] - kh) // kw["stride"][0] + 1
+            out = out.reshape(B, weight.shape[0], Ho, -1)
+        return out if bias is None else out + bias.view(1, -1, 1, 1)
+    if fwd_func is F.conv1d and x.is_cuda and weight.shape[2] == 1:
+        out = torch.einsum("oc,bcl->bol", weight[:, :, 0], x)
+        return out if bias is None else out + bias.view(1, -1, 1)
+    return fwd_func(x, weight, bias, **kw)
+
+
 class QuantModule(nn.Module):
     """Conv2d / Conv1d / Linear with weight and activation quantizers, optional channel split of
     the input (the UNet skip concatenation gets one quantizer per half, quant_layer.py:406-427)."""
@@ -284,9 +302,10 @@ class QuantModule(nn.Module):
             bias = self.bias
         else:
             weight, bias = self.org_weight, self.org_bias
-        # the fp32 contraction of the calibration graph: torch (MIOpen / rocBLAS) for now — see
-        # DESIGN.md "H1 contraction"; the sampling path never comes here (edadm/engine.py)
-        out = self.fwd_func(input, weight, bias, **self.fwd_kwargs)
+        # the fp32 contraction of the calibration graph (interim, DESIGN.md "H1 contraction"): a plain GEMM
+        # over unfolded patches (rocBLAS) — MIOpen's untuned convolution search on gfx950 falls back to
+        # naive kernels that are 100x slower; the sampling path never comes here (edadm/engine.py)
+        out = _contract(self.fwd_func, input, weight, bias, self.fwd_kwargs)
         return self.activation_function(out)
 
     def set_quant_state(self, weight_quant: bool = False, act_quant: bool = False):
