@@ -72,6 +72,55 @@ def build_quantised_unet(device, calib_rows=16, seed=1234):
     return qnn, sd_cpu, dict(weight_init_s=t1 - t0, act_init_s=t2 - t1, calib_rows=calib_rows)
 
 
+def time_calibration(qnn, dev, n_calib=64, iters=2):
+    """Bounded run of the calibration hot loop (H1) on the same full-size UNet: the conditional
+    reconstruction walk (qdiff_control.recon_block_Qmodel, every unit of the model) with `n_calib`
+    synthetic calibration samples (CFG-doubled rows) and `iters` iterations per unit; the shipped setting
+    is 1024 samples x 1000 iterations (sample_diffusion_ldm_imagenet.py:179-196), extrapolated linearly."""
+    import qdiff_control.block_recon as cb
+    import qdiff_control.layer_recon as cl
+    from qdiff_control import recon_block_Qmodel
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n_calib, 3, 64, 64, generator=g).to(dev)
+    ts = np.arange(0, 1000, 50) + 1
+    idx = torch.randint(0, 20, (n_calib,), generator=g)
+    t = torch.tensor(ts[idx.numpy()], dtype=torch.long, device=dev)
+    cond = torch.randn(n_calib, 1, 512, generator=g).to(dev)
+    uncond = torch.randn(1, 1, 512, generator=g).expand(n_calib, 1, 512).contiguous().to(dev)
+    cali = (x, t, idx.to(dev), cond, uncond)
+    kwargs = dict(cali_data=cali, iters=iters, act_quant=True, asym=True, opt_mode='mse', lr_a=1e-4, lr_w=5e-1, p=2.0,
+                  weight=0.0001, b_range=(20, 2), warmup=0.2, batch_size=32, input_prob=0.5, add_loss=0.8,
+                  recon_w=True, recon_a=True, keep_gpu=False)
+    t_cache = [0.0]
+    orig = (cb.save_inp_oup_data, cl.save_inp_oup_data)
+
+    def timed_save(*a, **k):
+        torch.cuda.synchronize()
+        t0 = time.time()
+        r = orig[0](*a, **k)
+        torch.cuda.synchronize()
+        t_cache[0] += time.time() - t0
+        return r
+
+    cb.save_inp_oup_data = cl.save_inp_oup_data = timed_save
+    try:
+        qnn.set_quant_state(True, True)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        recon_block_Qmodel(None, qnn, cali, kwargs).recon()
+        torch.cuda.synchronize()
+        total = time.time() - t0
+    finally:
+        cb.save_inp_oup_data, cl.save_inp_oup_data = orig
+    loop = total - t_cache[0]
+    units = qnn.block_count
+    return dict(units=units, calib_samples=n_calib, iters_per_unit=iters, wall_s=total, caching_s=t_cache[0],
+                loop_s=loop, s_per_iteration_all_units=loop / iters,
+                extrapolated_full_s={"caching_1024_samples": t_cache[0] * 1024 / n_calib,
+                                     "loops_1000_iters": loop / iters * 1000,
+                                     "total": t_cache[0] * 1024 / n_calib + loop / iters * 1000})
+
+
 def cpu_baseline(qnn, sd_cpu):
     """The oracle (CPU restatement of the reference's PyTorch fake-quant path) on this box's host
     cores: ONE UNet forward of one CFG-doubled image (2 rows), 1/20 of an image's work."""
@@ -103,6 +152,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-calib", action="store_true", help="skip the bounded reconstruction timing")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -202,6 +252,11 @@ def main():
                          "unet_algorithmic_tflops": 2 * B * UNET_GFLOP_PER_ROW / unet_ms},
             "calibration": calib,
         }
+        if world == 1 and not args.no_calib:
+            try:
+                line["calibration"]["reconstruction"] = time_calibration(qnn, dev)
+            except Exception as e:
+                line["calibration"]["reconstruction"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(qnn, sd_cpu)
