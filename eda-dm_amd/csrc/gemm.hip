@@ -44,12 +44,28 @@ struct ConvGeom {
     int mode, B, H, W, Cin, Ho, Wo, KH, KW, stride, pad0, ups, padval, r0, r1, r2;
 };
 
-template <bool I8>
-struct Acc;
+// operand types: 0 = int8 (i32 accumulate), 1 = f16, 2 = f32 (v_mfma_f32_32x32x2_f32: exact fp32 FMA chain; the
+// calibration graph's contraction).  A 16-byte fragment is 16 / 8 / 4 k-values.
+template <int DT>
+struct Acc { typedef v16f type; };
 template <>
-struct Acc<true> { typedef v16i type; };
-template <>
-struct Acc<false> { typedef v16f type; };
+struct Acc<0> { typedef v16i type; };
+
+template <int DT>
+__device__ __forceinline__ void mma_step(const uint4& fa, const uint4& fb, typename Acc<DT>::type& acc) {
+    if constexpr (DT == 0) {
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const v4i*>(&fa), *reinterpret_cast<const v4i*>(&fb),
+                                                    acc, 0, 0, 0);
+    } else if constexpr (DT == 1) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const v8h*>(&fa), *reinterpret_cast<const v8h*>(&fb),
+                                                     acc, 0, 0, 0);
+    } else {
+        const float* a = reinterpret_cast<const float*>(&fa);
+        const float* b = reinterpret_cast<const float*>(&fb);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+    }
+}
 
 // round(v / d) with the reference's true-division result at the cost of a multiply: t = v * (1/d) differs from
 // v / d by a couple of ulp, which can only change the rounded integer when t sits within 1e-3 of a .5
@@ -86,8 +102,8 @@ __device__ __forceinline__ void stage_epilogue_consts(float* ec, int tid, int nt
     }
 }
 
-template <bool I8, int TM, int TN, int BN, int RA, int HG>
-__device__ __forceinline__ void gemm_epilogue(typename Acc<I8>::type (&acc)[TM][TN], uint8_t* smem, const float* ec,
+template <int DT, int TM, int TN, int BN, int RA, int HG>
+__device__ __forceinline__ void gemm_epilogue(typename Acc<DT>::type (&acc)[TM][TN], uint8_t* smem, const float* ec,
                                               int wave, int lane, int64_t m0, int64_t row0, int64_t col0, int ecol0,
                                               int64_t M, int64_t N, int64_t rows_per_batch, bool has_rowadd,
                                               const float* __restrict__ residual, int64_t ldr,
@@ -207,7 +223,7 @@ __global__ void k_init_pad_rows() {
     for (int i = threadIdx.x; i < 256 * 64; i += blockDim.x) g_pad_rows[i] = (uint8_t)(i >> 6);
 }
 
-template <bool I8, int TM, int TN>
+template <int DT, int TM, int TN>
 __global__ void __launch_bounds__(256)
 k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const uint8_t* __restrict__ Bm,
           int64_t ldb_b, int64_t strideB_b, int64_t M, int64_t N, int64_t Kb, ConvGeom g,
@@ -337,7 +353,7 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
     stage_epilogue_consts<BN, RA>(ec, tid, (int)blockDim.x, m0, n0, M, N, scale, bias, rowadd, rows_per_batch, alpha, oqp);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // keep the pipeline's vmcnt bookkeeping to LDS-DMA only
 
-    typename Acc<I8>::type acc[TM][TN];
+    typename Acc<DT>::type acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -381,25 +397,19 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    if constexpr (I8) {
-                        acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(
-                            *reinterpret_cast<v4i*>(&fa[i]), *reinterpret_cast<v4i*>(&fb[j]), acc[i][j], 0, 0, 0);
-                    } else {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                            *reinterpret_cast<v8h*>(&fa[i]), *reinterpret_cast<v8h*>(&fb[j]), acc[i][j], 0, 0, 0);
-                    }
+                    mma_step<DT>(fa[i], fb[j], acc[i][j]);
                 }
         }
     }
 
-    gemm_epilogue<I8, TM, TN, BN, RA, (TN % 2 == 0 || TN == 3) ? 4 : 2>(acc, smem, ec, wave, lane, m0, m0 + wm * (TM * 32), n0 + wn * (TN * 32),
+    gemm_epilogue<DT, TM, TN, BN, RA, (TN % 2 == 0 || TN == 3) ? 4 : 2>(acc, smem, ec, wave, lane, m0, m0 + wm * (TM * 32), n0 + wn * (TN * 32),
                                       wn * (TN * 32), M, N, rows_per_batch, rowadd != nullptr, residual, ldr, out, ldo, out_mode);
 }
 
 // ---- 8-wave variant for the large-M layers: 256 x (64*TN) tile, 128-byte K rows (full cache lines per
 // request, half the L2->LDS bytes per flop of the 128-row tile), two LDS stages, 24 MFMAs per wave per
 // barrier.  Same gather / padding / epilogue contract as k_gemm_nt.
-template <bool I8, int TN>
+template <int DT, int TN>
 __global__ void __launch_bounds__(512)
 k_gemm_nt8(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const uint8_t* __restrict__ Bm,
            int64_t ldb_b, int64_t strideB_b, int64_t M, int64_t N, int64_t Kb, ConvGeom g,
@@ -523,7 +533,7 @@ k_gemm_nt8(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, cons
     stage_epilogue_consts<BN, RA>(ec, tid, (int)blockDim.x, m0, n0, M, N, scale, bias, rowadd, rows_per_batch, alpha, oqp);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // keep the pipeline's vmcnt bookkeeping to LDS-DMA only
 
-    typename Acc<I8>::type acc[TM][TN];
+    typename Acc<DT>::type acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -559,21 +569,15 @@ k_gemm_nt8(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, cons
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    if constexpr (I8) {
-                        acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(
-                            *reinterpret_cast<v4i*>(&fa[i]), *reinterpret_cast<v4i*>(&fb[j]), acc[i][j], 0, 0, 0);
-                    } else {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                            *reinterpret_cast<v8h*>(&fa[i]), *reinterpret_cast<v8h*>(&fb[j]), acc[i][j], 0, 0, 0);
-                    }
+                    mma_step<DT>(fa[i], fb[j], acc[i][j]);
                 }
         }
     }
-    gemm_epilogue<I8, TM, TN, BN, RA, 1>(acc, smem, ec, wave, lane, m0, m0 + wm * 64, n0 + wn * (TN * 32), wn * (TN * 32),
+    gemm_epilogue<DT, TM, TN, BN, RA, 1>(acc, smem, ec, wave, lane, m0, m0 + wm * 64, n0 + wn * (TN * 32), wn * (TN * 32),
                                       M, N, rows_per_batch, rowadd != nullptr, residual, ldr, out, ldo, out_mode);
 }
 
-template <bool I8>
+template <int DT>
 static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm, int64_t ldb_b, int64_t sB,
                        int64_t M, int64_t N, int64_t Kb, const ConvGeom& g, const float* scale, const float* bias,
                        const float* rowadd, int64_t rpb, const float* residual, int64_t ldr, float* out, int64_t ldo,
@@ -601,7 +605,7 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
         const dim3 grid8((unsigned)((N + 64 * tn - 1) / (64 * tn)), (unsigned)((M + 255) / 256), (unsigned)batch);
 #define EDADM_GEMM8_CASE(TN_)                                                                                  \
         if (tn == TN_) {                                                                                       \
-            hipLaunchKernelGGL((k_gemm_nt8<I8, TN_>), grid8, dim3(512), 0, st, (const uint8_t*)A, lda_b, sA,   \
+            hipLaunchKernelGGL((k_gemm_nt8<DT, TN_>), grid8, dim3(512), 0, st, (const uint8_t*)A, lda_b, sA,   \
                                (const uint8_t*)Bm, ldb_b, sB, M, N, Kb, g, scale, bias, rowadd, rpb, residual, \
                                ldr, out, ldo, sC, alpha, inner, sAi, sBi, sCi, out_mode, oqp);                 \
             return edadm_launch_status();                                                                      \
@@ -616,7 +620,7 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
     if (tm == TM_ && tn == TN_) {                                                                              \
         const dim3 grid((unsigned)((N + 64 * TN_ - 1) / (64 * TN_)), (unsigned)((M + 64 * TM_ - 1) / (64 * TM_)), \
                         (unsigned)batch);                                                                      \
-        hipLaunchKernelGGL((k_gemm_nt<I8, TM_, TN_>), grid, blk, 0, st, (const uint8_t*)A, lda_b, sA,          \
+        hipLaunchKernelGGL((k_gemm_nt<DT, TM_, TN_>), grid, blk, 0, st, (const uint8_t*)A, lda_b, sA,          \
                            (const uint8_t*)Bm, ldb_b, sB, M, N, Kb, g, scale, bias, rowadd, rpb, residual, ldr, \
                            out, ldo, sC, alpha, inner, sAi, sBi, sCi, out_mode, oqp);                          \
         return edadm_launch_status();                                                                          \
@@ -652,7 +656,7 @@ extern "C" int edadm_qgemm_i8(const int8_t* A, int64_t lda, const int8_t* Wt, in
             return EDADM_EINVAL;
     }
     if (rowadd && rows_per_batch < 16) return EDADM_EINVAL;   // the epilogue stages <= BM/16+1 row-add rows in LDS
-    return launch_gemm<true>(A, lda, 0, Wt, ldw, 0, M, N, K, g, scale, bias, rowadd, rows_per_batch, residual, ldr,
+    return launch_gemm<0>(A, lda, 0, Wt, ldw, 0, M, N, K, g, scale, bias, rowadd, rows_per_batch, residual, ldr,
                              out, ldo, 0, 1, 1.0f, (hipStream_t)stream);
 }
 
@@ -665,7 +669,7 @@ extern "C" int edadm_gemm_f16_nt(const void* A, int64_t lda, int64_t strideA, in
         return EDADM_EINVAL;
     if (((uintptr_t)A & 15) || ((uintptr_t)Bm & 15)) return EDADM_EINVAL;
     ConvGeom g{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    return launch_gemm<false>(A, lda * 2, strideA * 2, Bm, ldb * 2, strideB * 2, M, N, K * 2, g, nullptr, nullptr,
+    return launch_gemm<1>(A, lda * 2, strideA * 2, Bm, ldb * 2, strideB * 2, M, N, K * 2, g, nullptr, nullptr,
                               nullptr, 1, nullptr, 0, C, ldc, strideC, batch * inner, alpha, (hipStream_t)stream,
                               (int)inner, strideA_i * 2, strideB_i * 2, strideC_i);
 }
@@ -689,7 +693,7 @@ extern "C" int edadm_qgemm_f16(const void* A, int64_t lda, const void* Wt, int64
         return EDADM_EINVAL;
     }
     if (rowadd && rows_per_batch < 16) return EDADM_EINVAL;   // the epilogue stages <= BM/16+1 row-add rows in LDS
-    return launch_gemm<false>(A, lda * 2, 0, Wt, ldw * 2, 0, M, N, K * 2, g, scale, bias, rowadd, rows_per_batch,
+    return launch_gemm<1>(A, lda * 2, 0, Wt, ldw * 2, 0, M, N, K * 2, g, scale, bias, rowadd, rows_per_batch,
                               residual, ldr, out, ldo, 0, 1, 1.0f, (hipStream_t)stream);
 }
 
@@ -715,7 +719,7 @@ extern "C" int edadm_qgemm_i8_q(const int8_t* A, int64_t lda, const int8_t* Wt, 
         return EDADM_EINVAL;
     }
     if (rowadd && rows_per_batch < 16) return EDADM_EINVAL;
-    return launch_gemm<true>(A, lda, 0, Wt, ldw, 0, M, N, K, g, scale, bias, rowadd, rows_per_batch, residual, ldr,
+    return launch_gemm<0>(A, lda, 0, Wt, ldw, 0, M, N, K, g, scale, bias, rowadd, rows_per_batch, residual, ldr,
                              (float*)out, ldo, 0, 1, 1.0f, (hipStream_t)stream, 1, 0, 0, 0, out_mode, oqp);
 }
 
@@ -729,7 +733,25 @@ extern "C" int edadm_gemm_f16_nt_q(const void* A, int64_t lda, int64_t strideA, 
     if (out_mode < 1 || out_mode > 2 || !oqp) return EDADM_EINVAL;
     if (((uintptr_t)A & 15) || ((uintptr_t)Bm & 15)) return EDADM_EINVAL;
     ConvGeom g{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    return launch_gemm<false>(A, lda * 2, strideA * 2, Bm, ldb * 2, strideB * 2, M, N, K * 2, g, nullptr, nullptr,
+    return launch_gemm<1>(A, lda * 2, strideA * 2, Bm, ldb * 2, strideB * 2, M, N, K * 2, g, nullptr, nullptr,
                               nullptr, 1, nullptr, 0, (float*)C, ldc, strideC, batch * inner, alpha, (hipStream_t)stream,
                               (int)inner, strideA_i * 2, strideB_i * 2, strideC_i, out_mode, oqp);
+}
+
+// ---- fp32 NT GEMM on v_mfma_f32_32x32x2_f32 for the calibration graph (H1): C[z] = alpha * A[z] . B[z]^T
+// (+ bias[n]) (+ residual[m][n]).  Exact fp32 FMA chains (no reduced-precision path exists on gfx950).
+// quant_layer.py:434 (F.conv2d / F.linear on fake-quantised operands) and its autograd backward are built
+// from this entry point plus the im2col / col2im / transpose / slab-sum kernels below.
+extern "C" int edadm_gemm_f32_nt(const float* A, int64_t lda, int64_t strideA, const float* Bm, int64_t ldb,
+                                 int64_t strideB, float* C, int64_t ldc, int64_t strideC, int64_t batch, int64_t M,
+                                 int64_t N, int64_t K, float alpha, const float* bias, const float* residual,
+                                 int64_t ldr, void* stream) {
+    if (!A || !Bm || !C || batch <= 0 || M <= 0 || N <= 0 || K <= 0 || (K & 3) || (lda & 3) || (ldb & 3) ||
+        (strideA & 3) || (strideB & 3))
+        return EDADM_EINVAL;
+    if (((uintptr_t)A & 15) || ((uintptr_t)Bm & 15)) return EDADM_EINVAL;
+    if (residual && batch != 1) return EDADM_EINVAL;
+    ConvGeom g{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    return launch_gemm<2>(A, lda * 4, strideA * 4, Bm, ldb * 4, strideB * 4, M, N, K * 4, g, nullptr, bias, nullptr, 1,
+                          residual, ldr, C, ldc, strideC, batch, alpha, (hipStream_t)stream);
 }

@@ -519,3 +519,81 @@ extern "C" int edadm_unpack_w4(const uint8_t* packed, const float* zp, int8_t* o
                        zp, out, rows, cols);
     return edadm_launch_status();
 }
+
+// ------------------------------------------------------------------ fp32 im2col / col2im / slab sum (H1 contraction)
+// NHWC x[B][H][W][C] -> cols[m][(ky*KW+kx)*C + c], m = (b, y, x) over the Ho x Wo outputs; zero padding.
+__global__ void __launch_bounds__(256) k_im2col_f32(const float* __restrict__ x, float* __restrict__ cols, int64_t B,
+                                                    int64_t H, int64_t W, int64_t C, int64_t Ho, int64_t Wo, int KH,
+                                                    int KW, int stride, int pad) {
+    const int64_t C4 = C >> 2, K4 = (int64_t)KH * KW * C4;
+    const int64_t n = B * Ho * Wo * K4, st = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += st) {
+        const int64_t m = i / K4, k = i - m * K4;
+        const int tap = (int)(k / C4);
+        const int64_t c4 = k - (int64_t)tap * C4;
+        const int64_t b = m / (Ho * Wo), r = m - b * Ho * Wo, y = r / Wo, xx = r - y * Wo;
+        const int64_t iy = y * stride + tap / KW - pad, ix = xx * stride + tap % KW - pad;
+        float4 v = make_float4(0, 0, 0, 0);
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = reinterpret_cast<const float4*>(x)[((b * H + iy) * W + ix) * C4 + c4];
+        reinterpret_cast<float4*>(cols)[i] = v;
+    }
+}
+extern "C" int edadm_im2col_f32(const float* x, float* cols, int64_t B, int64_t H, int64_t W, int64_t C, int64_t Ho,
+                                int64_t Wo, int KH, int KW, int stride, int pad, void* stream) {
+    if (!x || !cols || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || Ho <= 0 || Wo <= 0 || KH < 1 || KW < 1 ||
+        stride < 1 || pad < 0)
+        return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_im2col_f32, dim3(edadm_grid(B * Ho * Wo * KH * KW * C / 4, 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, cols, B, H, W, C, Ho, Wo, KH, KW, stride, pad);
+    return edadm_launch_status();
+}
+// gather form of the adjoint (deterministic): dx[b][iy][ix][c] = sum over taps of dcols at the output pixel that read it
+__global__ void __launch_bounds__(256) k_col2im_f32(const float* __restrict__ dcols, float* __restrict__ dx, int64_t B,
+                                                    int64_t H, int64_t W, int64_t C, int64_t Ho, int64_t Wo, int KH,
+                                                    int KW, int stride, int pad) {
+    const int64_t C4 = C >> 2, K4 = (int64_t)KH * KW * C4;
+    const int64_t n = B * H * W * C4, st = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += st) {
+        const int64_t c4 = i % C4, p = i / C4, ix = p % W, iy = (p / W) % H, b = p / (W * H);
+        float4 acc = make_float4(0, 0, 0, 0);
+        for (int ky = 0; ky < KH; ++ky) {
+            const int64_t ty = iy + pad - ky;
+            if (ty < 0 || ty % stride) continue;
+            const int64_t y = ty / stride;
+            if (y >= Ho) continue;
+            for (int kx = 0; kx < KW; ++kx) {
+                const int64_t tx = ix + pad - kx;
+                if (tx < 0 || tx % stride) continue;
+                const int64_t xo = tx / stride;
+                if (xo >= Wo) continue;
+                const float4 v = reinterpret_cast<const float4*>(dcols)[((b * Ho + y) * Wo + xo) * K4 + (ky * KW + kx) * C4 + c4];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        }
+        reinterpret_cast<float4*>(dx)[i] = acc;
+    }
+}
+extern "C" int edadm_col2im_f32(const float* dcols, float* dx, int64_t B, int64_t H, int64_t W, int64_t C, int64_t Ho,
+                                int64_t Wo, int KH, int KW, int stride, int pad, void* stream) {
+    if (!dcols || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || Ho <= 0 || Wo <= 0 || KH < 1 || KW < 1 ||
+        stride < 1 || pad < 0)
+        return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_col2im_f32, dim3(edadm_grid(B * H * W * C / 4, 256)), dim3(256), 0, (hipStream_t)stream, dcols,
+                       dx, B, H, W, C, Ho, Wo, KH, KW, stride, pad);
+    return edadm_launch_status();
+}
+// out[i] = sum_s slabs[s][i] in slab order (split-K partials of the weight gradient; deterministic)
+__global__ void __launch_bounds__(256) k_sum_slabs(const float* __restrict__ slabs, float* __restrict__ out, int64_t n,
+                                                   int64_t S) {
+    const int64_t st = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += st) {
+        float a = 0.f;
+        for (int64_t s = 0; s < S; ++s) a += slabs[s * n + i];
+        out[i] = a;
+    }
+}
+extern "C" int edadm_sum_slabs(const float* slabs, float* out, int64_t n, int64_t S, void* stream) {
+    if (!slabs || !out || n <= 0 || S <= 0) return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_sum_slabs, dim3(edadm_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, slabs, out, n, S);
+    return edadm_launch_status();
+}

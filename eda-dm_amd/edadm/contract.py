@@ -1,0 +1,154 @@
+"""fp32 contraction of the calibration graph (H1) on hand-written kernels: `conv2d` / `conv1d(k=1)` /
+`linear` forward and autograd backward built from edadm_gemm_f32_nt (exact-fp32 MFMA, NT form),
+edadm_im2col_f32 / edadm_col2im_f32 and a split-K transposed product for the weight gradient
+(quant_layer.py:434 and the `loss.backward()` of block_recon.py:197).
+
+    forward   Y[m][o]  = cols[m][k] . W[o][k]          cols = im2col(X) (NHWC rows), k = (ky, kx, c)
+    dX        dcols    = dY[m][o] . W^T[k][o]  -> col2im
+    dW        dW[o][k] = sum_m dY^T[o][m] . cols^T[k][m]   split over m into S slabs, summed in order
+"""
+import torch
+
+from . import ops
+
+
+def _split(M, O, K):
+    """Number of slabs along the reduction (row) axis for the weight gradient: enough workgroups for the
+    256 CUs, slab length a multiple of 16 floats."""
+    tiles = ((O + 127) // 128) * ((K + 127) // 128)
+    s = 1
+    while tiles * s < 256 and s < 64 and M % (s * 2 * 16) == 0 and M // (s * 2) >= 256:
+        s *= 2
+    return s
+
+
+def _matmul_nt(a2d, w2d, bias=None):
+    """[M][K] . [N][K]^T; few-tile shapes (the 8x8 / 16x16 levels) are split along K into slabs so that
+    the launch still covers the 256 CUs, and the slabs are summed in a fixed order."""
+    M, K = a2d.shape
+    N = w2d.shape[0]
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    S = 1
+    while tiles * S < 192 and K % (S * 2 * 16) == 0 and K // (S * 2) >= 512:
+        S *= 2
+    if S == 1:
+        return ops.gemm_f32_nt(a2d, w2d, M, N, K, bias=bias)
+    Ks = K // S
+    slabs = ops.gemm_f32_nt(a2d, w2d, M, N, Ks, lda=K, ldb=K, batch=S, strideA=Ks, strideB=Ks)
+    out = ops.sum_slabs(slabs)
+    return out if bias is None else out.add_(bias)
+
+
+def _wgrad(gy2d, a2d):
+    """dW[o][k] = gy2d^T . a2d  (gy2d [M][O], a2d [M][K])."""
+    M, O = gy2d.shape
+    K = a2d.shape[1]
+    if M % 4:                                   # the reduction length must be a multiple of 4 floats: zero rows add 0
+        Mp = (M + 3) // 4 * 4
+        gy2d = torch.cat([gy2d, gy2d.new_zeros(Mp - M, O)])
+        a2d = torch.cat([a2d, a2d.new_zeros(Mp - M, K)])
+        M = Mp
+    gyT, aT = ops.transpose_f32(gy2d), ops.transpose_f32(a2d)            # [O][M], [K][M]
+    S = _split(M, O, K)
+    Ms = M // S
+    if S == 1:
+        return ops.gemm_f32_nt(gyT, aT, O, K, M)
+    slabs = ops.gemm_f32_nt(gyT, aT, O, K, Ms, lda=M, ldb=M, batch=S, strideA=Ms, strideB=Ms)
+    return ops.sum_slabs(slabs)
+
+
+def _pad4(t2d):
+    """K (row length) must be a multiple of 4 floats for the 16-byte staging: zero-pad the tail."""
+    K = t2d.shape[1]
+    if K % 4 == 0:
+        return t2d, K
+    Kp = (K + 3) // 4 * 4
+    out = torch.zeros(t2d.shape[0], Kp, dtype=t2d.dtype, device=t2d.device)
+    out[:, :K] = t2d
+    return out, K
+
+
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        x2p, K = _pad4(x2)
+        wp, _ = _pad4(weight.contiguous())
+        out = _matmul_nt(x2p, wp, bias)
+        ctx.save_for_backward(x2p, wp)
+        ctx.meta = (x.shape, K, bias is not None)
+        return out.reshape(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2p, wp = ctx.saved_tensors
+        xshape, K, has_bias = ctx.meta
+        gy2 = gy.reshape(-1, gy.shape[-1]).contiguous()
+        gy2p, O = _pad4(gy2)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            wT, _ = _pad4(ops.transpose_f32(wp))                                   # [Kp][O]
+            gx = _matmul_nt(gy2p, wT)[:, :K].reshape(xshape)
+        if ctx.needs_input_grad[1]:
+            gw = _wgrad(gy2, x2p)[:, :K].contiguous()
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = gy2.sum(0)
+        return gx, gw, gb
+
+
+class _Conv2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad):
+        B, C, H, W = x.shape
+        O, _, KH, KW = weight.shape
+        Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+        xh = ops.nchw_to_nhwc(x.contiguous())
+        if C % 4:                                            # tiny-Cin first layer: pad channels to 4
+            Cp = (C + 3) // 4 * 4
+            xp = torch.zeros(B, H, W, Cp, dtype=x.dtype, device=x.device)
+            xp[..., :C] = xh
+            wp = torch.zeros(O, Cp, KH, KW, dtype=x.dtype, device=x.device)
+            wp[:, :C] = weight
+            xh, wsrc = xp, wp
+        else:
+            Cp, wsrc = C, weight
+        one = KH == 1 and KW == 1 and stride == 1 and pad == 0
+        cols = xh.reshape(B * H * W, Cp) if one else ops.im2col_f32(xh, KH, KW, stride, pad, Ho, Wo)
+        w2 = wsrc.permute(0, 2, 3, 1).reshape(O, KH * KW * Cp).contiguous()
+        out = _matmul_nt(cols, w2, bias)                                            # [M][O] (NHWC rows)
+        ctx.save_for_backward(cols, w2)
+        ctx.meta = (B, C, Cp, H, W, O, KH, KW, stride, pad, Ho, Wo, one, bias is not None)
+        return ops.nhwc_to_nchw(out.reshape(B, Ho, Wo, O))
+
+    @staticmethod
+    def backward(ctx, gy):
+        cols, w2 = ctx.saved_tensors
+        B, C, Cp, H, W, O, KH, KW, stride, pad, Ho, Wo, one, has_bias = ctx.meta
+        gyh = ops.nchw_to_nhwc(gy.contiguous()).reshape(B * Ho * Wo, O)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gyp, _ = _pad4(gyh)
+            w2t, _ = _pad4(ops.transpose_f32(w2))                                     # [K][O]
+            dcols = _matmul_nt(gyp, w2t)                                               # [M][K]
+            dxh = dcols.reshape(B, H, W, Cp) if one else ops.col2im_f32(dcols, B, H, W, Cp, KH, KW, stride, pad, Ho, Wo)
+            gx = ops.nhwc_to_nchw(dxh[..., :C].contiguous() if Cp != C else dxh)
+        if ctx.needs_input_grad[1]:
+            gw2 = _wgrad(gyh, cols)                                                   # [O][KH*KW*Cp]
+            gw = gw2.reshape(O, KH, KW, Cp)[..., :C].permute(0, 3, 1, 2).contiguous()
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = gyh.sum(0)
+        return gx, gw, gb, None, None
+
+
+def linear(x, weight, bias=None):
+    return _LinearFn.apply(x, weight, bias)
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0):
+    return _Conv2dFn.apply(x, weight, bias, int(stride), int(padding))
+
+
+def conv1d_k1(x, weight, bias=None):
+    """Conv1d with kernel 1 over [B][C][L] (attention qkv / proj_out of the legacy AttentionBlock)."""
+    y = _LinearFn.apply(x.permute(0, 2, 1), weight[:, :, 0], bias)
+    return y.permute(0, 2, 1)

@@ -400,3 +400,49 @@ def unpack_w4(packed, zp, rows, cols):
     out = torch.empty(rows, cols, dtype=torch.int8, device=packed.device)
     lib.call("edadm_unpack_w4", _p(packed, torch.uint8), _pf(zp), _p(out, torch.int8), rows, cols, _stream())
     return out
+
+
+# ------------------------------------------------------------------------------ fp32 contraction (H1)
+def gemm_f32_nt(A, Bm, M, N, K, alpha=1.0, bias=None, residual=None, out=None, lda=None, ldb=None, batch=1,
+                strideA=0, strideB=0, strideC=None):
+    """C[z][M][N] = alpha * A[z] . B[z]^T (+bias[n]) (+residual) on the fp32 MFMA."""
+    lda = K if lda is None else lda
+    ldb = K if ldb is None else ldb
+    strideC = M * N if strideC is None else strideC
+    if out is None:
+        out = torch.empty((batch, M, N) if batch > 1 else (M, N), dtype=torch.float32, device=A.device)
+    lib.call("edadm_gemm_f32_nt", ctypes.c_void_p(A.data_ptr()), int(lda), int(strideA), ctypes.c_void_p(Bm.data_ptr()),
+             int(ldb), int(strideB), _pf(out), int(N), int(strideC), int(batch), int(M), int(N), int(K), float(alpha),
+             _pf(bias), _pf(residual), int(N), _stream())
+    return out
+
+
+def im2col_f32(x_nhwc, KH, KW, stride, pad, Ho, Wo):
+    B, H, W, C = x_nhwc.shape
+    cols = torch.empty(B * Ho * Wo, KH * KW * C, dtype=torch.float32, device=x_nhwc.device)
+    lib.call("edadm_im2col_f32", _pf(x_nhwc), _pf(cols), B, H, W, C, Ho, Wo, int(KH), int(KW), int(stride), int(pad),
+             _stream())
+    return cols
+
+
+def col2im_f32(dcols, B, H, W, C, KH, KW, stride, pad, Ho, Wo):
+    dx = torch.empty(B, H, W, C, dtype=torch.float32, device=dcols.device)
+    lib.call("edadm_col2im_f32", _pf(dcols), _pf(dx), B, H, W, C, Ho, Wo, int(KH), int(KW), int(stride), int(pad),
+             _stream())
+    return dx
+
+
+def transpose_f32(x2d):
+    """[R][C] -> [C][R]."""
+    R, C = x2d.shape
+    out = torch.empty(C, R, dtype=torch.float32, device=x2d.device)
+    lib.call("edadm_nchw_to_nhwc", _pf(x2d), _pf(out), 1, R, C, _stream())
+    return out
+
+
+def sum_slabs(slabs):
+    S = slabs.shape[0]
+    n = slabs[0].numel()
+    out = torch.empty(slabs.shape[1:], dtype=torch.float32, device=slabs.device)
+    lib.call("edadm_sum_slabs", _pf(slabs), _pf(out), n, S, _stream())
+    return out

@@ -9,6 +9,7 @@ re-implemented on the HIP kernels of libedadm.so:
 Device tensors only: there is no CPU code path (ops raise on host tensors).
 """
 import logging
+import os
 import random
 
 import torch
@@ -219,7 +220,27 @@ class UniformAffineQuantizer(nn.Module):
 
 
 def _contract(fwd_func, x, weight, bias, kw):
-    if fwd_func is F.conv2d and x.is_cuda and kw.get("groups", 1) == 1 and tuple(kw.get("dilation", (1, 1))) == (1, 1):
+    """The contraction of quant_layer.py:434 on the fp32-MFMA kernels of edadm.contract (im2col + NT
+    GEMM, autograd backward through the same kernels). EDADM_CONTRACT=blas routes the GEMM through
+    torch.matmul (rocBLAS) instead -- a measurement leg only (tools/calib_bench.py), never a fallback:
+    host tensors go to the plain torch functional, as the reference's do."""
+    if not x.is_cuda:
+        return fwd_func(x, weight, bias, **kw)
+    if os.environ.get("EDADM_CONTRACT", "") == "blas":
+        return _contract_blas(fwd_func, x, weight, bias, kw)
+    from edadm import contract
+    if fwd_func is F.linear:
+        return contract.linear(x, weight, bias)
+    if fwd_func is F.conv1d and weight.shape[2] == 1:
+        return contract.conv1d_k1(x, weight, bias)
+    if (fwd_func is F.conv2d and kw.get("groups", 1) == 1 and tuple(kw.get("dilation", (1, 1))) == (1, 1)
+            and kw["stride"][0] == kw["stride"][1] and kw["padding"][0] == kw["padding"][1]):
+        return contract.conv2d(x, weight, bias, kw["stride"][0], kw["padding"][0])
+    raise NotImplementedError("contraction %s %s %s" % (fwd_func.__name__, tuple(weight.shape), kw))
+
+
+def _contract_blas(fwd_func, x, weight, bias, kw):
+    if fwd_func is F.conv2d:
         kh, kw_ = weight.shape[2], weight.shape[3]
         if kh == 1 and kw_ == 1 and tuple(kw["stride"]) == (1, 1) and tuple(kw["padding"]) == (0, 0):
             out = torch.einsum("oc,bchw->bohw", weight[:, :, 0, 0], x)
@@ -230,7 +251,7 @@ def _contract(fwd_func, x, weight, bias, kw):
             Ho = (H + 2 * kw["padding"][0] - kh) // kw["stride"][0] + 1
             out = out.reshape(B, weight.shape[0], Ho, -1)
         return out if bias is None else out + bias.view(1, -1, 1, 1)
-    if fwd_func is F.conv1d and x.is_cuda and weight.shape[2] == 1:
+    if fwd_func is F.conv1d:
         out = torch.einsum("oc,bcl->bol", weight[:, :, 0], x)
         return out if bias is None else out + bias.view(1, -1, 1)
     return fwd_func(x, weight, bias, **kw)

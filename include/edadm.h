@@ -188,6 +188,20 @@ int edadm_gemm_f16_nt_q(const void* A, int64_t lda, int64_t strideA, int64_t str
                         int64_t ldb, int64_t strideB, int64_t strideB_i, void* C, int64_t ldc,
                         int64_t strideC, int64_t strideC_i, int64_t batch, int64_t inner, int64_t M,
                         int64_t N, int64_t K, float alpha, int out_mode, const float* oqp, void* stream);
+/* ---- fp32 contraction of the calibration graph (H1) -----------------------------------------------
+ * quant_layer.py:434 `F.conv2d / F.linear` on fake-quantised operands and its autograd backward
+ * (block_recon.py:197): C[z] = alpha * A[z] . B[z]^T (+ bias[n]) (+ residual[m][n]) on the exact-fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32); convolutions through im2col (forward), col2im (input gradient) and a
+ * split-K transposed product + slab sum (weight gradient); all NHWC, deterministic. */
+int edadm_gemm_f32_nt(const float* A, int64_t lda, int64_t strideA, const float* Bm, int64_t ldb,
+                      int64_t strideB, float* C, int64_t ldc, int64_t strideC, int64_t batch, int64_t M,
+                      int64_t N, int64_t K, float alpha, const float* bias, const float* residual,
+                      int64_t ldr, void* stream);
+int edadm_im2col_f32(const float* x, float* cols, int64_t B, int64_t H, int64_t W, int64_t C, int64_t Ho,
+                     int64_t Wo, int KH, int KW, int stride, int pad, void* stream);
+int edadm_col2im_f32(const float* dcols, float* dx, int64_t B, int64_t H, int64_t W, int64_t C, int64_t Ho,
+                     int64_t Wo, int KH, int KW, int stride, int pad, void* stream);
+int edadm_sum_slabs(const float* slabs, float* out, int64_t n, int64_t S, void* stream);
 /* fp32 3x3 / pad-1 convolution with few output channels (the network's last layer, whose
  * activation quantizer is disabled, quant_model.py:90-95): x NHWC fp32, w [N][3][3][C] fp32. */
 int edadm_conv3x3_f32_smalln(const float* x, const float* w, const float* bias, float* out, int64_t B,
