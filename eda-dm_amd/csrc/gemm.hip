@@ -13,6 +13,12 @@
 // MFMAs (double-buffered LDS, one barrier per K-step).  A and B fragments use the same
 // (lane, byte) -> k map, so the dot product is independent of the hardware's k numbering.
 #include "common.h"
+// This file is compiled once per operand type (Makefile: -DEDADM_GEMM_DT=0 int8, 1 f16, 2 f32); each object holds
+// the kernels and C entry points of that type only, so the three builds run in parallel.
+#ifndef EDADM_GEMM_DT
+#error "compile with -DEDADM_GEMM_DT=0|1|2"
+#endif
+#include <type_traits>
 #include "../../include/edadm.h"
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
@@ -69,12 +75,45 @@ __device__ __forceinline__ void mma_step(const uint4& fa, const uint4& fb, typen
 
 // round(v / d) with the reference's true-division result at the cost of a multiply: t = v * (1/d) differs from
 // v / d by a couple of ulp, which can only change the rounded integer when t sits within 1e-3 of a .5
-// boundary; those (rare) lanes redo the IEEE division.
+// boundary (|t| < 1024; larger magnitudes saturate in the clamp that follows).  Those rare lanes redo the IEEE
+// division behind a REAL branch: the empty asm keeps the compiler from if-converting it into an unconditional
+// 10-instruction division per element.
 __device__ __forceinline__ float rint_div(float v, float d, float inv_d) {
-    float t = v * inv_d;
-    const float f = t - floorf(t);
-    if (fabsf(f - 0.5f) < 1e-3f) t = v / d;
-    return rintf(t);
+    const float t = v * inv_d;
+    float r = rintf(t);
+    if (__builtin_expect(fabsf(t - r) > 0.499f, 0)) {
+        asm volatile("" : "+v"(r));
+        r = rintf(v / d);
+    }
+    return r;
+}
+
+template <int NV>
+__device__ __forceinline__ void rint_div_n(const float (&v)[NV], float d, float inv_d, float (&r)[NV]) {
+    bool near = false;
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+        const float t = v[e] * inv_d;
+        r[e] = rintf(t);
+        near |= fabsf(t - r[e]) > 0.499f;
+    }
+    if (__builtin_expect(near, 0)) {                       // one branch per group
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+            asm volatile("" : "+v"(r[e]));
+            r[e] = rintf(v[e] / d);
+        }
+    }
+}
+
+// four quantised codes (float, already clamped to [0, 255]) -> int8 operand bytes code - 128
+__device__ __forceinline__ uint32_t pack_codes_i8(const float (&q)[4]) {
+    uint32_t w = 0;
+    w = __builtin_amdgcn_cvt_pk_u8_f32(q[0], 0, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(q[1], 1, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(q[2], 2, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(q[3], 3, w);
+    return w ^ 0x80808080u;
 }
 
 // Per-column epilogue constants live in LDS (scale, bias, and the time-embedding rows of the few batch
@@ -163,8 +202,8 @@ __device__ __forceinline__ void gemm_epilogue(typename Acc<DT>::type (&acc)[TM][
                         const float od = ec[(2 + RA) * BN], oz = ec[(2 + RA) * BN + 1], oq = ec[(2 + RA) * BN + 2];
                         const float oi = 1.0f / od;
                         if (out_mode == 3) {               // GEGLU on interleaved (a, gate) columns -> int8 operand
-                            const float y0 = v.x * (0.5f * v.y * (1.0f + erff(v.y * 0.70710678118654752440f)));
-                            const float y1 = v.z * (0.5f * v.w * (1.0f + erff(v.w * 0.70710678118654752440f)));
+                            const float y0 = v.x * (0.5f * v.y * (1.0f + erf_fast(v.y * 0.70710678118654752440f)));
+                            const float y1 = v.z * (0.5f * v.w * (1.0f + erf_fast(v.w * 0.70710678118654752440f)));
                             const int c0 = (int)fminf(fmaxf(rint_div(y0, od, oi) + oz, 0.f), oq) - 128;
                             const int c1 = (int)fminf(fmaxf(rint_div(y1, od, oi) + oz, 0.f), oq) - 128;
                             *reinterpret_cast<uint16_t*>(reinterpret_cast<int8_t*>(out) + row * ldo + (col >> 1)) =
@@ -216,15 +255,195 @@ __device__ __forceinline__ void gemm_epilogue(typename Acc<DT>::type (&acc)[TM][
     }
 }
 
+// ---- register-direct epilogue for fp32 outputs of full tiles.  In the MFMA accumulator layout a lane owns ONE
+// column per 32-wide block (col = 32 j + lane%32) and rows 8g + 4 (lane/32) + e: the per-column constants are
+// per-lane registers (one FMA per output, no LDS round trip), a store instruction writes two full 128-byte row
+// segments, and the address is a wave-uniform row pointer (SGPR pair, bumped on the scalar unit) + one fixed
+// 32-bit lane offset.  Residual loads use the same layout and run DEPTH row-groups ahead of the stores, so the
+// in-order vmcnt never makes a load wait behind a store issued before it.
+template <int TN>
+struct EpiRegs {
+    float s[TN], b[TN], ra0[TN], ra1[TN];
+    int64_t boundary;          // first row of the second batch entry the wave's rows can reach
+};
+
+template <int TN, int BN>
+__device__ __forceinline__ void load_epi_regs(EpiRegs<TN>& er, const float* ec, int lane, int64_t m0, int64_t row0, int ecol0,
+                                              int64_t rows_per_batch) {
+    const int fr = lane & 31;
+    const int64_t bw = row0 / rows_per_batch;
+    const int bj = (int)(bw - m0 / rows_per_batch);        // staged row-add entry of the wave's first row
+    er.boundary = (bw + 1) * rows_per_batch;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int ecol = ecol0 + j * 32 + fr;
+        er.s[j] = ec[ecol];
+        er.b[j] = ec[BN + ecol];
+        er.ra0[j] = ec[(2 + bj) * BN + ecol];
+        er.ra1[j] = ec[(3 + bj) * BN + ecol];
+    }
+}
+
+__device__ __forceinline__ int64_t uniform_i64(int64_t v) {  // pin a wave-uniform 64-bit value to an SGPR pair
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+template <int DT, int TM, int TN, bool HAS_RA, bool HAS_RES>
+__device__ __forceinline__ void epilogue_direct_body(typename Acc<DT>::type (&acc)[TM][TN], const EpiRegs<TN>& er, int lane,
+                                                     int64_t row0, int64_t col0, const float* __restrict__ residual,
+                                                     int64_t ldr, float* __restrict__ out, int64_t ldo) {
+    const int fr = lane & 31, fh4 = (lane >> 5) * 4;
+    constexpr int NG = TM * 4;                             // row groups: 4 rows x TN columns per lane each
+    constexpr int DEPTH = 2;
+    const uint32_t ooff = (uint32_t)(fh4 * (int)ldo + fr) * 4u;
+    const uint32_t roff = (uint32_t)(fh4 * (int)ldr + fr) * 4u;
+    const int64_t rbase = uniform_i64((row0 * ldr + col0) * 4);      // byte offsets of the wave's tile corner
+    const int64_t obase = uniform_i64((row0 * ldo + col0) * 4);
+    const char* resb = reinterpret_cast<const char*>(residual);
+    char* outb = reinterpret_cast<char*>(out);
+    const int64_t lim64 = er.boundary - row0;              // rows (relative) from which the second batch entry applies
+    const int lim = __builtin_amdgcn_readfirstlane((int)(lim64 > (1 << 20) ? (1 << 20) : lim64));
+    float rr[NG][4][TN];
+    auto issue = [&](int gi) {
+        const int i = gi >> 2, g = gi & 3;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const char* rp = resb + uniform_i64(rbase + (int64_t)(i * 32 + 8 * g + e) * ldr * 4);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) rr[gi][e][j] = *reinterpret_cast<const float*>(rp + roff + j * 128);
+        }
+    };
+    if constexpr (HAS_RES) {
+#pragma unroll
+        for (int gi = 0; gi < DEPTH && gi < NG; ++gi) issue(gi);
+    }
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+        const int i = gi >> 2, g = gi & 3;
+        if constexpr (HAS_RES) {
+            if (gi + DEPTH < NG) issue(gi + DEPTH);
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int rl = i * 32 + 8 * g + e;
+            char* op = outb + uniform_i64(obase + (int64_t)rl * ldo * 4);
+            const bool late = fh4 >= lim - rl;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                auto a = acc[i][j][4 * g + e];
+                asm volatile("" : "+v"(a));                // read the accumulator here, not hoisted above the dispatch
+                float v = (float)a * er.s[j] + er.b[j];
+                if constexpr (HAS_RA) v += late ? er.ra1[j] : er.ra0[j];
+                if constexpr (HAS_RES) v += rr[gi][e][j];
+                *reinterpret_cast<float*>(op + ooff + j * 128) = v;
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+}
+
+template <int DT, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_direct(typename Acc<DT>::type (&acc)[TM][TN], const EpiRegs<TN>& er, int lane,
+                                                     int64_t row0, int64_t col0, bool has_rowadd,
+                                                     const float* __restrict__ residual, int64_t ldr,
+                                                     float* __restrict__ out, int64_t ldo) {
+    if (residual) {
+        if (has_rowadd) epilogue_direct_body<DT, TM, TN, true, true>(acc, er, lane, row0, col0, residual, ldr, out, ldo);
+        else epilogue_direct_body<DT, TM, TN, false, true>(acc, er, lane, row0, col0, residual, ldr, out, ldo);
+    } else {
+        if (has_rowadd) epilogue_direct_body<DT, TM, TN, true, false>(acc, er, lane, row0, col0, residual, ldr, out, ldo);
+        else epilogue_direct_body<DT, TM, TN, false, false>(acc, er, lane, row0, col0, residual, ldr, out, ldo);
+    }
+}
+
+// ---- register-direct epilogue for the quantised outputs (out_mode 1..3) of full tiles.  The main loop ran the
+// MFMA with its operands swapped, so the accumulator holds the TRANSPOSED block: a lane owns one output ROW
+// (lane%32) and four consecutive columns 8g + 4 (lane/32) + e per register group -- the four codes of an int8
+// dword, the two half2 of an f16 store or the two (value, gate) pairs of GEGLU are all in one lane; the column
+// constants come from LDS as float4 broadcasts.
+template <int DT, int TM, int TN, int BN, int RA>
+__device__ __forceinline__ void gemm_epilogue_qdirect(typename Acc<DT>::type (&acc)[TM][TN], const float* ec, int lane,
+                                                      int64_t row0, int64_t col0, int ecol0, void* __restrict__ outv,
+                                                      int64_t ldo, int out_mode) {
+    const int fr = lane & 31, fh4 = (lane >> 5) * 4;
+    const float od = ec[(2 + RA) * BN], oz = ec[(2 + RA) * BN + 1], oq = ec[(2 + RA) * BN + 2];
+    const float oi = 1.0f / od;
+    // element offset of (row0 + fr, col0 + fh4) in the output matrix (GEGLU halves the column index)
+    const int64_t rbase = (row0 + fr) * ldo;
+    auto body = [&](auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ecol = ecol0 + j * 32 + 8 * g + fh4;
+                const float4 s4 = *reinterpret_cast<const float4*>(ec + ecol);
+                const float4 b4 = *reinterpret_cast<const float4*>(ec + BN + ecol);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        auto a = acc[i][j][4 * g + e];
+                        asm volatile("" : "+v"(a));
+                        v[e] = (float)a;
+                    }
+                    v[0] = v[0] * s4.x + b4.x; v[1] = v[1] * s4.y + b4.y; v[2] = v[2] * s4.z + b4.z; v[3] = v[3] * s4.w + b4.w;
+                    const int64_t col = col0 + j * 32 + 8 * g + fh4;
+                    const int64_t ro = rbase + (int64_t)(i * 32) * ldo;
+                    if constexpr (MODE == 3) {             // GEGLU on interleaved (a, gate) columns -> int8 operand
+                        float y[2], r[2];
+                        y[0] = v[0] * (0.5f * v[1] * (1.0f + erf_fast(v[1] * 0.70710678118654752440f)));
+                        y[1] = v[2] * (0.5f * v[3] * (1.0f + erf_fast(v[3] * 0.70710678118654752440f)));
+                        rint_div_n<2>(y, od, oi, r);
+                        uint32_t w = 0;
+                        w = __builtin_amdgcn_cvt_pk_u8_f32(fminf(fmaxf(r[0] + oz, 0.f), oq), 0, w);
+                        w = __builtin_amdgcn_cvt_pk_u8_f32(fminf(fmaxf(r[1] + oz, 0.f), oq), 1, w);
+                        *reinterpret_cast<uint16_t*>(reinterpret_cast<int8_t*>(outv) + ro + (col >> 1)) = (uint16_t)(w ^ 0x8080u);
+                    } else {
+                        float q[4];
+                        rint_div_n<4>(v, od, oi, q);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) q[e] = fminf(fmaxf(q[e] + oz, 0.f), oq);
+                        if constexpr (MODE == 1) {         // f16 operand code - zp (attention products)
+                            __half2 h0 = __floats2half2_rn(q[0] - oz, q[1] - oz), h1 = __floats2half2_rn(q[2] - oz, q[3] - oz);
+                            uint2 pk;
+                            pk.x = *reinterpret_cast<uint32_t*>(&h0);
+                            pk.y = *reinterpret_cast<uint32_t*>(&h1);
+                            *reinterpret_cast<uint2*>(reinterpret_cast<__half*>(outv) + ro + col) = pk;
+                        } else {                           // int8 operand code - 128
+                            *reinterpret_cast<uint32_t*>(reinterpret_cast<int8_t*>(outv) + ro + col) = pack_codes_i8(q);
+                        }
+                    }
+                }
+            }
+        }
+    };
+    if (out_mode == 1) body(std::integral_constant<int, 1>{});
+    else if (out_mode == 2) body(std::integral_constant<int, 2>{});
+    else body(std::integral_constant<int, 3>{});
+}
+
 // Source rows for everything that is not real data (convolution padding, M/N/K tails): row v holds
 // 64 bytes of value v, so a direct-to-LDS load can fetch "padding" like any other address.
-__device__ uint8_t g_pad_rows[256 * 64];
-__global__ void k_init_pad_rows() {
+static __device__ uint8_t g_pad_rows[256 * 64];
+#ifdef EDADM_STAMPS
+// diagnostic build only (make stamps): per-wave cycle stamps summed over all waves of a launch
+static __device__ unsigned long long g_stamps[8];
+#define STAMP(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define STAMP_ADD(slot, d) do { if (lane == 0) atomicAdd(&g_stamps[slot], (unsigned long long)(d)); } while (0)
+#else
+#define STAMP(v)
+#define STAMP_ADD(slot, d)
+#endif
+static __global__ void k_init_pad_rows() {
     for (int i = threadIdx.x; i < 256 * 64; i += blockDim.x) g_pad_rows[i] = (uint8_t)(i >> 6);
 }
 
 template <int DT, int TM, int TN>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)      // two workgroups per CU: at most 256 registers (VGPR + AGPR) per lane
 k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const uint8_t* __restrict__ Bm,
           int64_t ldb_b, int64_t strideB_b, int64_t M, int64_t N, int64_t Kb, ConvGeom g,
           const float* __restrict__ scale, const float* __restrict__ bias, const float* __restrict__ rowadd,
@@ -350,8 +569,10 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
         }
     };
 
-    stage_epilogue_consts<BN, RA>(ec, tid, (int)blockDim.x, m0, n0, M, N, scale, bias, rowadd, rows_per_batch, alpha, oqp);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // keep the pipeline's vmcnt bookkeeping to LDS-DMA only
+    // full fp32 tiles take the register-direct epilogue (workgroup-uniform choice)
+    const bool full = m0 + BM <= M && n0 + BN <= N;
+    const bool direct = out_mode == 0 && full && (!rowadd || rows_per_batch >= TM * 32);
+    const bool qdirect = out_mode != 0 && full && !rowadd && !residual;    // transposed accumulators, see the epilogue
 
     typename Acc<DT>::type acc[TM][TN];
 #pragma unroll
@@ -366,6 +587,10 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
 #pragma unroll
     for (int p = 0; p < STAGES - 1; ++p)
         if (p < nk) issue_tile(p, (int64_t)p * 64);
+    // epilogue constants go to LDS behind the first tiles' DMA, so their load latency hides under it
+    stage_epilogue_consts<BN, RA>(ec, tid, (int)blockDim.x, m0, n0, M, N, scale, bias, rowadd, rows_per_batch, alpha, oqp);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // keep the pipeline's vmcnt bookkeeping to LDS-DMA only
+    auto main_loop = [&](auto swp) {
     for (int64_t kt = 0; kt < nk; ++kt) {
         // tile kt has landed once at most the newer tile's LPT loads are still in flight
         // tiles kt+1 .. kt+STAGES-2 may still be in flight
@@ -397,11 +622,27 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    mma_step<DT>(fa[i], fb[j], acc[i][j]);
+                    if constexpr (decltype(swp)::value) mma_step<DT>(fb[j], fa[i], acc[i][j]);
+                    else mma_step<DT>(fa[i], fb[j], acc[i][j]);
                 }
         }
     }
+    };
+    if (qdirect) main_loop(std::true_type{});
+    else main_loop(std::false_type{});
 
+    if (qdirect) {
+        gemm_epilogue_qdirect<DT, TM, TN, BN, RA>(acc, ec, lane, m0 + wm * (TM * 32), n0 + wn * (TN * 32), wn * (TN * 32), out, ldo,
+                                                  out_mode);
+        return;
+    }
+    if (direct) {
+        EpiRegs<TN> er;
+        load_epi_regs<TN, BN>(er, ec, lane, m0, m0 + wm * (TM * 32), wn * (TN * 32), rows_per_batch);
+        gemm_epilogue_direct<DT, TM, TN>(acc, er, lane, m0 + wm * (TM * 32), n0 + wn * (TN * 32), rowadd != nullptr, residual,
+                                         ldr, out, ldo);
+        return;
+    }
     gemm_epilogue<DT, TM, TN, BN, RA, (TN % 2 == 0 || TN == 3) ? 4 : 2>(acc, smem, ec, wave, lane, m0, m0 + wm * (TM * 32), n0 + wn * (TN * 32),
                                       wn * (TN * 32), M, N, rows_per_batch, rowadd != nullptr, residual, ldr, out, ldo, out_mode);
 }
@@ -432,6 +673,7 @@ k_gemm_nt8(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, cons
     float* ec = reinterpret_cast<float*>(smem + MAIN_BYTES);
 
     const int tid = threadIdx.x, lane = tid & 63;
+    STAMP(t_entry);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
     const int wm = wave >> 1, wn = wave & 1;
@@ -530,8 +772,11 @@ k_gemm_nt8(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, cons
         }
     };
 
-    stage_epilogue_consts<BN, RA>(ec, tid, (int)blockDim.x, m0, n0, M, N, scale, bias, rowadd, rows_per_batch, alpha, oqp);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // keep the pipeline's vmcnt bookkeeping to LDS-DMA only
+    // full fp32 tiles take the register-direct epilogue (workgroup-uniform choice)
+    const bool full = m0 + BM <= M && n0 + BN <= N;
+    const bool direct = out_mode == 0 && full && (!rowadd || rows_per_batch >= TM * 32);
+    const bool qdirect = out_mode != 0 && full && !rowadd && !residual;    // transposed accumulators, see the epilogue
+    STAMP(t_consts);
 
     typename Acc<DT>::type acc[TM][TN];
 #pragma unroll
@@ -544,10 +789,16 @@ k_gemm_nt8(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, cons
     const int64_t nk = (Kb + 127) / 128;
     const int fr = lane & 31, fh = lane >> 5;
     issue_tile(0, 0);
+    // epilogue constants go to LDS behind the first tile's DMA, so their load latency hides under it
+    stage_epilogue_consts<BN, RA>(ec, tid, (int)blockDim.x, m0, n0, M, N, scale, bias, rowadd, rows_per_batch, alpha, oqp);
+    auto main_loop = [&](auto swp) {
     for (int64_t kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+#ifdef EDADM_STAMPS
+        if (kt == 0) { STAMP(t_first); STAMP_ADD(1, t_first - t_consts); }
+#endif
         if (kt + 1 < nk) issue_tile((int)((kt + 1) & 1), (kt + 1) * 128);
         const uint8_t* As = smem + (int)(kt & 1) * TILE;
         const uint8_t* Bs = As + BM * 128;
@@ -569,13 +820,295 @@ k_gemm_nt8(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, cons
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    mma_step<DT>(fa[i], fb[j], acc[i][j]);
+                    if constexpr (decltype(swp)::value) mma_step<DT>(fb[j], fa[i], acc[i][j]);
+                    else mma_step<DT>(fa[i], fb[j], acc[i][j]);
                 }
         }
     }
-    gemm_epilogue<DT, TM, TN, BN, RA, 1>(acc, smem, ec, wave, lane, m0, m0 + wm * 64, n0 + wn * (TN * 32), wn * (TN * 32),
-                                      M, N, rows_per_batch, rowadd != nullptr, residual, ldr, out, ldo, out_mode);
+    };
+    if (qdirect) main_loop(std::true_type{});
+    else main_loop(std::false_type{});
+    STAMP(t_main);
+    if (qdirect) {
+        gemm_epilogue_qdirect<DT, TM, TN, BN, RA>(acc, ec, lane, m0 + wm * 64, n0 + wn * (TN * 32), wn * (TN * 32), out, ldo, out_mode);
+    } else if (direct) {
+        EpiRegs<TN> er;
+        load_epi_regs<TN, BN>(er, ec, lane, m0, m0 + wm * 64, wn * (TN * 32), rows_per_batch);
+        gemm_epilogue_direct<DT, TM, TN>(acc, er, lane, m0 + wm * 64, n0 + wn * (TN * 32), rowadd != nullptr, residual, ldr,
+                                         out, ldo);
+    } else
+        gemm_epilogue<DT, TM, TN, BN, RA, 1>(acc, smem, ec, wave, lane, m0, m0 + wm * 64, n0 + wn * (TN * 32), wn * (TN * 32),
+                                             M, N, rows_per_batch, rowadd != nullptr, residual, ldr, out, ldo, out_mode);
+#ifdef EDADM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(t_end);
+    STAMP_ADD(0, t_consts - t_entry); STAMP_ADD(2, t_main - t_consts); STAMP_ADD(3, t_end - t_main); STAMP_ADD(4, 1);
+    STAMP_ADD(5, t_end - t_entry);
+#endif
 }
+
+
+// ---- persistent, wave-specialised variant for the large quantised layers (full 256 x (64 TN) tiles, int8).
+// One workgroup per CU stays resident and walks its tiles; 8 MFMA waves (4 x 2, 64 x 32TN each) only read LDS,
+// run the MFMAs and the register-direct epilogues, 4 loader waves only issue the direct-to-LDS gathers of the
+// K-step ring.  A wave's vmcnt retires in order and counts stores, so a wave that both stores an output tile
+// and loads the next operands waits for its own store stream; with the roles split the loader's counted waits
+// see loads only, it runs S-1 K-steps ahead ACROSS tile boundaries (the next tile's first operands land while
+// the MFMA waves drain their epilogue), and the MFMA waves never wait on memory in the main loop -- only on the
+// one barrier per K-step.  Tiles are walked in an XCD-aware order: the workgroups of one XCD take neighbouring
+// tiles (same A rows, consecutive N blocks), so an activation block is fetched into one L2 instead of eight.
+template <int DT, int TN, int KSTEP>
+__global__ void __launch_bounds__(768)
+k_gemm_p(const uint8_t* __restrict__ A, int64_t lda_b, const uint8_t* __restrict__ Bm, int64_t ldb_b, int64_t M,
+         int64_t N, int64_t Kb, ConvGeom g, const float* __restrict__ scale, const float* __restrict__ bias,
+         const float* __restrict__ rowadd, int64_t rows_per_batch, const float* __restrict__ residual, int64_t ldr,
+         float* __restrict__ out, int64_t ldo, float alpha, int out_mode, const float* __restrict__ oqp) {
+    constexpr int TM = 2, BM = 256, BN = 64 * TN;
+    constexpr int S = 256 / KSTEP;               // ring depth: 4 x 64-byte or 2 x 128-byte K-steps
+    constexpr int CPR = KSTEP / 16;              // 16-byte chunks per operand row
+    constexpr int RPP = 64 / CPR;                // rows per 1-KiB direct-to-LDS piece
+    constexpr int NA = BM / RPP / 4, NB = BN / RPP / 4;      // pieces per loader wave per K-step
+    constexpr int PPW = NA + NB;
+    constexpr int TILE = (BM + BN) * KSTEP;
+    constexpr int RA = 5;                        // row-add entries a tile can span (rows_per_batch >= 64)
+    constexpr int ECN = (2 + RA) * BN + 4;       // floats per epilogue-constant buffer (+ output quantiser)
+    constexpr int SMEM_BYTES = S * TILE + 2 * ECN * 4;
+    __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM_BYTES];
+    float* ec_all = reinterpret_cast<float*>(smem + S * TILE);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
+    const int tiles_n = (int)(N / BN);
+    const int tiles_total = (int)(M / BM) * tiles_n;
+    const int nwg = gridDim.x, wg = blockIdx.x;
+    const int logical = (wg & 7) * (nwg >> 3) + (wg >> 3);           // workgroups of one XCD are neighbours
+    const int ntl = logical < tiles_total ? (tiles_total - 1 - logical) / nwg + 1 : 0;
+    const int nk = (int)((Kb + KSTEP - 1) / KSTEP);
+    const int G = ntl * nk;                                          // K-steps this workgroup runs in total
+
+    if (wave >= 8) {
+        // ------------------------------------------------------------------ loader waves
+        const int lw = wave - 8;
+        const int prow = lane / CPR, pch = lane % CPR;
+        const int sc = KSTEP == 64 ? (pch ^ ((lane >> 4) & 3)) : (pch ^ ((4 * (lw & 1) + (lane >> 4)) & 7));
+        const uint8_t* zero_row = g_pad_rows;
+        const uint8_t* pad_row = g_pad_rows + (int)(uint8_t)g.padval * 64;
+        const bool uniform_tap = g.mode != 0 && !g.ups && (g.Cin % KSTEP) == 0;
+        int64_t a_base[NA];
+        int a_y[NA], a_x[NA], a_y0[NA], a_x0[NA], a_off[NA];
+        const uint8_t* b_row[NB];
+        int tap_c = 0, ci_c = 0, tap_s = 0, ci_s = 0;
+        const int ltid = tid - 512;                                  // 0..255 over the loader waves
+
+        auto setup_tile = [&](int T) {
+            const int t = logical + T * nwg;
+            const int mt = t / tiles_n, nt = t - mt * tiles_n;
+            const int64_t m0 = (int64_t)mt * BM, n0 = (int64_t)nt * BN;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const unsigned m = (unsigned)(m0 + (lw + 4 * i) * RPP + prow);
+                if (g.mode == 0) {
+                    a_base[i] = (int64_t)m * lda_b;
+                    a_y[i] = a_x[i] = a_y0[i] = a_x0[i] = a_off[i] = 0;
+                } else {
+                    const unsigned hw = (unsigned)(g.Ho * g.Wo);
+                    const unsigned b = m / hw, r = m - b * hw;
+                    a_y[i] = (int)(r / (unsigned)g.Wo);
+                    a_x[i] = (int)(r - (unsigned)a_y[i] * (unsigned)g.Wo);
+                    a_base[i] = (int64_t)b * g.H * g.W;
+                    a_y0[i] = a_y[i] * g.stride - g.pad0;
+                    a_x0[i] = a_x[i] * g.stride - g.pad0;
+                    a_off[i] = (int)((a_base[i] + (int64_t)a_y0[i] * g.W + a_x0[i]) * g.Cin) + sc * 16;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) b_row[i] = Bm + (n0 + (lw + 4 * i) * RPP + prow) * ldb_b;
+            tap_s = 0; ci_s = 0;
+            if (g.mode != 0) { tap_c = (sc * 16) / g.Cin; ci_c = (sc * 16) % g.Cin; }
+            // epilogue constants of this tile (consumed >= S-1 barriers later)
+            float* ec = ec_all + (T & 1) * ECN;
+            if (ltid < 3) ec[(2 + RA) * BN + ltid] = oqp ? oqp[ltid] : 0.f;
+            const int64_t b0 = m0 / rows_per_batch;
+            for (int c = ltid; c < BN; c += 256) {
+                const int64_t col = n0 + c;
+                ec[c] = scale ? scale[col] : alpha;
+                ec[BN + c] = bias ? bias[col] : 0.f;
+#pragma unroll
+                for (int j = 0; j < RA; ++j) {
+                    const int64_t b = b0 + j;
+                    ec[(2 + j) * BN + c] = (rowadd && b * rows_per_batch < M) ? rowadd[b * N + col] : 0.f;
+                }
+            }
+        };
+
+        auto issue = [&](int stage, int kk) {
+            const int64_t off = (int64_t)kk * KSTEP + sc * 16;
+            const bool kin = off < Kb;
+            const uint8_t* src[NA];
+            if (g.mode == 0) {
+#pragma unroll
+                for (int i = 0; i < NA; ++i) src[i] = kin ? A + a_base[i] + off : zero_row;
+            } else if (uniform_tap) {
+                const int ky = tap_s / g.KW, kx = tap_s - ky * g.KW;
+                const int dlt = (ky * g.W + kx) * g.Cin + ci_s;
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    const bool in = (unsigned)(a_y0[i] + ky) < (unsigned)g.H && (unsigned)(a_x0[i] + kx) < (unsigned)g.W;
+                    src[i] = !kin ? zero_row : in ? A + (int64_t)(a_off[i] + dlt) : pad_row;
+                }
+                ci_s += KSTEP;
+                if (ci_s >= g.Cin) { ci_s = 0; ++tap_s; }
+            } else {
+                const int ky = tap_c / g.KW, kx = tap_c - ky * g.KW;
+                const int Hl = g.ups ? 2 * g.H : g.H, Wl = g.ups ? 2 * g.W : g.W;
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    int iy = a_y[i] * g.stride + ky - g.pad0, ix = a_x[i] * g.stride + kx - g.pad0;
+                    const bool in = iy >= 0 && iy < Hl && ix >= 0 && ix < Wl;
+                    if (g.ups) { iy >>= 1; ix >>= 1; }
+                    src[i] = !kin ? zero_row
+                             : in ? A + ((a_base[i] + (int64_t)iy * g.W + ix) * g.Cin + ci_c)
+                                  : pad_row;
+                }
+                ci_c += KSTEP;
+                while (ci_c >= g.Cin) { ci_c -= g.Cin; ++tap_c; }
+            }
+#pragma unroll
+            for (int i = 0; i < NA; ++i) glds16(src[i], lds0 + (uint32_t)(stage * TILE + (lw + 4 * i) * 1024));
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+                glds16(kin ? b_row[i] + off : zero_row, lds0 + (uint32_t)(stage * TILE + BM * KSTEP + (lw + 4 * i) * 1024));
+        };
+
+        int gi = 0, kk_i = 0, T_i = 0;
+        auto advance = [&]() {
+            if (kk_i == 0) setup_tile(T_i);
+            issue(gi % S, kk_i);
+            ++gi;
+            if (++kk_i == nk) { kk_i = 0; ++T_i; }
+        };
+#ifdef EDADM_STAMPS
+        unsigned long long l_wait = 0, l_bar = 0, l_issue = 0;
+        const unsigned long long l_t0 = __builtin_amdgcn_s_memtime();
+#endif
+        for (int p = 0; p < S - 1; ++p)
+            if (gi < G) advance();
+        for (int gs = 0; gs < G; ++gs) {
+            STAMP(ls0);
+            // step gs has landed once only the steps issued after it are still in flight
+            const int ahead = G - 1 - gs < S - 2 ? G - 1 - gs : S - 2;
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            STAMP(ls1);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            STAMP(ls2);
+            if (gi < G) advance();
+#ifdef EDADM_STAMPS
+            { STAMP(ls3); l_wait += ls1 - ls0; l_bar += ls2 - ls1; l_issue += ls3 - ls2; }
+#endif
+        }
+#ifdef EDADM_STAMPS
+        if (lw == 0) { STAMP_ADD(4, l_wait); STAMP_ADD(5, l_bar); STAMP_ADD(6, l_issue); STAMP_ADD(7, __builtin_amdgcn_s_memtime() - l_t0); }
+#endif
+        return;
+    }
+
+    // ---------------------------------------------------------------------- MFMA waves
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 31, fh = lane >> 5;
+    typename Acc<DT>::type acc[TM][TN];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+    };
+    zero_acc();
+    auto run = [&](auto swp) {
+        int kk = 0, T = 0;
+#ifdef EDADM_STAMPS
+        unsigned long long m_bar = 0, m_comp = 0, m_epi = 0;
+#endif
+        for (int gs = 0; gs < G; ++gs) {
+            STAMP(ms0);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            STAMP(ms1);
+            const uint8_t* As = smem + (gs % S) * TILE;
+            const uint8_t* Bs = As + BM * KSTEP;
+#pragma unroll
+            for (int ks = 0; ks < KSTEP / 32; ++ks) {
+                const int c = 2 * ks + fh;
+                uint4 fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int r = wm * 64 + i * 32 + fr;
+                    if constexpr (KSTEP == 64) fa[i] = *reinterpret_cast<const uint4*>(As + (r * 4 + (c ^ ((r >> 2) & 3))) * 16);
+                    else fa[i] = *reinterpret_cast<const uint4*>(As + r * 128 + ((c ^ ((r >> 1) & 7)) * 16));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int r = wn * (TN * 32) + j * 32 + fr;
+                    if constexpr (KSTEP == 64) fb[j] = *reinterpret_cast<const uint4*>(Bs + (r * 4 + (c ^ ((r >> 2) & 3))) * 16);
+                    else fb[j] = *reinterpret_cast<const uint4*>(Bs + r * 128 + ((c ^ ((r >> 1) & 7)) * 16));
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if constexpr (decltype(swp)::value) mma_step<DT>(fb[j], fa[i], acc[i][j]);
+                        else mma_step<DT>(fa[i], fb[j], acc[i][j]);
+                    }
+            }
+#ifdef EDADM_STAMPS
+            asm volatile("s_nop 0" ::: "memory");
+            STAMP(ms2);
+            m_bar += ms1 - ms0; m_comp += ms2 - ms1;
+#endif
+            if (++kk == nk) {
+                const int t = logical + T * nwg;
+                const int mt = t / tiles_n, nt = t - mt * tiles_n;
+                const int64_t m0 = (int64_t)mt * BM, n0 = (int64_t)nt * BN;
+                const float* ec = ec_all + (T & 1) * ECN;
+                if constexpr (decltype(swp)::value) {
+                    gemm_epilogue_qdirect<DT, TM, TN, BN, RA>(acc, ec, lane, m0 + wm * 64, n0 + wn * (TN * 32), wn * (TN * 32), out,
+                                                              ldo, out_mode);
+                } else {
+                    EpiRegs<TN> er;
+                    load_epi_regs<TN, BN>(er, ec, lane, m0, m0 + wm * 64, wn * (TN * 32), rows_per_batch);
+                    gemm_epilogue_direct<DT, TM, TN>(acc, er, lane, m0 + wm * 64, n0 + wn * (TN * 32), rowadd != nullptr, residual,
+                                                     ldr, out, ldo);
+                }
+                zero_acc();
+                kk = 0;
+                ++T;
+#ifdef EDADM_STAMPS
+                { STAMP(ms3); m_epi += ms3 - ms2; }
+#endif
+            }
+        }
+#ifdef EDADM_STAMPS
+        if (wave == 0) { STAMP_ADD(0, m_bar); STAMP_ADD(1, m_comp); STAMP_ADD(2, m_epi); STAMP_ADD(3, 1); }
+#endif
+    };
+    if (out_mode != 0) run(std::true_type{});
+    else run(std::false_type{});
+}
+
+#if defined(EDADM_STAMPS) && EDADM_GEMM_DT == 0
+extern "C" void edadm_dbg_read(unsigned long long* dst) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 8);
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z));
+}
+#endif
 
 template <int DT>
 static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm, int64_t ldb_b, int64_t sB,
@@ -601,6 +1134,34 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
     // convolutions whose Cin is a multiple of 64 but not of 128 keep scalar tap arithmetic only with 64-byte K-steps
     const bool nt8_gather_ok = true;
     static const int force = getenv("EDADM_GEMM_FORCE") ? atoi(getenv("EDADM_GEMM_FORCE")) : 0;   // diagnostics only
+    if constexpr (DT == 0) {
+        // persistent wave-specialised kernel: full 256-row tiles of the big quantised layers
+        const int kstep = force == 6 ? 128 : 64;
+        const int64_t ptiles = (M / 256) * (N / (64 * tn));
+        if (force != 2 && force != 3 && batch == 1 && inner == 1 && tn >= 2 && M % 256 == 0 && N % (64 * tn) == 0 &&
+            (Kb + kstep - 1) / kstep >= 256 / kstep && (!rowadd || rpb >= 64) && (out_mode == 0 || (!rowadd && !residual)) &&
+            (force >= 5 || ptiles >= 224) && (g.mode == 0 || (int64_t)g.B * g.H * g.W * g.Cin < (1ll << 31))) {
+            static int ncu = 0;
+            if (!ncu) {
+                int dev = 0;
+                hipGetDevice(&dev);
+                hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+                ncu = ncu >= 8 ? ncu & ~7 : 8;
+            }
+#define EDADM_GEMMP_CASE(TN_, KS_)                                                                              \
+            if (tn == TN_ && kstep == KS_) {                                                                    \
+                hipLaunchKernelGGL((k_gemm_p<DT, TN_, KS_>), dim3(ncu), dim3(768), 0, st, (const uint8_t*)A, lda_b, \
+                                   (const uint8_t*)Bm, ldb_b, M, N, Kb, g, scale, bias, rowadd, rpb, residual, ldr, out, \
+                                   ldo, alpha, out_mode, oqp);                                                  \
+                return edadm_launch_status();                                                                   \
+            }
+            EDADM_GEMMP_CASE(3, 64)
+            EDADM_GEMMP_CASE(2, 64)
+            EDADM_GEMMP_CASE(3, 128)
+            EDADM_GEMMP_CASE(2, 128)
+#undef EDADM_GEMMP_CASE
+        }
+    }
     if (force != 2 && EDADM_USE_NT8 && (force == 3 || (tiles8 >= 224 && Kb >= 256)) && nt8_gather_ok) {
         const dim3 grid8((unsigned)((N + 64 * tn - 1) / (64 * tn)), (unsigned)((M + 255) / 256), (unsigned)batch);
 #define EDADM_GEMM8_CASE(TN_)                                                                                  \
@@ -635,6 +1196,7 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
     return EDADM_EINVAL;
 }
 
+#if EDADM_GEMM_DT == 0
 extern "C" int edadm_qgemm_i8(const int8_t* A, int64_t lda, const int8_t* Wt, int64_t ldw, int64_t M, int64_t N,
                               int64_t K, const int32_t* geom, const float* scale, const float* bias,
                               const float* rowadd, int64_t rows_per_batch, const float* residual, int64_t ldr,
@@ -659,7 +1221,9 @@ extern "C" int edadm_qgemm_i8(const int8_t* A, int64_t lda, const int8_t* Wt, in
     return launch_gemm<0>(A, lda, 0, Wt, ldw, 0, M, N, K, g, scale, bias, rowadd, rows_per_batch, residual, ldr,
                              out, ldo, 0, 1, 1.0f, (hipStream_t)stream);
 }
+#endif
 
+#if EDADM_GEMM_DT == 1
 extern "C" int edadm_gemm_f16_nt(const void* A, int64_t lda, int64_t strideA, int64_t strideA_i, const void* Bm,
                                  int64_t ldb, int64_t strideB, int64_t strideB_i, float* C, int64_t ldc,
                                  int64_t strideC, int64_t strideC_i, int64_t batch, int64_t inner, int64_t M,
@@ -673,7 +1237,9 @@ extern "C" int edadm_gemm_f16_nt(const void* A, int64_t lda, int64_t strideA, in
                               nullptr, 1, nullptr, 0, C, ldc, strideC, batch * inner, alpha, (hipStream_t)stream,
                               (int)inner, strideA_i * 2, strideB_i * 2, strideC_i);
 }
+#endif
 
+#if EDADM_GEMM_DT == 1
 // same contract as edadm_qgemm_i8 with f16 operands (a = code - zp_x, w = wcode - zp_w as exact f16 integers):
 // used for layers whose integer weight range does not fit int8 (8-bit weights with zp 127).
 extern "C" int edadm_qgemm_f16(const void* A, int64_t lda, const void* Wt, int64_t ldw, int64_t M, int64_t N,
@@ -696,7 +1262,9 @@ extern "C" int edadm_qgemm_f16(const void* A, int64_t lda, const void* Wt, int64
     return launch_gemm<1>(A, lda * 2, 0, Wt, ldw * 2, 0, M, N, K * 2, g, scale, bias, rowadd, rows_per_batch,
                               residual, ldr, out, ldo, 0, 1, 1.0f, (hipStream_t)stream);
 }
+#endif
 
+#if EDADM_GEMM_DT == 0
 // ---- variants whose epilogue feeds an activation quantizer directly (no fp32 round trip through HBM):
 // out_mode 1: f16 operand (code - zp), 2: int8 operand (code - 128), 3: GEGLU over interleaved (a, gate)
 // output columns then int8 operand [M][N/2] (attention.py:37-45 + the consumer's quantizer,
@@ -722,7 +1290,9 @@ extern "C" int edadm_qgemm_i8_q(const int8_t* A, int64_t lda, const int8_t* Wt, 
     return launch_gemm<0>(A, lda, 0, Wt, ldw, 0, M, N, K, g, scale, bias, rowadd, rows_per_batch, residual, ldr,
                              (float*)out, ldo, 0, 1, 1.0f, (hipStream_t)stream, 1, 0, 0, 0, out_mode, oqp);
 }
+#endif
 
+#if EDADM_GEMM_DT == 1
 extern "C" int edadm_gemm_f16_nt_q(const void* A, int64_t lda, int64_t strideA, int64_t strideA_i, const void* Bm,
                                    int64_t ldb, int64_t strideB, int64_t strideB_i, void* C, int64_t ldc,
                                    int64_t strideC, int64_t strideC_i, int64_t batch, int64_t inner, int64_t M,
@@ -737,7 +1307,9 @@ extern "C" int edadm_gemm_f16_nt_q(const void* A, int64_t lda, int64_t strideA, 
                               nullptr, 1, nullptr, 0, (float*)C, ldc, strideC, batch * inner, alpha, (hipStream_t)stream,
                               (int)inner, strideA_i * 2, strideB_i * 2, strideC_i, out_mode, oqp);
 }
+#endif
 
+#if EDADM_GEMM_DT == 2
 // ---- fp32 NT GEMM on v_mfma_f32_32x32x2_f32 for the calibration graph (H1): C[z] = alpha * A[z] . B[z]^T
 // (+ bias[n]) (+ residual[m][n]).  Exact fp32 FMA chains (no reduced-precision path exists on gfx950).
 // quant_layer.py:434 (F.conv2d / F.linear on fake-quantised operands) and its autograd backward are built
@@ -755,3 +1327,4 @@ extern "C" int edadm_gemm_f32_nt(const float* A, int64_t lda, int64_t strideA, c
     return launch_gemm<2>(A, lda * 4, strideA * 4, Bm, ldb * 4, strideB * 4, M, N, K * 4, g, nullptr, bias, nullptr, 1,
                           residual, ldr, C, ldc, strideC, batch, alpha, (hipStream_t)stream);
 }
+#endif

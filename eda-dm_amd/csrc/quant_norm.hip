@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(256) k_geglu_q(const float* __restrict__ x, in
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const int64_t r = i / inner, c = i - r * inner;
         const float a = x[r * 2 * inner + c], g = x[r * 2 * inner + inner + c];
-        const float gl = 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f));
+        const float gl = 0.5f * g * (1.0f + erf_fast(g * 0.70710678118654752440f));
         out[i] = (int8_t)q_code_i8(a * gl, q);
     }
 }

@@ -7,7 +7,7 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
 HEADER = os.path.join(_ROOT, "include", "edadm.h")
-SO_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libedadm.so")
+SO_PATH = os.environ.get("EDADM_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "csrc", "libedadm.so")   # override: instrumented diagnostic builds
 
 _CT = {
     "int": ctypes.c_int, "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64, "float": ctypes.c_float,

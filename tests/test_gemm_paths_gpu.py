@@ -1,0 +1,91 @@
+"""-m gpu: the three K4 kernel structures of edadm_qgemm_i8 / _q (4-wave tile, 8-wave tile, persistent
+wave-specialised kernel) and their epilogues (LDS-staged, register-direct fp32, transposed-accumulator quantised)
+on shapes big enough to reach each of them.  Integer accumulation bit-exact (scale 1, bias 0); the scaled
+epilogue against fp64 at 1e-5; quantised outputs against the stand-alone quantiser kernels on the fp32 output
+of the same GEMM (codes may differ by one where the fp32 value sits within rounding of a code boundary:
+<= 1e-4 of the elements, never by more than one code)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    from edadm import ops as _ops
+    return _ops
+
+
+def _mk(M, N, K, seed):
+    g = torch.Generator().manual_seed(seed)
+    A = torch.randint(-128, 128, (M, K), generator=g, dtype=torch.int8)
+    W = torch.randint(-8, 9, (N, K), generator=g, dtype=torch.int8)
+    scale = torch.rand(N, generator=g) * 1e-3 + 1e-4
+    bias = torch.randn(N, generator=g)
+    return A, W, scale, bias, g
+
+
+# M multiple of 256 with >= 224 tiles -> persistent kernel; 57344 + 100 -> 8-wave kernel with an edge tile;
+# 3000 -> 4-wave kernel
+@pytest.mark.parametrize("M,N,K,rpb", [(57344, 192, 256, 64), (57344, 384, 448, 1024), (57444, 192, 320, 100),
+                                         (3000, 192, 192, 48), (65536, 128, 256, 4096)])
+def test_qgemm_paths_fp32(ops, M, N, K, rpb):
+    A, W, scale, bias, g = _mk(M, N, K, M + N + K)
+    nb = (M + rpb - 1) // rpb
+    rowadd = torch.randn(nb, N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    Ad, Wd = A.cuda(), W.cuda()
+    out = torch.empty(M, N, device="cuda")
+    ops.qgemm_i8(Ad, Wd, M, N, K, torch.ones(N).cuda(), torch.zeros(N).cuda(), out)
+    acc = (Ad.float() @ Wd.float().t())                    # |acc| < 2^24: exact in fp32
+    assert torch.equal(out, acc)
+    ops.qgemm_i8(Ad, Wd, M, N, K, scale.cuda(), bias.cuda(), out, rowadd=rowadd.cuda(), rows_per_batch=rpb, residual=res.cuda())
+    ref = acc.double() * scale.double().cuda() + bias.double().cuda() + rowadd.double().cuda()[torch.arange(M, device="cuda") // rpb] \
+        + res.double().cuda()
+    assert (out.double() - ref).abs().max() <= 1e-5 * max(1.0, float(ref.abs().max()))
+    ops.qgemm_i8(Ad, Wd, M, N, K, scale.cuda(), bias.cuda(), out, residual=res.cuda())
+    ref = acc.double() * scale.double().cuda() + bias.double().cuda() + res.double().cuda()
+    assert (out.double() - ref).abs().max() <= 1e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,stride", [(56, 32, 192, 192, 1), (64, 32, 64, 384, 1), (224, 32, 128, 192, 2)])
+def test_qgemm_conv_persistent(ops, B, H, Cin, Cout, stride):
+    g = torch.Generator().manual_seed(B + H + Cin)
+    x = torch.randint(-128, 128, (B, H, H, Cin), generator=g, dtype=torch.int8)
+    w = torch.randint(-8, 9, (Cout, 3, 3, Cin), generator=g, dtype=torch.int8)
+    padval = 5
+    Ho = H // stride
+    M, K = B * Ho * Ho, 9 * Cin
+    geom = ops.make_geom(B, H, H, Cin, Ho, Ho, 3, 3, stride, 1, False, padval)
+    out = torch.empty(M, Cout, device="cuda")
+    ops.qgemm_i8(x.cuda(), w.reshape(Cout, K).cuda(), M, Cout, K, torch.ones(Cout).cuda(), torch.zeros(Cout).cuda(), out, geom=geom)
+    xp = F.pad(x.cuda().permute(0, 3, 1, 2).float(), (1, 1, 1, 1), value=padval)
+    ref = torch.zeros(B, Cout, Ho, Ho, device="cuda")
+    for c0 in range(0, Cin, 64):                            # fp32 conv in channel slices keeps every partial sum exact
+        ref += F.conv2d(xp[:, c0:c0 + 64].double(), w.cuda().permute(0, 3, 1, 2)[:, c0:c0 + 64].double(), stride=stride).float()
+    assert torch.equal(out, ref.permute(0, 2, 3, 1).reshape(M, Cout))
+
+
+@pytest.mark.parametrize("M,N,K", [(57344, 384, 256), (57444, 192, 192), (3000, 384, 128)])
+def test_qgemm_quantised_outputs(ops, M, N, K):
+    A, W, scale, bias, g = _mk(M, N, K, 3 * M + N + K)
+    scale = scale * 4
+    Ad, Wd, sd, bd = A.cuda(), W.cuda(), scale.cuda(), bias.cuda()
+    f32 = torch.empty(M, N, device="cuda")
+    ops.qgemm_i8(Ad, Wd, M, N, K, sd, bd, f32)
+    qp = ops.qp_tensor([(0.037, 119.0, 255.0)], "cuda")
+
+    def codes_close(got, want, name):
+        d = (got.int() - want.int()).abs()
+        assert int(d.max()) <= 1, name
+        assert float((d > 0).float().mean()) <= 1e-4, (name, float((d > 0).float().mean()))
+
+    codes_close(ops.qgemm_i8_q(Ad, Wd, M, N, K, sd, bd, 2, qp), ops.quant_i8(f32, qp), "int8")
+    h = ops.qgemm_i8_q(Ad, Wd, M, N, K, sd, bd, 1, qp)
+    codes_close(h.float(), ops.quant_f16(f32, qp).float(), "f16")
+    # the fused GEGLU reads interleaved (value, gate) columns; the stand-alone kernel takes [values | gates]
+    split = torch.cat([f32[:, 0::2], f32[:, 1::2]], 1).contiguous()
+    codes_close(ops.qgemm_i8_q(Ad, Wd, M, N, K, sd, bd, 3, qp), ops.geglu_quant_i8(split, qp), "geglu")
