@@ -864,7 +864,8 @@ k_gemm_p(const uint8_t* __restrict__ A, int64_t lda_b, const uint8_t* __restrict
          const float* __restrict__ rowadd, int64_t rows_per_batch, const float* __restrict__ residual, int64_t ldr,
          float* __restrict__ out, int64_t ldo, float alpha, int out_mode, const float* __restrict__ oqp) {
     constexpr int TM = 2, BM = 256, BN = 64 * TN;
-    constexpr int S = 256 / KSTEP;               // ring depth: 4 x 64-byte or 2 x 128-byte K-steps
+    constexpr int S = KSTEP == 64 ? 5 : 2;       // LDS ring slots (64-byte steps: 5 x 28 KiB = the whole K of a 384-wide layer)
+    constexpr int D = 128 / KSTEP;               // K-steps a loader wave keeps in flight in registers
     constexpr int CPR = KSTEP / 16;              // 16-byte chunks per operand row
     constexpr int RPP = 64 / CPR;                // rows per 1-KiB direct-to-LDS piece
     constexpr int NA = BM / RPP / 4, NB = BN / RPP / 4;      // pieces per loader wave per K-step
@@ -872,13 +873,12 @@ k_gemm_p(const uint8_t* __restrict__ A, int64_t lda_b, const uint8_t* __restrict
     constexpr int TILE = (BM + BN) * KSTEP;
     constexpr int RA = 5;                        // row-add entries a tile can span (rows_per_batch >= 64)
     constexpr int ECN = (2 + RA) * BN + 4;       // floats per epilogue-constant buffer (+ output quantiser)
-    constexpr int SMEM_BYTES = S * TILE + 2 * ECN * 4;
+    constexpr int SMEM_BYTES = S * TILE + 3 * ECN * 4;
     __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM_BYTES];
     float* ec_all = reinterpret_cast<float*>(smem + S * TILE);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
     const int tiles_n = (int)(N / BN);
     const int tiles_total = (int)(M / BM) * tiles_n;
     const int nwg = gridDim.x, wg = blockIdx.x;
@@ -889,9 +889,14 @@ k_gemm_p(const uint8_t* __restrict__ A, int64_t lda_b, const uint8_t* __restrict
 
     if (wave >= 8) {
         // ------------------------------------------------------------------ loader waves
+        // global -> registers -> LDS.  (A wave gets one 1-KiB direct-to-LDS load through per ~250 cycles however many
+        // it has queued -- tools/dma_bench.hip -- so four loader waves on LDS-DMA take in 12 B/clk; plain 16-byte
+        // loads keep D K-steps per wave in flight and the XOR swizzle moves to the ds_write address.)
         const int lw = wave - 8;
         const int prow = lane / CPR, pch = lane % CPR;
-        const int sc = KSTEP == 64 ? (pch ^ ((lane >> 4) & 3)) : (pch ^ ((4 * (lw & 1) + (lane >> 4)) & 7));
+        const int sc = pch;                                          // source chunk = logical chunk
+        const int swz = KSTEP == 64 ? ((lane >> 4) & 3) : ((4 * (lw & 1) + (lane >> 4)) & 7);
+        const uint32_t lds_lane = (uint32_t)(prow * KSTEP + ((pch ^ swz) * 16));
         const uint8_t* zero_row = g_pad_rows;
         const uint8_t* pad_row = g_pad_rows + (int)(uint8_t)g.padval * 64;
         const bool uniform_tap = g.mode != 0 && !g.ups && (g.Cin % KSTEP) == 0;
@@ -900,6 +905,11 @@ k_gemm_p(const uint8_t* __restrict__ A, int64_t lda_b, const uint8_t* __restrict
         const uint8_t* b_row[NB];
         int tap_c = 0, ci_c = 0, tap_s = 0, ci_s = 0;
         const int ltid = tid - 512;                                  // 0..255 over the loader waves
+        constexpr int NEC = ((2 + RA) * BN + 255) / 256;             // epilogue constants per loader lane
+        float ecv[NEC], ecq = 0.f;
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 buf0[PPW], buf1[D > 1 ? PPW : 1];                        // one register set per K-step in flight
+        typedef const __attribute__((address_space(1))) u32x4* gptr4;   // keep the loads global_load (not flat)
 
         auto setup_tile = [&](int T) {
             const int t = logical + T * nwg;
@@ -926,24 +936,29 @@ k_gemm_p(const uint8_t* __restrict__ A, int64_t lda_b, const uint8_t* __restrict
             for (int i = 0; i < NB; ++i) b_row[i] = Bm + (n0 + (lw + 4 * i) * RPP + prow) * ldb_b;
             tap_s = 0; ci_s = 0;
             if (g.mode != 0) { tap_c = (sc * 16) / g.Cin; ci_c = (sc * 16) % g.Cin; }
-            // epilogue constants of this tile (consumed >= S-1 barriers later)
-            float* ec = ec_all + (T & 1) * ECN;
-            if (ltid < 3) ec[(2 + RA) * BN + ltid] = oqp ? oqp[ltid] : 0.f;
+            // epilogue constants of this tile: requested here, written to LDS with the tile's first K-step
             const int64_t b0 = m0 / rows_per_batch;
-            for (int c = ltid; c < BN; c += 256) {
-                const int64_t col = n0 + c;
-                ec[c] = scale ? scale[col] : alpha;
-                ec[BN + c] = bias ? bias[col] : 0.f;
 #pragma unroll
-                for (int j = 0; j < RA; ++j) {
-                    const int64_t b = b0 + j;
-                    ec[(2 + j) * BN + c] = (rowadd && b * rows_per_batch < M) ? rowadd[b * N + col] : 0.f;
+            for (int e = 0; e < NEC; ++e) {
+                const int idx = ltid + 256 * e, row = idx / BN, c = idx - row * BN;
+                const int64_t col = n0 + c;
+                float v = 0.f;
+                if (row == 0) v = scale ? scale[col] : alpha;
+                else if (row == 1) v = bias ? bias[col] : 0.f;
+                else if (row < 2 + RA) {
+                    const int64_t bb = b0 + (row - 2);
+                    v = (rowadd && bb * rows_per_batch < M) ? rowadd[bb * N + col] : 0.f;
                 }
+                ecv[e] = v;
             }
+            if (ltid < 3) ecq = oqp ? oqp[ltid] : 0.f;
         };
 
-        auto issue = [&](int stage, int kk) {
-            const int64_t off = (int64_t)kk * KSTEP + sc * 16;
+        int kk_l = 0, T_l = 0;                                       // (K-step, tile) of the next load
+        auto load_step = [&](auto slot) {
+            constexpr int SLOT = decltype(slot)::value;
+            if (kk_l == 0) setup_tile(T_l);
+            const int64_t off = (int64_t)kk_l * KSTEP + sc * 16;
             const bool kin = off < Kb;
             const uint8_t* src[NA];
             if (g.mode == 0) {
@@ -975,41 +990,87 @@ k_gemm_p(const uint8_t* __restrict__ A, int64_t lda_b, const uint8_t* __restrict
                 while (ci_c >= g.Cin) { ci_c -= g.Cin; ++tap_c; }
             }
 #pragma unroll
-            for (int i = 0; i < NA; ++i) glds16(src[i], lds0 + (uint32_t)(stage * TILE + (lw + 4 * i) * 1024));
+            for (int i = 0; i < NA; ++i) {
+                const u32x4 v = *(gptr4)(uintptr_t)src[i];
+                if constexpr (SLOT == 0) buf0[i] = v; else buf1[i] = v;
+            }
 #pragma unroll
-            for (int i = 0; i < NB; ++i)
-                glds16(kin ? b_row[i] + off : zero_row, lds0 + (uint32_t)(stage * TILE + BM * KSTEP + (lw + 4 * i) * 1024));
+            for (int i = 0; i < NB; ++i) {
+                const u32x4 v = *(gptr4)(uintptr_t)(kin ? b_row[i] + off : zero_row);
+                if constexpr (SLOT == 0) buf0[NA + i] = v; else buf1[NA + i] = v;
+            }
+            if (++kk_l == nk) { kk_l = 0; ++T_l; }
         };
 
-        int gi = 0, kk_i = 0, T_i = 0;
-        auto advance = [&]() {
-            if (kk_i == 0) setup_tile(T_i);
-            issue(gi % S, kk_i);
-            ++gi;
-            if (++kk_i == nk) { kk_i = 0; ++T_i; }
+        int kk_w = 0, T_w = 0, st_w = 0;                             // (K-step, tile, ring slot) of the next LDS write
+        auto write_step = [&](auto slot) {
+            constexpr int SLOT = decltype(slot)::value;
+            uint8_t* base = smem + st_w * TILE + lds_lane;
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+                *reinterpret_cast<u32x4*>(base + (lw + 4 * i) * 1024) = SLOT == 0 ? buf0[i] : buf1[D > 1 ? i : 0];
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+                *reinterpret_cast<u32x4*>(base + BM * KSTEP + (lw + 4 * i) * 1024) = SLOT == 0 ? buf0[NA + i] : buf1[D > 1 ? NA + i : 0];
+            if (kk_w == 0) {                                         // the tile's epilogue constants ride along
+                float* ec = ec_all + (T_w % 3) * ECN;
+#pragma unroll
+                for (int e = 0; e < NEC; ++e) {
+                    const int idx = ltid + 256 * e;
+                    if (idx < (2 + RA) * BN) ec[idx] = ecv[e];
+                }
+                if (ltid < 3) ec[(2 + RA) * BN + ltid] = ecq;
+            }
+            if (++kk_w == nk) { kk_w = 0; ++T_w; }
+            st_w = st_w == S - 1 ? 0 : st_w + 1;
         };
+
+        // pipeline: loads run D steps ahead of the LDS writes, the writes S-1 steps ahead of the consumers.
+        // Register slot of step x is x % D; the loops are written out per slot so every buffer index is static.
+        typedef std::integral_constant<int, 0> S0;
+        typedef std::integral_constant<int, D - 1> S1;
+        int nl = 0, nw = 0;
+        if (nl < G) { load_step(S0{}); ++nl; }
+        if (D > 1 && nl < G) { load_step(S1{}); ++nl; }
+        // fill S-1 ring slots (steps 0 .. S-2)
+        if (nw < G) { write_step(S0{}); ++nw; if (nl < G) { load_step(S0{}); ++nl; } }
+        static_assert(D == 1 || (S & 1), "two register slots: the first in-loop write must land on slot 0");
+#pragma unroll
+        for (int p = 1; p < S - 1; ++p) {
+            if (nw < G) {
+                if ((p & 1) && D > 1) { write_step(S1{}); ++nw; if (nl < G) { load_step(S1{}); ++nl; } }
+                else { write_step(S0{}); ++nw; if (nl < G) { load_step(S0{}); ++nl; } }
+            }
+        }
+        // in-loop: after barrier gs, write step gs+S-1 (slot (gs+S-1) % D) and reload that slot
 #ifdef EDADM_STAMPS
         unsigned long long l_wait = 0, l_bar = 0, l_issue = 0;
         const unsigned long long l_t0 = __builtin_amdgcn_s_memtime();
 #endif
-        for (int p = 0; p < S - 1; ++p)
-            if (gi < G) advance();
-        for (int gs = 0; gs < G; ++gs) {
+        auto turn = [&](auto slot) {
             STAMP(ls0);
-            // step gs has landed once only the steps issued after it are still in flight
-            const int ahead = G - 1 - gs < S - 2 ? G - 1 - gs : S - 2;
-            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            STAMP(ls1);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            STAMP(ls2);
-            if (gi < G) advance();
+            STAMP(ls1);
+            if (nw < G) { write_step(slot); ++nw; }
 #ifdef EDADM_STAMPS
-            { STAMP(ls3); l_wait += ls1 - ls0; l_bar += ls2 - ls1; l_issue += ls3 - ls2; }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
+            STAMP(ls2);
+            if (nl < G) { load_step(slot); ++nl; }
+#ifdef EDADM_STAMPS
+            { STAMP(ls3); l_bar += ls1 - ls0; l_wait += ls2 - ls1; l_issue += ls3 - ls2; }
+#endif
+        };
+        if constexpr (D == 1) {
+            for (int gs = 0; gs < G; ++gs) turn(S0{});
+        } else {
+            // S - 1 = 2 steps were pre-written, so the first in-loop write is step 2 -> slot 0
+            for (int gs = 0; gs < G; gs += 2) {
+                turn(S0{});
+                if (gs + 1 < G) turn(S1{});
+            }
         }
 #ifdef EDADM_STAMPS
         if (lw == 0) { STAMP_ADD(4, l_wait); STAMP_ADD(5, l_bar); STAMP_ADD(6, l_issue); STAMP_ADD(7, __builtin_amdgcn_s_memtime() - l_t0); }
@@ -1075,7 +1136,7 @@ k_gemm_p(const uint8_t* __restrict__ A, int64_t lda_b, const uint8_t* __restrict
                 const int t = logical + T * nwg;
                 const int mt = t / tiles_n, nt = t - mt * tiles_n;
                 const int64_t m0 = (int64_t)mt * BM, n0 = (int64_t)nt * BN;
-                const float* ec = ec_all + (T & 1) * ECN;
+                const float* ec = ec_all + (T % 3) * ECN;
                 if constexpr (decltype(swp)::value) {
                     gemm_epilogue_qdirect<DT, TM, TN, BN, RA>(acc, ec, lane, m0 + wm * 64, n0 + wn * (TN * 32), wn * (TN * 32), out,
                                                               ldo, out_mode);
@@ -1135,12 +1196,14 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
     const bool nt8_gather_ok = true;
     static const int force = getenv("EDADM_GEMM_FORCE") ? atoi(getenv("EDADM_GEMM_FORCE")) : 0;   // diagnostics only
     if constexpr (DT == 0) {
-        // persistent wave-specialised kernel: full 256-row tiles of the big quantised layers
+        // persistent wave-specialised kernel: full 256-row tiles of the short-K layers (projections, 1x1), where a
+        // per-tile launch spends most of its life in prologue latency and epilogue; measured on the LDM-4 layer mix
+        // the long-K convolutions run as fast or faster on k_gemm_nt8 (tools_gemm_table.py)
         const int kstep = force == 6 ? 128 : 64;
         const int64_t ptiles = (M / 256) * (N / (64 * tn));
         if (force != 2 && force != 3 && batch == 1 && inner == 1 && tn >= 2 && M % 256 == 0 && N % (64 * tn) == 0 &&
-            (Kb + kstep - 1) / kstep >= 256 / kstep && (!rowadd || rpb >= 64) && (out_mode == 0 || (!rowadd && !residual)) &&
-            (force >= 5 || ptiles >= 224) && (g.mode == 0 || (int64_t)g.B * g.H * g.W * g.Cin < (1ll << 31))) {
+            (Kb + kstep - 1) / kstep >= 3 && (!rowadd || rpb >= 64) && (out_mode == 0 || (!rowadd && !residual)) &&
+            (force >= 5 || (ptiles >= 224 && Kb <= 1024)) && (g.mode == 0 || (int64_t)g.B * g.H * g.W * g.Cin < (1ll << 31))) {
             static int ncu = 0;
             if (!ncu) {
                 int dev = 0;

@@ -28,7 +28,7 @@ def case(M, N, K, mode, residual):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); f(); e1.record(); torch.cuda.synchronize(); L.edadm_dbg_read(buf)
         us = e0.elapsed_time(e1) * 1e3
-        print("M=%d N=%d K=%d mode=%d res=%d | %.0f us | MFMA wave0: barrier=%.0f compute=%.0f epilogue=%.0f | loader w0: vmcnt=%.0f barrier=%.0f issue=%.0f total=%.0f ticks" %
+        print("M=%d N=%d K=%d mode=%d res=%d | %.0f us | MFMA wave0: barrier=%.0f compute=%.0f epilogue=%.0f | loader w0: write(+wait loads)=%.0f barrier=%.0f load-issue=%.0f total=%.0f ticks" %
               (M, N, K, mode, residual, us, buf[0] / n, buf[1] / n, buf[2] / n, buf[4] / n, buf[5] / n, buf[6] / n, buf[7] / n))
         return
     n = buf[4]
