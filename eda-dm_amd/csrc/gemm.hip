@@ -73,49 +73,6 @@ __device__ __forceinline__ void mma_step(const uint4& fa, const uint4& fb, typen
     }
 }
 
-// round(v / d) with the reference's true-division result at the cost of a multiply: t = v * (1/d) differs from
-// v / d by a couple of ulp, which can only change the rounded integer when t sits within 1e-3 of a .5
-// boundary (|t| < 1024; larger magnitudes saturate in the clamp that follows).  Those rare lanes redo the IEEE
-// division behind a REAL branch: the empty asm keeps the compiler from if-converting it into an unconditional
-// 10-instruction division per element.
-__device__ __forceinline__ float rint_div(float v, float d, float inv_d) {
-    const float t = v * inv_d;
-    float r = rintf(t);
-    if (__builtin_expect(fabsf(t - r) > 0.499f, 0)) {
-        asm volatile("" : "+v"(r));
-        r = rintf(v / d);
-    }
-    return r;
-}
-
-template <int NV>
-__device__ __forceinline__ void rint_div_n(const float (&v)[NV], float d, float inv_d, float (&r)[NV]) {
-    bool near = false;
-#pragma unroll
-    for (int e = 0; e < NV; ++e) {
-        const float t = v[e] * inv_d;
-        r[e] = rintf(t);
-        near |= fabsf(t - r[e]) > 0.499f;
-    }
-    if (__builtin_expect(near, 0)) {                       // one branch per group
-#pragma unroll
-        for (int e = 0; e < NV; ++e) {
-            asm volatile("" : "+v"(r[e]));
-            r[e] = rintf(v[e] / d);
-        }
-    }
-}
-
-// four quantised codes (float, already clamped to [0, 255]) -> int8 operand bytes code - 128
-__device__ __forceinline__ uint32_t pack_codes_i8(const float (&q)[4]) {
-    uint32_t w = 0;
-    w = __builtin_amdgcn_cvt_pk_u8_f32(q[0], 0, w);
-    w = __builtin_amdgcn_cvt_pk_u8_f32(q[1], 1, w);
-    w = __builtin_amdgcn_cvt_pk_u8_f32(q[2], 2, w);
-    w = __builtin_amdgcn_cvt_pk_u8_f32(q[3], 3, w);
-    return w ^ 0x80808080u;
-}
-
 // Per-column epilogue constants live in LDS (scale, bias, and the time-embedding rows of the few batch
 // entries a tile spans), so the store phase issues no global load except the residual, and all residual
 // loads of a slab are issued before its first store: on gfx950 vmcnt counts stores too and retires in

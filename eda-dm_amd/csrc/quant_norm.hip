@@ -6,18 +6,32 @@
 #include "../../include/edadm.h"
 #include <hip/hip_fp16.h>
 
-struct QP { float d, z, qmax, pad; };
-
-__device__ __forceinline__ int q_code_i8(float x, const QP& q) {
-    const float c = fminf(fmaxf(rintf(x / q.d) + q.z, 0.f), q.qmax);
-    return (int)c - 128;
+// (delta, zero point, qmax) as the host passes them; `inv` (the 4th float, unused by the host) is filled with
+// 1/delta when a kernel loads the entry: codes are rint(x * inv) with the exact division kept for the rare values
+// within 1e-3 of a rounding boundary (rint_div, common.h) -- the IEEE division costs ~12 instructions per element
+// and made these producers ALU-bound instead of HBM-bound.
+struct QP { float d, z, qmax, inv; };
+__device__ __forceinline__ QP qp_load(const QP* p, int i) {
+    QP q = p[i];
+    q.inv = 1.0f / q.d;
+    return q;
 }
+
+__device__ __forceinline__ float q_code_f(float x, const QP& q) {      // clamped code as a float
+    return fminf(fmaxf(rint_div(x, q.d, q.inv) + q.z, 0.f), q.qmax);
+}
+__device__ __forceinline__ int q_code_i8(float x, const QP& q) { return (int)q_code_f(x, q) - 128; }
 __device__ __forceinline__ uint32_t pack4_i8(int a, int b, int c, int d) {
     return (uint32_t)(a & 0xff) | ((uint32_t)(b & 0xff) << 8) | ((uint32_t)(c & 0xff) << 16) |
            ((uint32_t)(d & 0xff) << 24);
 }
 __device__ __forceinline__ uint32_t quant4(const float4& v, const QP& q) {
-    return pack4_i8(q_code_i8(v.x, q), q_code_i8(v.y, q), q_code_i8(v.z, q), q_code_i8(v.w, q));
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    float r[4];
+    rint_div_n<4>(x, q.d, q.inv, r);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = fminf(fmaxf(r[e] + q.z, 0.f), q.qmax);
+    return pack_codes_i8(r);
 }
 
 // ------------------------------------------------------------------ plain quantise [rows][C]
@@ -25,8 +39,8 @@ __global__ void __launch_bounds__(256) k_quant_i8(const float* __restrict__ x, i
                                                   int64_t rows, int64_t C, const QP* __restrict__ qp,
                                                   int64_t split) {
     const int64_t n = rows * C, stride = (int64_t)gridDim.x * blockDim.x;
-    const QP q0 = qp[0];
-    const QP q1 = split > 0 ? qp[1] : qp[0];
+    const QP q0 = qp_load(qp, 0);
+    const QP q1 = split > 0 ? qp_load(qp, 1) : q0;
     if ((C & 3) == 0 && (split & 3) == 0) {
         const int64_t n4 = n >> 2, C4 = C >> 2, s4 = split >> 2;
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -53,13 +67,13 @@ extern "C" int edadm_quant_i8(const float* x, int8_t* out, int64_t rows, int64_t
 __global__ void __launch_bounds__(256) k_quant_f16(const float* __restrict__ x, int64_t ldx,
                                                    __half* __restrict__ out, int64_t ldo, int64_t rows, int64_t C,
                                                    const QP* __restrict__ qp, float premul) {
-    const QP q = qp[0];
+    const QP q = qp_load(qp, 0);
     const int64_t n = rows * C, stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const int64_t r = i / C, c = i - r * C;
         float v = x[r * ldx + c];
         if (premul != 1.0f) v = v * premul;
-        const float code = fminf(fmaxf(rintf(v / q.d) + q.z, 0.f), q.qmax);
+        const float code = q_code_f(v, q);
         out[r * ldo + c] = __float2half(code - q.z);
     }
 }
@@ -106,7 +120,7 @@ extern "C" int edadm_nhwc_to_nchw(const float* x, float* out, int64_t B, int64_t
 __global__ void __launch_bounds__(256) k_im2col_q(const float* __restrict__ x, int8_t* __restrict__ out,
                                                   int64_t B, int64_t H, int64_t W, int64_t C, int64_t Kpad,
                                                   const QP* __restrict__ qp) {
-    const QP q = qp[0];
+    const QP q = qp_load(qp, 0);
     const int padv = (int)q.z - 128;
     const int64_t n = B * H * W * Kpad, stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -229,7 +243,7 @@ __global__ void __launch_bounds__(256) k_gn_apply(const float* __restrict__ x, c
     const int64_t r1 = r0 + rows_per_block < HW ? r0 + rows_per_block : HW;
     const int Q = (int)(C >> 2);
     const int cpg = (int)(C / G);
-    QP qa = qp ? qp[0] : QP{1, 0, 255, 0}, qb = (qp && nq > 1) ? qp[1] : qa, qc = (qp && nq > 2) ? qp[2] : qa;
+    QP qa = qp ? qp_load(qp, 0) : QP{1, 0, 255, 1}, qb = (qp && nq > 1) ? qp_load(qp, 1) : qa, qc = (qp && nq > 2) ? qp_load(qp, 2) : qa;
     const int RS = Q <= 256 ? 256 / Q : 1;
     const int tid = threadIdx.x;
     const int qstep = Q <= 256 ? Q : 256;           // a thread keeps its quad(s): constants loaded once
@@ -257,7 +271,7 @@ __global__ void __launch_bounds__(256) k_gn_apply(const float* __restrict__ x, c
             }
             if (silu) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) y[j] = silu_f(y[j]);
+                for (int j = 0; j < 4; ++j) y[j] = silu_rcp(y[j]);
             }
             const float4 o = make_float4(y[0], y[1], y[2], y[3]);
             if (out_f32) reinterpret_cast<float4*>(out_f32)[idx] = o;
@@ -286,6 +300,57 @@ extern "C" int edadm_groupnorm_apply(const float* x, const float* stats, const f
 // ------------------------------------------------------------------ LayerNorm (+ up to 3 quantised outputs)
 // one wave per row; the row stays in registers (C <= 64*MAXPL) between the two passes
 #define LN_MAXPL 32
+#define LN_MAXV4 8
+// C % 4 == 0 (every layer of the UNets): a lane owns float4 chunks lane, lane+64, ... -> 16-byte loads, one packed
+// dword per quantised output
+__global__ void __launch_bounds__(256) k_ln_quant_v4(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, int64_t rows, int64_t C,
+                                                     float eps, float* __restrict__ out_f32, int8_t* __restrict__ q0,
+                                                     int8_t* __restrict__ q1, int8_t* __restrict__ q2,
+                                                     const QP* __restrict__ qp, int nq) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    QP qa = qp ? qp_load(qp, 0) : QP{1, 0, 255, 1}, qb = (qp && nq > 1) ? qp_load(qp, 1) : qa, qc = (qp && nq > 2) ? qp_load(qp, 2) : qa;
+    const int Q = (int)(C >> 2);
+    const float4* xr = reinterpret_cast<const float4*>(x + row * C);
+    float4 v[LN_MAXV4];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV4; ++j) {
+        const int c = j * 64 + lane;
+        v[j] = c < Q ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV4; ++j) {
+        const int c = j * 64 + lane;
+        if (c < Q) {
+            const float d0 = v[j].x - mean, d1 = v[j].y - mean, d2 = v[j].z - mean, d3 = v[j].w - mean;
+            ss += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)C + eps);
+#pragma unroll
+    for (int j = 0; j < LN_MAXV4; ++j) {
+        const int c = j * 64 + lane;
+        if (c < Q) {
+            const float4 g4 = reinterpret_cast<const float4*>(gamma)[c], b4 = reinterpret_cast<const float4*>(beta)[c];
+            float4 y;
+            y.x = (v[j].x - mean) * rstd * g4.x + b4.x;
+            y.y = (v[j].y - mean) * rstd * g4.y + b4.y;
+            y.z = (v[j].z - mean) * rstd * g4.z + b4.z;
+            y.w = (v[j].w - mean) * rstd * g4.w + b4.w;
+            const int64_t o = row * Q + c;
+            if (out_f32) reinterpret_cast<float4*>(out_f32)[o] = y;
+            if (q0) reinterpret_cast<uint32_t*>(q0)[o] = quant4(y, qa);
+            if (q1) reinterpret_cast<uint32_t*>(q1)[o] = quant4(y, qb);
+            if (q2) reinterpret_cast<uint32_t*>(q2)[o] = quant4(y, qc);
+        }
+    }
+}
 __global__ void __launch_bounds__(256) k_ln_quant(const float* __restrict__ x, const float* __restrict__ gamma,
                                                   const float* __restrict__ beta, int64_t rows, int64_t C,
                                                   float eps, float* __restrict__ out_f32, int8_t* __restrict__ q0,
@@ -294,7 +359,7 @@ __global__ void __launch_bounds__(256) k_ln_quant(const float* __restrict__ x, c
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    QP qa = qp ? qp[0] : QP{1, 0, 255, 0}, qb = (qp && nq > 1) ? qp[1] : qa, qc = (qp && nq > 2) ? qp[2] : qa;
+    QP qa = qp ? qp_load(qp, 0) : QP{1, 0, 255, 1}, qb = (qp && nq > 1) ? qp_load(qp, 1) : qa, qc = (qp && nq > 2) ? qp_load(qp, 2) : qa;
     const float* xr = x + row * C;
     float v[LN_MAXPL];
     const int npl = (int)((C + 63) / 64);
@@ -337,18 +402,24 @@ extern "C" int edadm_layernorm_quant(const float* x, const float* gamma, const f
                                      int nq, void* stream) {
     if (!x || !gamma || !beta || rows <= 0 || C <= 0 || C > 64 * LN_MAXPL) return EDADM_EINVAL;
     if ((q0 || q1 || q2) && !qp) return EDADM_EINVAL;
-    hipLaunchKernelGGL(k_ln_quant, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma,
-                       beta, rows, C, eps, out_f32, q0, q1, q2, (const QP*)qp, nq);
+    const bool al = !(((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)out_f32) & 15) &&
+                    !(((uintptr_t)q0 | (uintptr_t)q1 | (uintptr_t)q2) & 3);
+    if ((C & 3) == 0 && C <= 256 * LN_MAXV4 && al)
+        hipLaunchKernelGGL(k_ln_quant_v4, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma,
+                           beta, rows, C, eps, out_f32, q0, q1, q2, (const QP*)qp, nq);
+    else
+        hipLaunchKernelGGL(k_ln_quant, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma,
+                           beta, rows, C, eps, out_f32, q0, q1, q2, (const QP*)qp, nq);
     return edadm_launch_status();
 }
 
 // ------------------------------------------------------------------ small fused producers
 __global__ void __launch_bounds__(256) k_silu_q(const float* __restrict__ x, int8_t* __restrict__ out, int64_t n,
                                                 const QP* __restrict__ qp) {
-    const QP q = qp[0];
+    const QP q = qp_load(qp, 0);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        out[i] = (int8_t)q_code_i8(silu_f(x[i]), q);
+        out[i] = (int8_t)q_code_i8(silu_rcp(x[i]), q);
 }
 extern "C" int edadm_silu_quant_i8(const float* x, int8_t* out, int64_t n, const float* qp, void* stream) {
     if (!x || !out || !qp || n <= 0) return EDADM_EINVAL;
@@ -368,7 +439,7 @@ extern "C" int edadm_silu(const float* x, float* out, int64_t n, void* stream) {
 // GEGLU: x[rows][2*inner] -> a * gelu(gate) quantised  (attention.py:37-45; exact-erf gelu)
 __global__ void __launch_bounds__(256) k_geglu_q(const float* __restrict__ x, int8_t* __restrict__ out,
                                                  int64_t rows, int64_t inner, const QP* __restrict__ qp) {
-    const QP q = qp[0];
+    const QP q = qp_load(qp, 0);
     const int64_t n = rows * inner, stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const int64_t r = i / inner, c = i - r * inner;
@@ -445,10 +516,76 @@ extern "C" int edadm_upsample2_nhwc(const float* x, float* out, int64_t B, int64
 }
 
 // ------------------------------------------------------------------ K6: softmax rows + quantise to f16 codes
+// cols % 4 == 0, cols <= 4096: the row lives in registers (one read of the scores), exp once per element,
+// the probability's code from one multiply (exact division only next to a rounding boundary), 8-byte stores
+#define SM_MAXV4 16
+__global__ void __launch_bounds__(256) k_softmax_q_v4(const float* __restrict__ s, __half* __restrict__ out,
+                                                      int64_t rows, int64_t cols, int64_t ldo,
+                                                      const QP* __restrict__ qp) {
+    const QP q = qp_load(qp, 0);
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int Q = (int)(cols >> 2);
+    const float4* sr = reinterpret_cast<const float4*>(s + row * cols);
+    float4 v[SM_MAXV4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < SM_MAXV4; ++j) {
+        const int c = j * 64 + lane;
+        if (c < Q) {
+            v[j] = sr[c];
+            mx = fmaxf(mx, fmaxf(fmaxf(v[j].x, v[j].y), fmaxf(v[j].z, v[j].w)));
+        }
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < SM_MAXV4; ++j) {
+        const int c = j * 64 + lane;
+        if (c < Q) {
+            v[j].x = expf(v[j].x - mx); v[j].y = expf(v[j].y - mx); v[j].z = expf(v[j].z - mx); v[j].w = expf(v[j].w - mx);
+            sum += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+        }
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / (sum * q.d);                  // e / sum / delta ~ e * inv; boundary cases redo both divisions
+    __half* orow = out + row * ldo;
+#pragma unroll
+    for (int j = 0; j < SM_MAXV4; ++j) {
+        const int c = j * 64 + lane;
+        if (c < Q) {
+            const float e[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+            float r[4];
+            bool near = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float t = e[k] * inv;
+                r[k] = rintf(t);
+                near |= fabsf(t - r[k]) > 0.499f;
+            }
+            if (__builtin_expect(near, 0)) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    asm volatile("" : "+v"(r[k]));
+                    r[k] = rintf((e[k] / sum) / q.d);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r[k] = fminf(fmaxf(r[k] + q.z, 0.f), q.qmax) - q.z;
+            __half2 h0 = __floats2half2_rn(r[0], r[1]), h1 = __floats2half2_rn(r[2], r[3]);
+            uint2 pk;
+            pk.x = *reinterpret_cast<uint32_t*>(&h0);
+            pk.y = *reinterpret_cast<uint32_t*>(&h1);
+            *reinterpret_cast<uint2*>(orow + 4 * c) = pk;
+        }
+    }
+    for (int64_t c = cols + lane; c < ldo; c += 64) orow[c] = __float2half(0.f);
+}
 __global__ void __launch_bounds__(256) k_softmax_q(const float* __restrict__ s, __half* __restrict__ out,
                                                    int64_t rows, int64_t cols, int64_t ldo,
                                                    const QP* __restrict__ qp) {
-    const QP q = qp[0];
+    const QP q = qp_load(qp, 0);
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -461,7 +598,7 @@ __global__ void __launch_bounds__(256) k_softmax_q(const float* __restrict__ s, 
     sum = wave_sum(sum);
     for (int64_t c = lane; c < cols; c += 64) {
         const float p = expf(sr[c] - mx) / sum;
-        const float code = fminf(fmaxf(rintf(p / q.d) + q.z, 0.f), q.qmax);
+        const float code = q_code_f(p, q);
         out[row * ldo + c] = __float2half(code - q.z);
     }
     for (int64_t c = cols + lane; c < ldo; c += 64) out[row * ldo + c] = __float2half(0.f);
@@ -469,8 +606,12 @@ __global__ void __launch_bounds__(256) k_softmax_q(const float* __restrict__ s, 
 extern "C" int edadm_softmax_quant_f16(const float* s, void* out, int64_t rows, int64_t cols, int64_t ldo,
                                        const float* qp, void* stream) {
     if (!s || !out || !qp || rows <= 0 || cols <= 0 || ldo < cols) return EDADM_EINVAL;
-    hipLaunchKernelGGL(k_softmax_q, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, s,
-                       (__half*)out, rows, cols, ldo, (const QP*)qp);
+    if ((cols & 3) == 0 && (ldo & 3) == 0 && cols <= 256 * SM_MAXV4 && !((uintptr_t)s & 15) && !((uintptr_t)out & 7))
+        hipLaunchKernelGGL(k_softmax_q_v4, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, s,
+                           (__half*)out, rows, cols, ldo, (const QP*)qp);
+    else
+        hipLaunchKernelGGL(k_softmax_q, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, s,
+                           (__half*)out, rows, cols, ldo, (const QP*)qp);
     return edadm_launch_status();
 }
 
