@@ -323,7 +323,8 @@ __device__ __forceinline__ void gemm_epilogue_direct(typename Acc<DT>::type (&ac
 template <int DT, int TM, int TN, int BN, int RA>
 __device__ __forceinline__ void gemm_epilogue_qdirect(typename Acc<DT>::type (&acc)[TM][TN], const float* ec, int lane,
                                                       int64_t row0, int64_t col0, int ecol0, void* __restrict__ outv,
-                                                      int64_t ldo, int out_mode) {
+                                                      int64_t ldo, int out_mode, const float* __restrict__ residual = nullptr,
+                                                      int64_t ldr = 0) {
     const int fr = lane & 31, fh4 = (lane >> 5) * 4;
     const float od = ec[(2 + RA) * BN], oz = ec[(2 + RA) * BN + 1], oq = ec[(2 + RA) * BN + 2];
     const float oi = 1.0f / od;
@@ -349,6 +350,10 @@ __device__ __forceinline__ void gemm_epilogue_qdirect(typename Acc<DT>::type (&a
                     }
                     v[0] = v[0] * s4.x + b4.x; v[1] = v[1] * s4.y + b4.y; v[2] = v[2] * s4.z + b4.z; v[3] = v[3] * s4.w + b4.w;
                     const int64_t col = col0 + j * 32 + 8 * g + fh4;
+                    if (residual) {                        // the lane's four columns are one 16-byte piece of its row
+                        const float4 r4 = *reinterpret_cast<const float4*>(residual + (row0 + i * 32 + fr) * ldr + col);
+                        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+                    }
                     const int64_t ro = rbase + (int64_t)(i * 32) * ldo;
                     if constexpr (MODE == 3) {             // GEGLU on interleaved (a, gate) columns -> int8 operand
                         float y[2], r[2];
@@ -529,7 +534,7 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
     // full fp32 tiles take the register-direct epilogue (workgroup-uniform choice)
     const bool full = m0 + BM <= M && n0 + BN <= N;
     const bool direct = out_mode == 0 && full && (!rowadd || rows_per_batch >= TM * 32);
-    const bool qdirect = out_mode != 0 && full && !rowadd && !residual;    // transposed accumulators, see the epilogue
+    const bool qdirect = out_mode != 0 && full && !rowadd && (!residual || !(ldr & 3));   // transposed accumulators, see the epilogue
 
     typename Acc<DT>::type acc[TM][TN];
 #pragma unroll
@@ -590,7 +595,7 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
 
     if (qdirect) {
         gemm_epilogue_qdirect<DT, TM, TN, BN, RA>(acc, ec, lane, m0 + wm * (TM * 32), n0 + wn * (TN * 32), wn * (TN * 32), out, ldo,
-                                                  out_mode);
+                                                  out_mode, residual, ldr);
         return;
     }
     if (direct) {
@@ -732,7 +737,7 @@ k_gemm_nt8(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, cons
     // full fp32 tiles take the register-direct epilogue (workgroup-uniform choice)
     const bool full = m0 + BM <= M && n0 + BN <= N;
     const bool direct = out_mode == 0 && full && (!rowadd || rows_per_batch >= TM * 32);
-    const bool qdirect = out_mode != 0 && full && !rowadd && !residual;    // transposed accumulators, see the epilogue
+    const bool qdirect = out_mode != 0 && full && !rowadd && (!residual || !(ldr & 3));   // transposed accumulators, see the epilogue
     STAMP(t_consts);
 
     typename Acc<DT>::type acc[TM][TN];
@@ -787,7 +792,8 @@ k_gemm_nt8(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, cons
     else main_loop(std::false_type{});
     STAMP(t_main);
     if (qdirect) {
-        gemm_epilogue_qdirect<DT, TM, TN, BN, RA>(acc, ec, lane, m0 + wm * 64, n0 + wn * (TN * 32), wn * (TN * 32), out, ldo, out_mode);
+        gemm_epilogue_qdirect<DT, TM, TN, BN, RA>(acc, ec, lane, m0 + wm * 64, n0 + wn * (TN * 32), wn * (TN * 32), out, ldo, out_mode,
+                                                  residual, ldr);
     } else if (direct) {
         EpiRegs<TN> er;
         load_epi_regs<TN, BN>(er, ec, lane, m0, m0 + wm * 64, wn * (TN * 32), rows_per_batch);
@@ -1096,7 +1102,7 @@ k_gemm_p(const uint8_t* __restrict__ A, int64_t lda_b, const uint8_t* __restrict
                 const float* ec = ec_all + (T % 3) * ECN;
                 if constexpr (decltype(swp)::value) {
                     gemm_epilogue_qdirect<DT, TM, TN, BN, RA>(acc, ec, lane, m0 + wm * 64, n0 + wn * (TN * 32), wn * (TN * 32), out,
-                                                              ldo, out_mode);
+                                                              ldo, out_mode, residual, ldr);
                 } else {
                     EpiRegs<TN> er;
                     load_epi_regs<TN, BN>(er, ec, lane, m0, m0 + wm * 64, wn * (TN * 32), rows_per_batch);
@@ -1159,13 +1165,13 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
         const int kstep = force == 6 ? 128 : 64;
         const int64_t ptiles = (M / 256) * (N / (64 * tn));
         if (force != 2 && force != 3 && batch == 1 && inner == 1 && tn >= 2 && M % 256 == 0 && N % (64 * tn) == 0 &&
-            (Kb + kstep - 1) / kstep >= 3 && (!rowadd || rpb >= 64) && (out_mode == 0 || (!rowadd && !residual)) &&
+            (Kb + kstep - 1) / kstep >= 3 && (!rowadd || rpb >= 64) && (out_mode == 0 || (!rowadd && (!residual || !(ldr & 3)))) &&
             (force >= 5 || (ptiles >= 224 && Kb <= 1024)) && (g.mode == 0 || (int64_t)g.B * g.H * g.W * g.Cin < (1ll << 31))) {
             static int ncu = 0;
             if (!ncu) {
                 int dev = 0;
-                hipGetDevice(&dev);
-                hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+                (void)hipGetDevice(&dev);
+                (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
                 ncu = ncu >= 8 ? ncu & ~7 : 8;
             }
 #define EDADM_GEMMP_CASE(TN_, KS_)                                                                              \

@@ -7,11 +7,15 @@
 #include "../../include/edadm.h"
 
 #define SMALLN_MAX 4
+#define SMALLN_P 4          // output pixels per strip: a row of the input is loaded once for its three horizontal taps
+// One block per output row (b, y), a wave per 16-pixel span in strips of SMALLN_P pixels.  A lane owns channels
+// lane + 64 j; the 9 x N weight vectors of those channels stay in registers; per strip the 3 x (P + 2) input
+// pixels are read once (coalesced 256-byte rows) and feed every tap that uses them.
 template <int CJ>
 __global__ void __launch_bounds__(256) k_conv3x3_smalln(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ out,
                                                         int64_t B, int64_t H, int64_t W, int64_t C, int N) {
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float wr[SMALLN_MAX][9][CJ];
 #pragma unroll
     for (int n = 0; n < SMALLN_MAX; ++n)
@@ -22,37 +26,61 @@ __global__ void __launch_bounds__(256) k_conv3x3_smalln(const float* __restrict_
                 const int64_t c = lane + 64 * j;
                 wr[n][t][j] = (n < N && c < C) ? w[((int64_t)n * 9 + t) * C + c] : 0.f;
             }
-    const int64_t npix = B * H * W;
-    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
-    for (int64_t pix = wave0; pix < npix; pix += nwaves) {
-        const int64_t b = pix / (H * W), r = pix - b * H * W, y = r / W, xx = r - y * W;
-        float acc[SMALLN_MAX] = {0.f, 0.f, 0.f, 0.f};
+    const int iW = (int)W, iH = (int)H;
+    const int b = (int)(blockIdx.x / (unsigned)iH), y = (int)(blockIdx.x - (unsigned)b * (unsigned)iH);
+    const float* xb = x + (int64_t)b * H * W * C;
+    const int nstrips = (iW + SMALLN_P - 1) / SMALLN_P;
+    for (int sidx = wave; sidx < nstrips; sidx += 4) {
+        const int x0 = sidx * SMALLN_P;
+        float acc[SMALLN_P][SMALLN_MAX];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int64_t iy = y + t / 3 - 1, ix = xx + t % 3 - 1;
-            if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;      // wave-uniform
-            const float* xp = x + ((b * H + iy) * W + ix) * C;
+        for (int p = 0; p < SMALLN_P; ++p)
 #pragma unroll
-            for (int j = 0; j < CJ; ++j) {
-                const int64_t c = lane + 64 * j;
-                const float v = c < C ? xp[c] : 0.f;
+            for (int n = 0; n < SMALLN_MAX; ++n) acc[p][n] = 0.f;
 #pragma unroll
-                for (int n = 0; n < SMALLN_MAX; ++n) acc[n] += v * wr[n][t][j];
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = y + ky - 1;
+            if (iy < 0 || iy >= iH) continue;                          // wave-uniform
+            const float* xrow = xb + (int64_t)iy * W * C;
+#pragma unroll
+            for (int xx = -1; xx <= SMALLN_P; ++xx) {
+                const int ix = x0 + xx;
+                if (ix < 0 || ix >= iW) continue;                      // wave-uniform
+                float v[CJ];
+#pragma unroll
+                for (int j = 0; j < CJ; ++j) {
+                    const int c = lane + 64 * j;
+                    v[j] = c < C ? xrow[(int64_t)ix * C + c] : 0.f;
+                }
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int p = xx - kx + 1;                         // output pixel this (input, tap) pair feeds
+                    if (p < 0 || p >= SMALLN_P) continue;
+#pragma unroll
+                    for (int j = 0; j < CJ; ++j)
+#pragma unroll
+                        for (int n = 0; n < SMALLN_MAX; ++n) acc[p][n] += v[j] * wr[n][ky * 3 + kx][j];
+                }
             }
         }
 #pragma unroll
-        for (int n = 0; n < SMALLN_MAX; ++n) {
-            const float s = wave_sum(acc[n]);
-            if (lane == 0 && n < N) out[pix * N + n] = s + (bias ? bias[n] : 0.f);
+        for (int p = 0; p < SMALLN_P; ++p) {
+            if (x0 + p >= iW) continue;
+#pragma unroll
+            for (int n = 0; n < SMALLN_MAX; ++n) {
+                if (n >= N) continue;
+                const float sum = wave_sum(acc[p][n]);
+                if (lane == 0) out[(((int64_t)b * H + y) * W + x0 + p) * N + n] = sum + (bias ? bias[n] : 0.f);
+            }
         }
     }
 }
 extern "C" int edadm_conv3x3_f32_smalln(const float* x, const float* w, const float* bias, float* out, int64_t B,
                                         int64_t H, int64_t W, int64_t C, int64_t N, void* stream) {
-    if (!x || !w || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C > 320 || N <= 0 || N > SMALLN_MAX)
+    if (!x || !w || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C > 320 || N <= 0 || N > SMALLN_MAX ||
+        B * H > 0x7fffffff)
         return EDADM_EINVAL;
-    int64_t g = (B * H * W + 3) / 4;
-    if (g > 2048) g = 2048;
+    const int64_t g = B * H;
     const int cj = (int)((C + 63) / 64);
     hipStream_t st = (hipStream_t)stream;
 #define SMALLN_CASE(CJ_)                                                                                          \
