@@ -35,32 +35,44 @@ __device__ __forceinline__ uint32_t quant4(const float4& v, const QP& q) {
 }
 
 // ------------------------------------------------------------------ plain quantise [rows][C]
-__global__ void __launch_bounds__(256) k_quant_i8(const float* __restrict__ x, int8_t* __restrict__ out,
-                                                  int64_t rows, int64_t C, const QP* __restrict__ qp,
-                                                  int64_t split) {
+// x is either one [rows][C] matrix or the channel concatenation [x | x2] of two (C1 and C - C1 channels wide):
+// the UNet skip concatenation is never materialised in fp32, its consumers read the two halves in place.
+__global__ void __launch_bounds__(256) k_quant_i8(const float* __restrict__ x, const float* __restrict__ x2, int64_t C1,
+                                                  int8_t* __restrict__ out, int64_t rows, int64_t C,
+                                                  const QP* __restrict__ qp, int64_t split) {
     const int64_t n = rows * C, stride = (int64_t)gridDim.x * blockDim.x;
     const QP q0 = qp_load(qp, 0);
     const QP q1 = split > 0 ? qp_load(qp, 1) : q0;
-    if ((C & 3) == 0 && (split & 3) == 0) {
-        const int64_t n4 = n >> 2, C4 = C >> 2, s4 = split >> 2;
+    if ((C & 3) == 0 && (split & 3) == 0 && (C1 & 3) == 0) {
+        const int64_t n4 = n >> 2, C4 = C >> 2, s4 = split >> 2, A4 = C1 >> 2, B4 = C4 - A4;
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-            const float4 v = reinterpret_cast<const float4*>(x)[i];
-            const bool second = split > 0 && (i % C4) >= s4;
+            const int64_t r = i / C4, c = i - r * C4;
+            const float4 v = c < A4 ? reinterpret_cast<const float4*>(x)[r * A4 + c]
+                                    : reinterpret_cast<const float4*>(x2)[r * B4 + (c - A4)];
+            const bool second = split > 0 && c >= s4;
             reinterpret_cast<uint32_t*>(out)[i] = quant4(v, second ? q1 : q0);
         }
     } else {
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-            const bool second = split > 0 && (i % C) >= split;
-            out[i] = (int8_t)q_code_i8(x[i], second ? q1 : q0);
+            const int64_t r = i / C, c = i - r * C;
+            const float v = c < C1 ? x[r * C1 + c] : x2[r * (C - C1) + (c - C1)];
+            const bool second = split > 0 && c >= split;
+            out[i] = (int8_t)q_code_i8(v, second ? q1 : q0);
         }
     }
 }
+extern "C" int edadm_quant_i8_cat(const float* x1, int64_t C1, const float* x2, int64_t C2, int8_t* out, int64_t rows,
+                                  const float* qp, int64_t split, void* stream) {
+    const int64_t C = C1 + (x2 ? C2 : 0);
+    if (!x1 || !out || !qp || rows <= 0 || C1 <= 0 || (x2 && C2 <= 0) || split < 0 || split >= C + (split == 0))
+        return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_quant_i8, dim3(edadm_grid(rows * C / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, x1, x2,
+                       C1, out, rows, C, (const QP*)qp, split);
+    return edadm_launch_status();
+}
 extern "C" int edadm_quant_i8(const float* x, int8_t* out, int64_t rows, int64_t C, const float* qp, int64_t split,
                               void* stream) {
-    if (!x || !out || !qp || rows <= 0 || C <= 0 || split < 0 || split >= C + (split == 0)) return EDADM_EINVAL;
-    hipLaunchKernelGGL(k_quant_i8, dim3(edadm_grid(rows * C / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, x,
-                       out, rows, C, (const QP*)qp, split);
-    return edadm_launch_status();
+    return edadm_quant_i8_cat(x, C, nullptr, 0, out, rows, qp, split, stream);
 }
 
 // f16 operand = code - zp (exact integers), optional pre-multiplier (q*scale, openaimodel.py:391)
@@ -148,8 +160,8 @@ extern "C" int edadm_im2col_quant_i8(const float* x, int8_t* out, int64_t B, int
 // finalize: per (b, group) sum of chunks x channels-in-group in double -> stats[b][g] = {mean, rstd}
 #define GN_CHUNKS(HW) ((int)((HW) >= 1024 ? 32 : ((HW) >= 64 ? 8 : 1)))
 
-__global__ void __launch_bounds__(256) k_gn_partial(const float* __restrict__ x, float* __restrict__ ws,
-                                                    int64_t HW, int64_t C, int nchunk) {
+__global__ void __launch_bounds__(256) k_gn_partial(const float* __restrict__ x, const float* __restrict__ x2, int64_t C1,
+                                                    float* __restrict__ ws, int64_t HW, int64_t C, int nchunk) {
     extern __shared__ float sm[];  // [RS][C][2] when RS > 1
     const int64_t b = blockIdx.y;
     const int chunk = blockIdx.x;
@@ -157,14 +169,17 @@ __global__ void __launch_bounds__(256) k_gn_partial(const float* __restrict__ x,
     const int Q = (int)(C >> 2);
     const int RS = Q <= 256 ? 256 / Q : 1;
     const int tid = threadIdx.x;
-    const float* xb = x + b * HW * C;
+    const int Q1 = (int)(C1 >> 2), Q2 = Q - Q1;                      // [x | x2] halves (x2 == nullptr: Q1 == Q)
+    const float4* xa = reinterpret_cast<const float4*>(x) + b * HW * Q1;
+    const float4* xc = reinterpret_cast<const float4*>(x2) + b * HW * Q2;
     float* wb = ws + ((b * nchunk + chunk) * C) * 2;
     if (Q <= 256) {
         const int q = tid % Q, rs = tid / Q;
         float s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
         if (rs < RS) {
+            const bool first = q < Q1;
             for (int64_t r = r0 + rs; r < r1; r += RS) {
-                const float4 v = reinterpret_cast<const float4*>(xb + r * C)[q];
+                const float4 v = first ? xa[r * Q1 + q] : xc[r * Q2 + (q - Q1)];
                 s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
                 ss[0] += v.x * v.x; ss[1] += v.y * v.y; ss[2] += v.z * v.z; ss[3] += v.w * v.w;
             }
@@ -183,8 +198,9 @@ __global__ void __launch_bounds__(256) k_gn_partial(const float* __restrict__ x,
     } else {
         for (int q = tid; q < Q; q += 256) {
             float s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+            const bool first = q < Q1;
             for (int64_t r = r0; r < r1; ++r) {
-                const float4 v = reinterpret_cast<const float4*>(xb + r * C)[q];
+                const float4 v = first ? xa[r * Q1 + q] : xc[r * Q2 + (q - Q1)];
                 s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
                 ss[0] += v.x * v.x; ss[1] += v.y * v.y; ss[2] += v.z * v.z; ss[3] += v.w * v.w;
             }
@@ -216,22 +232,27 @@ __global__ void __launch_bounds__(64) k_gn_final(const float* __restrict__ ws, f
     }
 }
 extern "C" int64_t edadm_gn_ws_floats(int64_t B, int64_t HW, int64_t C) { return B * GN_CHUNKS(HW) * C * 2; }
-extern "C" int edadm_groupnorm_stats(const float* x, float* stats, float* ws, int64_t B, int64_t HW, int64_t C,
-                                     int64_t G, float eps, void* stream) {
-    if (!x || !stats || !ws || B <= 0 || HW <= 0 || C <= 0 || G <= 0 || (C % G) || (C & 3)) return EDADM_EINVAL;
+extern "C" int edadm_groupnorm_stats_cat(const float* x1, int64_t C1, const float* x2, int64_t C2, float* stats, float* ws,
+                                         int64_t B, int64_t HW, int64_t G, float eps, void* stream) {
+    const int64_t C = C1 + (x2 ? C2 : 0);
+    if (!x1 || !stats || !ws || B <= 0 || HW <= 0 || C1 <= 0 || (x2 && C2 <= 0) || G <= 0 || (C % G) || (C & 3) || (C1 & 3))
+        return EDADM_EINVAL;
     const int nchunk = GN_CHUNKS(HW);
     const int Q = (int)(C >> 2);
     const int RS = Q <= 256 ? 256 / Q : 1;
     const size_t smem = Q <= 256 ? (size_t)RS * C * 2 * sizeof(float) : 0;
-    hipLaunchKernelGGL(k_gn_partial, dim3(nchunk, (unsigned)B), dim3(256), smem, (hipStream_t)stream, x, ws, HW, C,
-                       nchunk);
+    hipLaunchKernelGGL(k_gn_partial, dim3(nchunk, (unsigned)B), dim3(256), smem, (hipStream_t)stream, x1, x2, C1, ws, HW,
+                       C, nchunk);
     hipLaunchKernelGGL(k_gn_final, dim3((unsigned)G, (unsigned)B), dim3(64), 0, (hipStream_t)stream, ws, stats, HW,
                        C, G, nchunk, eps);
     return edadm_launch_status();
 }
-
-// pass 2: y = x*a + b per (batch, channel) [scale-shift] [silu] -> fp32 and/or up to 3 i8 operands
-__global__ void __launch_bounds__(256) k_gn_apply(const float* __restrict__ x, const float* __restrict__ stats,
+extern "C" int edadm_groupnorm_stats(const float* x, float* stats, float* ws, int64_t B, int64_t HW, int64_t C,
+                                     int64_t G, float eps, void* stream) {
+    return edadm_groupnorm_stats_cat(x, C, nullptr, 0, stats, ws, B, HW, G, eps, stream);
+}
+__global__ void __launch_bounds__(256) k_gn_apply(const float* __restrict__ x, const float* __restrict__ x2, int64_t C1,
+                                                  const float* __restrict__ stats,
                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                                   const float* __restrict__ scale_shift, int64_t HW, int64_t C,
                                                   int64_t G, int silu, float* __restrict__ out_f32,
@@ -261,9 +282,12 @@ __global__ void __launch_bounds__(256) k_gn_apply(const float* __restrict__ x, c
             sc[j] = 1.f; sh[j] = 0.f;
             if (scale_shift) { sc[j] = 1.0f + scale_shift[b * 2 * C + c]; sh[j] = scale_shift[b * 2 * C + C + c]; }
         }
+        const int Q1 = (int)(C1 >> 2), Q2 = Q - Q1;
+        const bool first = q < Q1;
         for (int64_t r = r0 + rs; r < r1; r += RS) {
             const int64_t idx = (b * HW + r) * Q + q;
-            float4 v = reinterpret_cast<const float4*>(x)[idx];
+            float4 v = first ? reinterpret_cast<const float4*>(x)[(b * HW + r) * Q1 + q]
+                             : reinterpret_cast<const float4*>(x2)[(b * HW + r) * Q2 + (q - Q1)];
             float y[4] = {v.x * a[0] + bb[0], v.y * a[1] + bb[1], v.z * a[2] + bb[2], v.w * a[3] + bb[3]};
             if (scale_shift) {
 #pragma unroll
@@ -282,19 +306,28 @@ __global__ void __launch_bounds__(256) k_gn_apply(const float* __restrict__ x, c
         if (Q <= 256) break;
     }
 }
-extern "C" int edadm_groupnorm_apply(const float* x, const float* stats, const float* gamma, const float* beta,
-                                     const float* scale_shift, int64_t B, int64_t HW, int64_t C, int64_t G,
-                                     int silu, float* out_f32, int8_t* q0, int8_t* q1, int8_t* q2, const float* qp,
-                                     int nq, void* stream) {
-    if (!x || !stats || !gamma || !beta || B <= 0 || HW <= 0 || C <= 0 || (C & 3) || (C % G)) return EDADM_EINVAL;
+extern "C" int edadm_groupnorm_apply_cat(const float* x1, int64_t C1, const float* x2, int64_t C2, const float* stats,
+                                         const float* gamma, const float* beta, const float* scale_shift, int64_t B,
+                                         int64_t HW, int64_t G, int silu, float* out_f32, int8_t* q0, int8_t* q1,
+                                         int8_t* q2, const float* qp, int nq, void* stream) {
+    const int64_t C = C1 + (x2 ? C2 : 0);
+    if (!x1 || !stats || !gamma || !beta || B <= 0 || HW <= 0 || C1 <= 0 || (x2 && C2 <= 0) || (C & 3) || (C1 & 3) || (C % G))
+        return EDADM_EINVAL;
     if ((q0 || q1 || q2) && !qp) return EDADM_EINVAL;
     // rows per block: a multiple of what keeps (quad) fixed per thread when Q | 256, ~16 KB of input per block
     int rpb = (int)(16384 / C);   // ~64 KB of fp32 input per block
     if (rpb < 1) rpb = 1;
     const unsigned gx = (unsigned)((HW + rpb - 1) / rpb);
-    hipLaunchKernelGGL(k_gn_apply, dim3(gx, (unsigned)B), dim3(256), 0, (hipStream_t)stream, x, stats, gamma, beta,
+    hipLaunchKernelGGL(k_gn_apply, dim3(gx, (unsigned)B), dim3(256), 0, (hipStream_t)stream, x1, x2, C1, stats, gamma, beta,
                        scale_shift, HW, C, G, silu, out_f32, q0, q1, q2, (const QP*)qp, nq, rpb);
     return edadm_launch_status();
+}
+extern "C" int edadm_groupnorm_apply(const float* x, const float* stats, const float* gamma, const float* beta,
+                                     const float* scale_shift, int64_t B, int64_t HW, int64_t C, int64_t G,
+                                     int silu, float* out_f32, int8_t* q0, int8_t* q1, int8_t* q2, const float* qp,
+                                     int nq, void* stream) {
+    return edadm_groupnorm_apply_cat(x, C, nullptr, 0, stats, gamma, beta, scale_shift, B, HW, G, silu, out_f32, q0, q1, q2,
+                                     qp, nq, stream);
 }
 
 // ------------------------------------------------------------------ LayerNorm (+ up to 3 quantised outputs)

@@ -143,7 +143,14 @@ class Engine:
     def L(self, qm):
         return self.layers[id(qm)]
 
+    @staticmethod
+    def _rows(x, C):
+        """[rows][C] view of an NHWC tensor or of an unmaterialised channel concatenation."""
+        return x.rows2d() if isinstance(x, ops.Cat) else x.reshape(-1, C)
+
     def _quant(self, L, x2d):
+        if isinstance(x2d, ops.Cat) and L.mode != "i8":
+            x2d = torch.cat([x2d.a, x2d.b], dim=-1)
         if L.mode == "i8":
             return ops.quant_i8(x2d, L.qp, split=L.split)
         if L.mode == "f16":
@@ -292,9 +299,9 @@ class Engine:
             sc = blk.conv_shortcut if blk.use_conv_shortcut else blk.nin_shortcut
             L = self.L(sc)
             if L.kind == "dense":
-                xs = self.lin(sc, x.reshape(-1, C)).reshape(B, H, W, -1)
+                xs = self.lin(sc, self._rows(x, C)).reshape(B, H, W, -1)
             else:
-                xs = self.conv(sc, self._quant(L, x.reshape(-1, C)).reshape(B, H, W, C), B, H, W)
+                xs = self.conv(sc, self._quant(L, self._rows(x, C)).reshape(B, H, W, C), B, H, W)
         else:
             xs = x
         return self.conv(blk.conv2, a2, B, H, W, residual=xs)
@@ -339,7 +346,7 @@ class Engine:
         for lvl in reversed(range(net.num_resolutions)):
             stage = net.up[lvl]
             for j in range(net.num_res_blocks + 1):
-                h = self.ddpm_resnet(stage.block[j], ops.concat_c(h, hs.pop()), temb)
+                h = self.ddpm_resnet(stage.block[j], ops.Cat(h, hs.pop()), temb)
                 if len(stage.attn) > 0:
                     h = self.ddpm_attn(stage.attn[j], h)
             if lvl != 0:
@@ -380,6 +387,8 @@ class Engine:
         B, H, W, C = x.shape
         e = self.emb_proj(blk.emb_layers[1], emb)                        # [B][Cout or 2 Cout]
         n_in, conv_in = blk.in_layers[0], blk.in_layers[2]
+        if blk.updown and isinstance(x, ops.Cat):
+            x = ops.concat_c(x.a, x.b)
         if blk.updown:
             up = isinstance(blk.h_upd, ldm_unet.Upsample)
             y, _ = self.gn(n_in, x, True, (), want_f32=True)
@@ -404,9 +413,9 @@ class Engine:
         else:
             L = self.L(blk.skip_connection)
             if L.kind == "dense":
-                xs = self.lin(blk.skip_connection, x.reshape(-1, C)).reshape(B, H, W, -1)
+                xs = self.lin(blk.skip_connection, self._rows(x, C)).reshape(B, H, W, -1)
             else:
-                xs = self.conv(blk.skip_connection, self._quant(L, x.reshape(-1, C)).reshape(B, H, W, C), B, H, W)
+                xs = self.conv(blk.skip_connection, self._quant(L, self._rows(x, C)).reshape(B, H, W, C), B, H, W)
         return self.conv(conv_out, a2, B, H, W, residual=xs)
 
     def ldm_cross_attn(self, attn, x2d_q, ctx_ops, B, Nq, Nk, residual):
@@ -512,7 +521,7 @@ class Engine:
             hs.append(h)
         h = self.ldm_seq(net.middle_block, h, emb, ctx)
         for mods in net.output_blocks:
-            h = self.ldm_seq(mods, ops.concat_c(h, hs.pop()), emb, ctx)
+            h = self.ldm_seq(mods, ops.Cat(h, hs.pop()), emb, ctx)
         return self.last_conv(net.out[0], net.out[2], h)
 
     # ------------------------------------------------------------------ entry points

@@ -180,7 +180,29 @@ def ddim_step(x, e_cond, e_uncond, cfg_scale, coef, noise=None, want_x0=False):
 
 
 # ------------------------------------------------------------------------------ operand producers
+class Cat:
+    """Channel concatenation [a | b] of two NHWC tensors that is never materialised: GroupNorm and the activation
+    quantiser read the two halves in place (edadm_*_cat)."""
+
+    def __init__(self, a, b):
+        assert a.shape[:-1] == b.shape[:-1]
+        self.a, self.b = a, b
+        self.shape = tuple(a.shape[:-1]) + (a.shape[-1] + b.shape[-1],)
+        self.device = a.device
+
+    def rows2d(self):
+        return Cat(self.a.reshape(-1, self.a.shape[-1]), self.b.reshape(-1, self.b.shape[-1]))
+
+
 def quant_i8(x2d, qp, split=0, out=None):
+    if isinstance(x2d, Cat):
+        a, b = x2d.a.reshape(-1, x2d.a.shape[-1]), x2d.b.reshape(-1, x2d.b.shape[-1])
+        rows, C = a.shape[0], a.shape[1] + b.shape[1]
+        if out is None:
+            out = torch.empty(rows, C, dtype=torch.int8, device=a.device)
+        lib.call("edadm_quant_i8_cat", _pf(a), a.shape[1], _pf(b), b.shape[1], _p(out, torch.int8), rows, _pf(qp), int(split),
+                 _stream())
+        return out
     rows, C = x2d.shape
     if out is None:
         out = torch.empty(rows, C, dtype=torch.int8, device=x2d.device)
@@ -221,6 +243,15 @@ def im2col_quant_i8(x_nhwc, Kpad, qp):
 
 
 def groupnorm_stats(x_nhwc, G, eps):
+    if isinstance(x_nhwc, Cat):
+        a, b = x_nhwc.a, x_nhwc.b
+        B, C = a.shape[0], x_nhwc.shape[-1]
+        HW = a.numel() // (B * a.shape[-1])
+        stats = torch.empty(B, G, 2, dtype=torch.float32, device=a.device)
+        ws = workspace(a.device, lib.load().edadm_gn_ws_floats(B, HW, C))
+        lib.call("edadm_groupnorm_stats_cat", _pf(a), a.shape[-1], _pf(b), b.shape[-1], _pf(stats), _pf(ws), B, HW, G,
+                 float(eps), _stream())
+        return stats
     B, C = x_nhwc.shape[0], x_nhwc.shape[-1]
     HW = x_nhwc.numel() // (B * C)
     stats = torch.empty(B, G, 2, dtype=torch.float32, device=x_nhwc.device)
@@ -230,6 +261,17 @@ def groupnorm_stats(x_nhwc, G, eps):
 
 
 def groupnorm_apply(x_nhwc, stats, gamma, beta, G, silu, qp=None, nq=0, want_f32=False, scale_shift=None):
+    if isinstance(x_nhwc, Cat):
+        a, b = x_nhwc.a, x_nhwc.b
+        B, C = a.shape[0], x_nhwc.shape[-1]
+        HW = a.numel() // (B * a.shape[-1])
+        out = torch.empty(x_nhwc.shape, dtype=torch.float32, device=a.device) if want_f32 else None
+        qs = [torch.empty(x_nhwc.shape, dtype=torch.int8, device=a.device) for _ in range(nq)]
+        qq = qs + [None] * (3 - nq)
+        lib.call("edadm_groupnorm_apply_cat", _pf(a), a.shape[-1], _pf(b), b.shape[-1], _pf(stats), _pf(gamma), _pf(beta),
+                 _pf(scale_shift), B, HW, G, 1 if silu else 0, _pf(out), _p(qq[0]), _p(qq[1]), _p(qq[2]), _pf(qp), nq,
+                 _stream())
+        return out, qs
     B, C = x_nhwc.shape[0], x_nhwc.shape[-1]
     HW = x_nhwc.numel() // (B * C)
     dev = x_nhwc.device

@@ -112,6 +112,10 @@ int edadm_ddim_step(const float* x, const float* e_cond, const float* e_uncond, 
  * [0,split) use segment 0, [split,C) segment 1 (quant_layer.py:415-419). x is [rows][C]. */
 int edadm_quant_i8(const float* x, int8_t* out, int64_t rows, int64_t C, const float* qp, int64_t split,
                    void* stream);
+/* the same over the channel concatenation [x1 | x2] (C1 and C2 channels; x2 may be NULL): the UNet skip
+ * concatenation (openaimodel.py:778, diffusion.py:320) is consumed in place, never materialised in fp32 */
+int edadm_quant_i8_cat(const float* x1, int64_t C1, const float* x2, int64_t C2, int8_t* out, int64_t rows,
+                       const float* qp, int64_t split, void* stream);
 int edadm_quant_f16(const float* x, int64_t ldx, void* out, int64_t ldo, int64_t rows, int64_t C,
                     const float* qp, float premul, void* stream);
 /* NCHW fp32 -> NHWC (boundary transposes of QuantModel.forward, quant_model.py:69). */
@@ -134,6 +138,13 @@ int edadm_groupnorm_apply(const float* x, const float* stats, const float* gamma
                           const float* scale_shift, int64_t B, int64_t HW, int64_t C, int64_t G, int silu,
                           float* out_f32, int8_t* q0, int8_t* q1, int8_t* q2, const float* qp, int nq,
                           void* stream);
+/* both passes over the channel concatenation [x1 | x2] (x2 may be NULL), C = C1 + C2 */
+int edadm_groupnorm_stats_cat(const float* x1, int64_t C1, const float* x2, int64_t C2, float* stats, float* ws,
+                              int64_t B, int64_t HW, int64_t G, float eps, void* stream);
+int edadm_groupnorm_apply_cat(const float* x1, int64_t C1, const float* x2, int64_t C2, const float* stats,
+                              const float* gamma, const float* beta, const float* scale_shift, int64_t B, int64_t HW,
+                              int64_t G, int silu, float* out_f32, int8_t* q0, int8_t* q1, int8_t* q2,
+                              const float* qp, int nq, void* stream);
 /* LayerNorm over the last dim, same output options (ldm/modules/attention.py:222-242). */
 int edadm_layernorm_quant(const float* x, const float* gamma, const float* beta, int64_t rows, int64_t C,
                           float eps, float* out_f32, int8_t* q0, int8_t* q1, int8_t* q2, const float* qp,

@@ -425,3 +425,23 @@ def test_gemm_f16_heads_and_qgemm_f16(ops):
     got = ops.conv3x3_f32_smalln(x.cuda(), w.cuda(), b.cuda())
     ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), b.double(), padding=1).permute(0, 2, 3, 1)
     close(got, ref, rtol=1e-5, atol=1e-5)
+
+
+def test_cat_consumers_match_materialised_concat(ops):
+    """GroupNorm (stats + apply) and the activation quantiser over an unmaterialised [a | b] channel concatenation
+    give the bits of the same kernels run on the concatenated tensor."""
+    g = torch.Generator().manual_seed(11)
+    for B, H, Ca, Cb, G in ((3, 8, 64, 32, 32), (2, 16, 384, 192, 32), (2, 4, 960, 960, 32)):
+        a = torch.randn(B, H, H, Ca, generator=g).cuda()
+        b = (torch.randn(B, H, H, Cb, generator=g) * 2 + 0.5).cuda()
+        cat = ops.concat_c(a, b)
+        C = Ca + Cb
+        gamma, beta = torch.randn(C, generator=g).cuda(), torch.randn(C, generator=g).cuda()
+        qp = ops.qp_tensor([(0.03, 120.0, 255.0), (0.05, 131.0, 255.0)], "cuda")
+        st0, st1 = ops.groupnorm_stats(cat, G, 1e-5), ops.groupnorm_stats(ops.Cat(a, b), G, 1e-5)
+        exact(st0, st1)
+        o0, q0 = ops.groupnorm_apply(cat, st0, gamma, beta, G, True, qp=qp, nq=2, want_f32=True)
+        o1, q1 = ops.groupnorm_apply(ops.Cat(a, b), st1, gamma, beta, G, True, qp=qp, nq=2, want_f32=True)
+        exact(o0, o1), exact(q0[0], q1[0]), exact(q0[1], q1[1])
+        for split in (0, Ca):
+            exact(ops.quant_i8(cat.reshape(-1, C), qp, split=split), ops.quant_i8(ops.Cat(a, b), qp, split=split))
