@@ -246,7 +246,7 @@ def main():
                        "images_per_step": B, "ddim_steps": 20, "cfg_scale": 3.0, "parallelism": "dp%d (independent batches, no collective)" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": I8_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / I8_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "k_gemm_nt<int8> (edadm_qgemm_i8): %d launches per UNet call, %.1f GFLOP, %.2f ms summed"
+                         "kernel": "int8 GEMM (edadm_qgemm_i8/_q: k_gemm_nt8, k_gemm_p, k_gemm_nt): %d launches per UNet call, %.1f GFLOP, %.2f ms summed"
                                    % (len(i8), gemm_flop / 1e9, gemm_ms),
                          "unet_call_ms": unet_ms,
                          "unet_algorithmic_tflops": 2 * B * UNET_GFLOP_PER_ROW / unet_ms},
