@@ -1161,7 +1161,7 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
     if constexpr (DT == 0) {
         // persistent wave-specialised kernel: full 256-row tiles of the short-K layers (projections, 1x1), where a
         // per-tile launch spends most of its life in prologue latency and epilogue; measured on the LDM-4 layer mix
-        // the long-K convolutions run as fast or faster on k_gemm_nt8 (tools_gemm_table.py)
+        // the long-K convolutions run as fast or faster on k_gemm_nt8 (tools/gemm_table.py)
         const int kstep = force == 6 ? 128 : 64;
         const int64_t ptiles = (M / 256) * (N / (64 * tn));
         if (force != 2 && force != 3 && batch == 1 && inner == 1 && tn >= 2 && M % 256 == 0 && N % (64 * tn) == 0 &&

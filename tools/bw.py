@@ -1,5 +1,5 @@
 import torch, sys, os
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "eda-dm_amd"))
 from edadm import ops
 dev=torch.device("cuda",0)

@@ -1,6 +1,6 @@
 """Diagnostic: a few launches of the dominant conv shape for rocprofv3 --pmc (not part of the product)."""
 import sys, os
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "eda-dm_amd"))
 import torch
 from edadm import ops

@@ -1,6 +1,6 @@
 """Diagnostic: time edadm_qgemm_i8 on the dominant LDM-4 shapes (not part of the product)."""
 import sys, os
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "eda-dm_amd"))
 import torch
 from edadm import ops

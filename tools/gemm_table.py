@@ -1,6 +1,6 @@
 """Diagnostic (not part of the product): per-layer timing table of one eager UNet call."""
 import sys, os
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "eda-dm_amd"))
 import torch, bench
 dev = torch.device("cuda", 0)

@@ -1,6 +1,6 @@
 """Diagnostic: 3 eager UNet calls of the frozen LDM-4 engine (for rocprofv3 --kernel-trace --stats)."""
 import sys, os
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "eda-dm_amd"))
 import torch, bench
 dev = torch.device("cuda", 0)
