@@ -471,6 +471,43 @@ extern "C" int edadm_ddim_step(const float* x, const float* e_cond, const float*
     return edadm_launch_status();
 }
 
+// K9b: PLMS update (ldm/models/diffusion/plms.py:205-279).  e_t = CFG combine (kept for the multistep history),
+// e' by `order`: 0 -> e_t (first half of the pseudo improved Euler step), -1 -> (o1 + e_t) / 2 (its second half: o1 is
+// the first evaluation, e_t the one at x_prev, t_next), 1..3 -> Adams-Bashforth with the 1..3 previous e_t (o1 newest),
+// in the reference's operation order; then pred_x0 and x_prev as in K9 with sigma = 0.
+__global__ void __launch_bounds__(256) k_plms(const float* __restrict__ x, const float* __restrict__ ec,
+                                              const float* __restrict__ eu, float s, const float* __restrict__ o1,
+                                              const float* __restrict__ o2, const float* __restrict__ o3, int order,
+                                              const float* __restrict__ coef, float* __restrict__ e_out,
+                                              float* __restrict__ xp, float* __restrict__ px0, int64_t B, int64_t chw) {
+    const int64_t n = B * chw, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t b = i / chw;
+        const float* c = coef + 5 * b;
+        float e = ec[i];
+        if (eu) { const float u_ = eu[i]; e = u_ + s * (e - u_); }
+        if (e_out) e_out[i] = e;
+        float ep = e;
+        if (order == -1) ep = (o1[i] + e) / 2.0f;
+        else if (order == 1) ep = (3.0f * e - o1[i]) / 2.0f;
+        else if (order == 2) ep = (23.0f * e - 16.0f * o1[i] + 5.0f * o2[i]) / 12.0f;
+        else if (order == 3) ep = (55.0f * e - 59.0f * o1[i] + 37.0f * o2[i] - 9.0f * o3[i]) / 24.0f;
+        const float p0 = (x[i] - c[0] * ep) / c[1];
+        xp[i] = c[2] * p0 + c[3] * ep;
+        if (px0) px0[i] = p0;
+    }
+}
+extern "C" int edadm_plms_step(const float* x, const float* e_cond, const float* e_uncond, float cfg_scale,
+                               const float* old1, const float* old2, const float* old3, int order, const float* coef,
+                               float* e_t, float* x_prev, float* pred_x0, int64_t B, int64_t chw, void* stream) {
+    if (!x || !e_cond || !coef || !x_prev || B <= 0 || chw <= 0 || order < -1 || order > 3) return EDADM_EINVAL;
+    if ((order == -1 || order >= 1) && !old1) return EDADM_EINVAL;
+    if ((order >= 2 && !old2) || (order >= 3 && !old3)) return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_plms, dim3(edadm_grid(B * chw, 256)), dim3(256), 0, (hipStream_t)stream, x, e_cond, e_uncond,
+                       cfg_scale, old1, old2, old3, order, coef, e_t, x_prev, pred_x0, B, chw);
+    return edadm_launch_status();
+}
+
 // ------------------------------------------------------------------------------------------ K3 bookkeeping
 // Candidate grids and the final (delta, zero_point) are O(100 x rows) work, but their float
 // arithmetic decides integer codes, so it runs here with IEEE division in the reference's exact

@@ -694,6 +694,25 @@ extern "C" int edadm_unpack_w4(const uint8_t* packed, const float* zp, int8_t* o
     return edadm_launch_status();
 }
 
+// int8 operand (code - zp_row) -> two 4-bit codes per byte (low nibble = even element): the storage format of
+// calibrated W4 weights (edadm/state.py); the inverse of k_unpack_w4
+__global__ void __launch_bounds__(256) k_pack_w4(const int8_t* __restrict__ w, const float* __restrict__ zp,
+                                                 uint8_t* __restrict__ out, int64_t rows, int64_t cols) {
+    const int64_t nb = (rows * cols) >> 1, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += stride) {
+        const int64_t e0 = 2 * i, e1 = 2 * i + 1;
+        const int c0 = (int)w[e0] + (int)zp[e0 / cols], c1 = (int)w[e1] + (int)zp[e1 / cols];
+        out[i] = (uint8_t)((c0 & 15) | ((c1 & 15) << 4));
+    }
+}
+extern "C" int edadm_pack_w4(const int8_t* w, const float* zp, uint8_t* packed, int64_t rows, int64_t cols,
+                             void* stream) {
+    if (!w || !zp || !packed || rows <= 0 || cols <= 0 || ((rows * cols) & 1)) return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_pack_w4, dim3(edadm_grid(rows * cols / 2, 256)), dim3(256), 0, (hipStream_t)stream, w, zp, packed,
+                       rows, cols);
+    return edadm_launch_status();
+}
+
 // ------------------------------------------------------------------ fp32 im2col / col2im / slab sum (H1 contraction)
 // NHWC x[B][H][W][C] -> cols[m][(ky*KW+kx)*C + c], m = (b, y, x) over the Ho x Wo outputs; zero padding.
 __global__ void __launch_bounds__(256) k_im2col_f32(const float* __restrict__ x, float* __restrict__ cols, int64_t B,

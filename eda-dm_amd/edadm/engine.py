@@ -19,6 +19,7 @@ from the O(B x 192) sinusoidal timestep table.  The whole forward is graph-captu
 """
 import math
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -123,6 +124,80 @@ class Engine:
                     s0["w"], s0["scale"] = s0["w"][order].contiguous(), s0["scale"][order].contiguous()
                     L0.bias = L0.bias[order].contiguous()
                     L0.geglu_interleaved = True
+
+    # ------------------------------------------------------------------ frozen-state export / import
+    def export_frozen(self):
+        """The integer model as a flat name -> numpy dict (edadm/state.py format): per layer the folded bias, the
+        activation quantiser table and, per channel segment, the per-channel scale and the integer weights --
+        4-bit layers as packed nibbles (`w4` + the per-row offset `w4_zp`), others as int8 / f16 / fp32."""
+        out = {}
+        quant_params = set()
+        for name, m in self.net.named_modules():
+            if isinstance(m, QuantModule):
+                quant_params.update(name + "." + n for n, _ in m.named_parameters())
+        for name, prm in self.net.named_parameters():         # what stays floating point: norm affines, embeddings
+            if name not in quant_params:
+                out["params/" + name] = prm.detach().cpu().numpy()
+        for L in self.layers.values():
+            k = L.name
+            out[k + "/mode"] = np.array(L.mode)
+            out[k + "/bias"] = L.bias.detach().cpu().numpy()
+            if L.mode == "f32":
+                out[k + "/w_f32"] = L.w_f32.detach().cpu().numpy()
+                continue
+            out[k + "/qp"] = L.qp.detach().cpu().numpy()
+            out[k + "/geglu_interleaved"] = np.int64(bool(getattr(L, "geglu_interleaved", False)))
+            for i, sg in enumerate(L.segs):
+                p = "%s/seg%d/" % (k, i)
+                out[p + "scale"] = sg["scale"].detach().cpu().numpy()
+                w = sg["w"]
+                lo = w.amin(dim=1).float() if w.dtype == torch.int8 else None
+                if lo is not None and bool(((w.amax(dim=1).float() - lo) <= 15).all()) and w.numel() % 2 == 0:
+                    zp = (-lo).contiguous()                                   # any row offset that maps the row into [0, 15]
+                    out[p + "w4"] = ops.pack_w4(w, zp).cpu().numpy()
+                    out[p + "w4_zp"] = zp.cpu().numpy()
+                    out[p + "shape"] = np.array(w.shape, dtype=np.int64)
+                else:
+                    out[p + "w"] = w.detach().cpu().numpy()
+        return out
+
+    def load_frozen(self, state):
+        """Replace every layer's integer weights / scales / bias / quantiser table by an exported state (same network
+        topology; the floating-point weights the engine was built from no longer matter).  Returns #layers."""
+        n = 0
+        with torch.no_grad():
+            for name, prm in self.net.named_parameters():
+                if "params/" + name in state:
+                    prm.copy_(torch.as_tensor(np.asarray(state["params/" + name]), device=prm.device))
+        for L in self.layers.values():
+            k = L.name
+            if hasattr(L, "w_pad"):
+                del L.w_pad                                   # derived (padded im2col weight of conv_in): rebuilt on use
+            if k + "/mode" not in state:
+                raise KeyError("frozen state has no layer %r" % k)
+            mode = str(np.asarray(state[k + "/mode"]))
+            assert mode == L.mode, (k, mode, L.mode)
+            L.bias = torch.as_tensor(np.asarray(state[k + "/bias"]), device=self.dev).contiguous()
+            n += 1
+            if mode == "f32":
+                L.w_f32 = torch.as_tensor(np.asarray(state[k + "/w_f32"]), device=self.dev).contiguous()
+                continue
+            L.qp = torch.as_tensor(np.asarray(state[k + "/qp"]), device=self.dev).contiguous()
+            L.zx = [int(v) for v in np.asarray(state[k + "/qp"]).reshape(-1, 4)[:, 1]]
+            if int(state[k + "/geglu_interleaved"]):
+                L.geglu_interleaved = True
+            for i, sg in enumerate(L.segs):
+                p = "%s/seg%d/" % (k, i)
+                sg["scale"] = torch.as_tensor(np.asarray(state[p + "scale"]), device=self.dev).contiguous()
+                if p + "w4" in state:
+                    rows, cols = (int(v) for v in np.asarray(state[p + "shape"]))
+                    packed = torch.as_tensor(np.asarray(state[p + "w4"]), device=self.dev)
+                    zp = torch.as_tensor(np.asarray(state[p + "w4_zp"]), device=self.dev).float()
+                    sg["w"] = ops.unpack_w4(packed, zp, rows, cols)
+                else:
+                    sg["w"] = torch.as_tensor(np.asarray(state[p + "w"]), device=self.dev).contiguous()
+        self.graph = None
+        return n
 
     # ------------------------------------------------------------------ primitives
     def _sinusoid(self, t, dim, ddpm):

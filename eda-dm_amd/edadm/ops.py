@@ -179,6 +179,17 @@ def ddim_step(x, e_cond, e_uncond, cfg_scale, coef, noise=None, want_x0=False):
     return (xp, p0) if want_x0 else xp
 
 
+def plms_step(x, e_cond, e_uncond, cfg_scale, olds, order, coef, want_x0=False):
+    """One PLMS update (K9b).  olds: previous e_t tensors, newest first.  Returns (x_prev, e_t[, pred_x0])."""
+    xp, et = torch.empty_like(x), torch.empty_like(x)
+    p0 = torch.empty_like(x) if want_x0 else None
+    o = list(olds) + [None] * (3 - len(olds))
+    B = x.shape[0]
+    lib.call("edadm_plms_step", _pf(x), _pf(e_cond), _pf(e_uncond), float(cfg_scale), _pf(o[0]), _pf(o[1]), _pf(o[2]),
+             int(order), _pf(coef), _pf(et), _pf(xp), _pf(p0), B, x.numel() // B, _stream())
+    return (xp, et, p0) if want_x0 else (xp, et)
+
+
 # ------------------------------------------------------------------------------ operand producers
 class Cat:
     """Channel concatenation [a | b] of two NHWC tensors that is never materialised: GroupNorm and the activation
@@ -441,6 +452,14 @@ def transpose_f16(x, ldx, strideX, batch, n, d, ldo, out=None, strideO=None):
 def unpack_w4(packed, zp, rows, cols):
     out = torch.empty(rows, cols, dtype=torch.int8, device=packed.device)
     lib.call("edadm_unpack_w4", _p(packed, torch.uint8), _pf(zp), _p(out, torch.int8), rows, cols, _stream())
+    return out
+
+
+def pack_w4(w_i8, zp):
+    """int8 operand rows (code - zp[row], codes in [0, 15]) -> packed nibbles [rows*cols/2] (uint8)."""
+    rows, cols = w_i8.shape
+    out = torch.empty(rows * cols // 2, dtype=torch.uint8, device=w_i8.device)
+    lib.call("edadm_pack_w4", _p(w_i8, torch.int8), _pf(zp), _p(out, torch.uint8), rows, cols, _stream())
     return out
 
 

@@ -76,3 +76,47 @@ class DDIMLoop:
             else:
                 img = ops.ddim_step(img.contiguous(), e, None, 1.0, coef)
         return img
+
+
+class PLMSLoop(DDIMLoop):
+    """S-step PLMS (ldm/models/diffusion/plms.py:136-279; eta must be 0) on a frozen QuantModel or any callable
+    `unet(x, t, ctx)`: the first step is the pseudo improved Euler pair of evaluations, later steps the
+    Adams-Bashforth combinations of the last 1..3 guided predictions (K9b, edadm_plms_step)."""
+
+    def __init__(self, engine, shape, batch, steps=50, scale=7.5, linear_start=0.00085, linear_end=0.012, **kw):
+        super().__init__(engine, shape, batch, steps=steps, eta=0.0, scale=scale, linear_start=linear_start,
+                         linear_end=linear_end, **kw)
+
+    def _eps(self, img, step, ctx):
+        B = img.shape[0]
+        ts = torch.full((B * (2 if self.cfg else 1),), int(step), device=img.device, dtype=torch.long)
+        e = self.unet(torch.cat([img, img]) if self.cfg else img, ts, ctx).contiguous()
+        return (e[B:], e[:B]) if self.cfg else (e, None)
+
+    @torch.no_grad()
+    def sample(self, x_T, cond=None, uncond=None, intermediates=None):
+        B = x_T.shape[0]
+        img = x_T.contiguous()
+        ctx = None
+        if cond is not None:
+            ctx = torch.cat([uncond, cond]) if self.cfg else cond
+        time_range = np.flip(self.ddim_timesteps)
+        total = time_range.shape[0]
+        scale = self.scale if self.cfg else 1.0
+        olds = []
+        for i, step in enumerate(time_range):
+            index = total - i - 1
+            coef = self.coef[index:index + 1].expand(B, 5).contiguous()
+            ec, eu = self._eps(img, step, ctx)
+            if not olds:
+                x_tmp, e_t = ops.plms_step(img, ec, eu, scale, [], 0, coef)
+                ec2, eu2 = self._eps(x_tmp, time_range[min(i + 1, total - 1)], ctx)
+                nxt, _, p0 = ops.plms_step(img, ec2, eu2, scale, [e_t], -1, coef, want_x0=True)
+            else:
+                nxt, e_t, p0 = ops.plms_step(img, ec, eu, scale, olds, len(olds), coef, want_x0=True)
+            olds = [e_t] + olds[:2]
+            img = nxt
+            if intermediates is not None:
+                intermediates.setdefault("x_inter", []).append(img)
+                intermediates.setdefault("pred_x0", []).append(p0)
+        return img

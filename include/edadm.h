@@ -105,6 +105,12 @@ int edadm_mix_where(const float* a, const float* b, float* out, int64_t n, const
 int edadm_ddim_step(const float* x, const float* e_cond, const float* e_uncond, float cfg_scale,
                     const float* coef, const float* noise, float* x_prev, float* pred_x0,
                     int64_t B, int64_t chw, void* stream);
+/* K9b: PLMS update (ldm/models/diffusion/plms.py:205-279): CFG combine -> e_t (stored when e_t != NULL, it is
+ * the multistep history), e' by `order` (0: e_t; -1: (old1 + e_t)/2, second half of the first pseudo improved
+ * Euler step; 1..3: Adams-Bashforth over old1 (newest) .. old3), then pred_x0 / x_prev with coef as above. */
+int edadm_plms_step(const float* x, const float* e_cond, const float* e_uncond, float cfg_scale,
+                    const float* old1, const float* old2, const float* old3, int order, const float* coef,
+                    float* e_t, float* x_prev, float* pred_x0, int64_t B, int64_t chw, void* stream);
 
 /* ---- activation quantisation to MFMA operands (inference form of K1) --------------------------
  * code = clamp(rint(x/delta)+zp,0,qmax); i8 operand = code-128; f16 operand = code-zp.
@@ -226,6 +232,7 @@ int edadm_transpose_f16(const void* x, int64_t ldx, int64_t strideX, void* out, 
 /* weight packing: int4 nibble codes <-> int8 operand (code - zp_row) */
 int edadm_unpack_w4(const uint8_t* packed, const float* zp, int8_t* out, int64_t rows, int64_t cols,
                     void* stream);
+int edadm_pack_w4(const int8_t* w, const float* zp, uint8_t* packed, int64_t rows, int64_t cols, void* stream);
 
 #ifdef __cplusplus
 }

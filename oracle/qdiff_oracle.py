@@ -1276,6 +1276,53 @@ def p_sample_ddim(x, e_cond, e_uncond, scale, a_t, a_prev, sigma_t, sqrt_one_min
     return a_prev.sqrt() * pred_x0 + dir_xt + nz, pred_x0
 
 
+def plms_sample(apply_model, x_T, cond, uncond, scale, alphacums, n_steps):
+    """ldm/models/diffusion/plms.py:136-279: full PLMS run (eta 0) with classifier-free guidance.
+    Returns (final x, [x after each step], [pred_x0 of each step])."""
+    ts = make_ddim_timesteps(n_steps, len(alphacums))
+    _, al, alp = make_ddim_sampling_parameters(np.asarray(alphacums, dtype=np.float32), ts, 0.0)
+    al, alp = torch.tensor(al, dtype=torch.float32), torch.tensor(alp, dtype=torch.float32)
+    b = x_T.shape[0]
+
+    def eps(x, t):
+        tt = torch.full((b,), int(t), dtype=torch.long)
+        if uncond is None or scale == 1.0:
+            return apply_model(x, tt, cond)
+        eu, ec = apply_model(torch.cat([x] * 2), torch.cat([tt] * 2), torch.cat([uncond, cond])).chunk(2)
+        return eu + scale * (ec - eu)
+
+    def step(x, e, index):
+        a_t = torch.full((b, 1, 1, 1), float(al[index]))
+        a_prev = torch.full((b, 1, 1, 1), float(alp[index]))
+        s1 = torch.full((b, 1, 1, 1), float(np.sqrt(1.0 - al[index].numpy())))
+        pred_x0 = (x - s1 * e) / a_t.sqrt()
+        return a_prev.sqrt() * pred_x0 + (1.0 - a_prev).sqrt() * e, pred_x0
+
+    time_range = np.flip(ts)
+    total = len(time_range)
+    img, old, xs, x0s = x_T, [], [], []
+    for i, t in enumerate(time_range):
+        index = total - i - 1
+        e_t = eps(img, t)
+        if len(old) == 0:
+            x_prev, _ = step(img, e_t, index)
+            e_next = eps(x_prev, time_range[min(i + 1, total - 1)])
+            e_p = (e_t + e_next) / 2
+        elif len(old) == 1:
+            e_p = (3 * e_t - old[-1]) / 2
+        elif len(old) == 2:
+            e_p = (23 * e_t - 16 * old[-1] + 5 * old[-2]) / 12
+        else:
+            e_p = (55 * e_t - 59 * old[-1] + 37 * old[-2] - 9 * old[-3]) / 24
+        img, p0 = step(img, e_p, index)
+        old.append(e_t)
+        if len(old) >= 4:
+            old.pop(0)
+        xs.append(img)
+        x0s.append(p0)
+    return img, xs, x0s
+
+
 # ======================================================================================
 # TDAC scoring                                           scripts/calibration.py:45-92
 # ======================================================================================

@@ -709,11 +709,44 @@ def g10_steps():
     save("g10_steps", d)
 
 
+def g14_plms():
+    """G14: the PLMS sampler (ldm/models/diffusion/plms.py:136-279): a full 8-step run through the reference's
+    PLMSSampler (pseudo improved Euler first step, then Adams-Bashforth orders 2-4) with classifier-free guidance and
+    a fixed linear stand-in for apply_model; every intermediate x and pred_x0 is kept."""
+    from ldm.models.diffusion.plms import PLMSSampler
+    g = torch.Generator().manual_seed(1414)
+    b = make_beta_schedule("linear", 1000, linear_start=0.00085, linear_end=0.012)
+    ac = np.cumprod(1.0 - b, axis=0)
+    Wm = torch.randn(4, 4, generator=g) * 0.3
+
+    class FakeLD:
+        def __init__(self):
+            self.num_timesteps = 1000
+            self.betas = torch.tensor(b, dtype=torch.float32)
+            self.alphas_cumprod = torch.tensor(ac, dtype=torch.float32)
+            self.alphas_cumprod_prev = torch.tensor(np.append(1.0, ac[:-1]), dtype=torch.float32)
+            self.device = torch.device("cpu")
+
+        def apply_model(self, x_, t_, c_):
+            return torch.einsum("oc,bchw->bohw", Wm, x_) * 0.5 + c_.mean(dim=(1, 2)).view(-1, 1, 1, 1) \
+                + t_.float().view(-1, 1, 1, 1) / 1000.0
+
+    s = PLMSSampler(FakeLD())
+    s.make_schedule(8, ddim_eta=0.0, verbose=False)
+    x = torch.randn(3, 4, 8, 8, generator=g)
+    c, uc = torch.randn(3, 2, 16, generator=g), torch.randn(3, 2, 16, generator=g)
+    img, inter, _ = s.plms_sampling(c, (3, 4, 8, 8), x_T=x.clone(), unconditional_guidance_scale=7.5,
+                                    unconditional_conditioning=uc)
+    d = {"betas": b, "Wm": Wm, "x_T": x, "c": c, "uc": uc, "scale": np.float32(7.5), "ts": s.ddim_timesteps,
+         "final": img, "x_inter": torch.stack(inter["x_inter"]), "pred_x0": torch.stack(inter["pred_x0"])}
+    save("g14_plms", d)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     jobs = dict(g1=g1_weight_init, g2=g2_act_init, g3=g3_uaq_forward, g4=g4_adaround, g5=g5_loss,
                 g6=g6_quant_module, g7=g7_blocks, g8=g8_g12_recon, g9=g9_tdac, g10=g10_steps,
-                g13c=g13_cifar_unet, g13i=lambda: g13_ldm_unet("imagenet"), g13h=lambda: g13_ldm_unet("church"))
+                g13c=g13_cifar_unet, g13i=lambda: g13_ldm_unet("imagenet"), g13h=lambda: g13_ldm_unet("church"), g14=g14_plms)
     for k, fn in jobs.items():
         if not only or k in only:
             print("==", k)

@@ -445,3 +445,20 @@ def test_cat_consumers_match_materialised_concat(ops):
         exact(o0, o1), exact(q0[0], q1[0]), exact(q0[1], q1[1])
         for split in (0, Ca):
             exact(ops.quant_i8(cat.reshape(-1, C), qp, split=split), ops.quant_i8(ops.Cat(a, b), qp, split=split))
+
+
+def test_plms_loop_golden(ops, golden):
+    """K9b + PLMSLoop (edadm/sampling.py) against the reference's PLMSSampler run (G14): every intermediate x and
+    pred_x0 of the 8 steps, classifier-free guidance 7.5; fp32 elementwise chains: 3e-5."""
+    from edadm.sampling import PLMSLoop
+    g = golden("g14_plms")
+    Wm = T(g["Wm"]).float().cuda()
+    unet = lambda x_, t_, c_: torch.einsum("oc,bchw->bohw", Wm, x_) * 0.5 + c_.mean(dim=(1, 2)).view(-1, 1, 1, 1) \
+        + t_.float().view(-1, 1, 1, 1) / 1000.0
+    loop = PLMSLoop(unet, (4, 8, 8), 3, steps=8, scale=float(g["scale"]), use_graph=False)
+    np.testing.assert_array_equal(loop.ddim_timesteps, g["ts"])
+    inter = {}
+    out = loop.sample(D(g["x_T"]), cond=D(g["c"]), uncond=D(g["uc"]), intermediates=inter)
+    close(torch.stack(inter["x_inter"]), g["x_inter"][1:], rtol=3e-5, atol=3e-5)
+    close(torch.stack(inter["pred_x0"]), g["pred_x0"][1:], rtol=3e-5, atol=3e-5)
+    close(out, g["final"], rtol=3e-5, atol=3e-5)

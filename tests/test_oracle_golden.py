@@ -186,3 +186,17 @@ def test_g10_stepping(golden):
     xp, px0 = O.p_sample_ddim(x, app(x, tq, c), app(x, tq, uc), 3.0, v(al), v(alp), v(sig), v(np.sqrt(1 - al)))
     close(xp, g["psq/x_prev"], rtol=2e-5, atol=2e-6)
     close(px0, g["psq/pred_x0"], rtol=2e-5, atol=2e-6)
+
+
+def test_g14_plms(golden):
+    """the oracle's PLMS restatement against a full run of the reference's PLMSSampler (orders 1-4 + the pseudo
+    improved Euler first step, CFG 7.5)"""
+    g = golden("g14_plms")
+    Wm = T(g["Wm"])
+    app = lambda x_, t_, c_: torch.einsum("oc,bchw->bohw", Wm, x_) * 0.5 + c_.mean(dim=(1, 2)).view(-1, 1, 1, 1) \
+        + t_.float().view(-1, 1, 1, 1) / 1000.0
+    ac = np.cumprod(1.0 - g["betas"], axis=0)
+    final, xs, x0s = O.plms_sample(app, T(g["x_T"]), T(g["c"]), T(g["uc"]), float(g["scale"]), ac, 8)
+    close(torch.stack(xs), g["x_inter"][1:], rtol=2e-5, atol=2e-5)
+    close(torch.stack(x0s), g["pred_x0"][1:], rtol=2e-5, atol=2e-5)
+    close(final, g["final"], rtol=2e-5, atol=2e-5)

@@ -108,3 +108,34 @@ def test_ldm_conditional_flow(golden):
     loop = DDIMLoop(qnn.engine, (3, 8, 8), 4, steps=10, scale=3.0, context_shape=(1, 16))
     b = loop.sample(x_T, c, uc)
     assert (a - b).abs().max() < 1e-4 * max(1.0, float(a.abs().max()))
+
+
+def test_frozen_state_round_trip(golden, tmp_path):
+    """calibration and sampling as separate jobs.  The frozen integer model (packed 4-bit weights,
+    scales, folded biases, quantiser tables) written by one process and loaded into an engine built over DIFFERENT
+    floating-point weights gives the bits of the original engine; 4-bit layers cost half a byte per weight."""
+    import numpy as np
+    from helpers import build_ldm, quantize_like_reference
+    from edadm.state import save_frozen, load_frozen
+    g = golden("g13_ldm_imagenet")
+    qnn, (x, t, ctx), _ = quantize_like_reference(build_ldm(g), g, "ldm")
+    qnn.set_quant_state(True, True)
+    with torch.no_grad():
+        want = qnn.freeze()(x, t, ctx)
+        path = str(tmp_path / "frozen.npz")
+        nbytes = save_frozen(qnn, path)
+        st = np.load(path)
+        n4 = sum(st[k].size * 2 for k in st.files if k.endswith("/w4"))
+        nw = n4 + sum(st[k].size for k in st.files if k.endswith("/w") or k.endswith("/w_f32"))
+        assert n4 > 0.9 * nw, "the W4 layers should be stored as nibbles"
+        print("frozen state: %d bytes for %d weights (%.2f B/weight)" % (nbytes, nw, nbytes / nw))
+        # a second model: same topology and quantiser state, other floating-point weights
+        other = build_ldm(g)
+        for p_ in other.parameters():
+            p_.data.add_(0.05 * torch.randn_like(p_))
+        qnn2, _, _ = quantize_like_reference(other, g, "ldm")
+        qnn2.set_quant_state(True, True)
+        eng2 = qnn2.freeze()
+        assert not torch.equal(eng2(x, t, ctx), want)
+        load_frozen(qnn2, path)
+        assert torch.equal(qnn2.engine(x, t, ctx), want)
