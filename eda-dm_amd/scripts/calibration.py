@@ -1,6 +1,7 @@
-"""TDAC calibration-set generators — entry points of the reference's scripts/calibration.py
-(`TDAC_cifar_calib_data_generator` :12, `TDAC_imagenet_calib_data_generator` :371; the bedroom / church /
-coco generators are the same recipe over other samplers and return tuples, :156,263,502)."""
+"""TDAC calibration-set generators — the five entry points of the reference's scripts/calibration.py
+(`TDAC_cifar_calib_data_generator` :12, `TDAC_bedroom_…` :156, `TDAC_church_…` :263, `TDAC_imagenet_…` :371,
+`TDAC_coco_…` :502): one recipe (FP trajectories, features of the middle attention block at every step, density +
+cosine scores -> samples per step, random step assignment) over four samplers; they return tuples."""
 import torch
 
 from ddim.functions.denoising import cali_generalized_steps
@@ -72,3 +73,78 @@ def TDAC_imagenet_calib_data_generator(model, args, calib_num_samples, num_sampl
     calib_data = pick_by_step(all_samples, t)
     calib_t = torch.stack([ts[int(s)][0] for s in t]).to(device)
     return calib_data, calib_t, index, torch.cat(cond), (torch.cat(uncond) if uncond else None)
+
+
+def _tdac_unconditional_ldm(model, args, calib_num_samples, num_samples, device, num_timesteps, fixup_ge):
+    """bedroom / church (:156-262, :263-370): unconditional LDM, DDIMSampler, density radius 0.3."""
+    from ldm.models.diffusion.ddim import DDIMSampler
+    unet = model.model.diffusion_model
+    shape = [unet.in_channels, unet.image_size, unet.image_size]
+    ddim = DDIMSampler(model)
+    hook = AttentionMap(getattr(unet, "model", unet).middle_block[1])
+    samples, feature_map, ts = [], None, None
+    with torch.no_grad():
+        for i in range(int(calib_num_samples / num_samples)):
+            out = ddim.sample(args.custom_steps, batch_size=num_samples, shape=shape, eta=args.eta, verbose=False,
+                              hooks=[hook] if i == 0 else None)
+            if i == 0:
+                feature_map = out[2]
+            samples.append(out[1]['x_inter'][:-1])
+            ts = out[1]['ts']
+    hook.remove()
+    all_samples = [torch.cat([s[k].to(device) for s in samples]) for k in range(num_timesteps)]
+    _, _, _, t_num = tdac_allocate(feature_map, args.lamda, calib_num_samples, 0.3, fixup_ge=fixup_ge)
+    t = shuffled_step_list(t_num, device)
+    index = (num_timesteps - 1) - t
+    calib_data = pick_by_step(all_samples, t)
+    calib_t = torch.stack([ts[int(s)][0] for s in t]).to(device)
+    return calib_data, calib_t, index
+
+
+def TDAC_bedroom_calib_data_generator(model, args, calib_num_samples, num_samples, device, num_timesteps):
+    """-> (calib_x, t, index)  (scripts/calibration.py:156-262)."""
+    return _tdac_unconditional_ldm(model, args, calib_num_samples, num_samples, device, num_timesteps, fixup_ge=False)
+
+
+def TDAC_church_calib_data_generator(model, args, calib_num_samples, num_samples, device, num_timesteps):
+    """-> (calib_x, t, index); differs from bedroom only in the `>= 0` fix-up of the rounding remainder (:332)."""
+    return _tdac_unconditional_ldm(model, args, calib_num_samples, num_samples, device, num_timesteps, fixup_ge=True)
+
+
+def TDAC_coco_calib_data_generator(model, args, calib_num_samples, num_samples, device, num_timesteps):
+    """-> (calib_x, t, index, cond, uncond, t_next) for text-conditional LDM (Stable Diffusion), PLMS or DDIM
+    (scripts/calibration.py:502-638); density radius 0.3."""
+    from ldm.models.diffusion.ddim import DDIMSampler
+    from ldm.models.diffusion.plms import PLMSSampler
+    uc = model.get_learned_conditioning(calib_num_samples * [""]) if args.scale != 1.0 else None
+    c = model.get_learned_conditioning(args.list_prompts[:calib_num_samples])
+    shape = [args.C, args.H // args.f, args.W // args.f]
+    sampler = PLMSSampler(model) if args.plms else DDIMSampler(model)
+    unet = model.model.diffusion_model
+    hook = AttentionMap(getattr(unet, "model", unet).middle_block[1])
+    samples, cond, uncond, feature_map, ts, ts_next = [], [], [], None, None, None
+    with torch.no_grad():
+        for i in range(int(calib_num_samples / num_samples)):
+            sl = slice(i * num_samples, (i + 1) * num_samples)
+            out = sampler.sample(S=args.custom_steps, conditioning=c[sl], batch_size=num_samples, shape=shape,
+                                 verbose=False, unconditional_guidance_scale=args.scale,
+                                 unconditional_conditioning=None if uc is None else uc[sl], eta=args.ddim_eta,
+                                 x_T=None, hooks=[hook] if i == 0 else None)
+            inter = out[1]
+            if i == 0:
+                feature_map = out[2]
+            samples.append(inter['x_inter'][:-1])
+            ts = inter['ts']
+            ts_next = inter.get('ts_next', inter['ts'][1:] + inter['ts'][-1:])
+            cond.append(inter['cond'][0].to(device))
+            if uc is not None:
+                uncond.append(inter['uncond'][0].to(device))
+    hook.remove()
+    all_samples = [torch.cat([s[k].to(device) for s in samples]) for k in range(num_timesteps)]
+    _, _, _, t_num = tdac_allocate(feature_map, args.lamda, calib_num_samples, 0.3)
+    t = shuffled_step_list(t_num, device)
+    index = (num_timesteps - 1) - t
+    calib_data = pick_by_step(all_samples, t)
+    calib_t = torch.stack([ts[int(s)][0] for s in t]).to(device)
+    calib_t_next = torch.stack([ts_next[int(s)][0] for s in t]).to(device)
+    return calib_data, calib_t, index, torch.cat(cond), (torch.cat(uncond) if uncond else None), calib_t_next

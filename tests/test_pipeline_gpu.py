@@ -139,3 +139,88 @@ def test_frozen_state_round_trip(golden, tmp_path):
         assert not torch.equal(eng2(x, t, ctx), want)
         load_frozen(qnn2, path)
         assert torch.equal(qnn2.engine(x, t, ctx), want)
+
+
+def test_plms_sampler_class_golden(golden):
+    """ldm.models.diffusion.plms.PLMSSampler (reference interface) reproduces the reference's own 8-step PLMS run
+    (G14): all x_inter / pred_x0, ts / ts_next bookkeeping, and the quant_unet branch returns the guided prediction."""
+    from ldm.models.diffusion.plms import PLMSSampler
+    g = golden("g14_plms")
+    dev = torch.device("cuda")
+    Wm = torch.tensor(g["Wm"]).float().to(dev)
+    ac = np.cumprod(1.0 - g["betas"], axis=0)
+
+    class FakeLD:
+        num_timesteps = 1000
+        betas = torch.tensor(g["betas"], dtype=torch.float32, device=dev)
+        alphas_cumprod = torch.tensor(ac, dtype=torch.float32, device=dev)
+        alphas_cumprod_prev = torch.tensor(np.append(1.0, ac[:-1]), dtype=torch.float32, device=dev)
+        device = dev
+
+        def apply_model(self, x_, t_, c_):
+            return torch.einsum("oc,bchw->bohw", Wm, x_) * 0.5 + c_.mean(dim=(1, 2)).view(-1, 1, 1, 1) \
+                + t_.float().view(-1, 1, 1, 1) / 1000.0
+
+    s = PLMSSampler(FakeLD())
+    x, c, uc = (torch.tensor(g[k]).float().to(dev) for k in ("x_T", "c", "uc"))
+    out, inter = s.sample(S=8, batch_size=3, shape=(4, 8, 8), conditioning=c, x_T=x.clone(), verbose=False,
+                          unconditional_guidance_scale=float(g["scale"]), unconditional_conditioning=uc)
+    tol = dict(rtol=3e-5, atol=3e-5)
+    np.testing.assert_allclose(torch.stack(inter["x_inter"]).cpu().numpy(), g["x_inter"], **tol)
+    np.testing.assert_allclose(torch.stack(inter["pred_x0"][1:]).cpu().numpy(), g["pred_x0"][1:], **tol)
+    np.testing.assert_allclose(out.cpu().numpy(), g["final"], **tol)
+    assert [int(t[0]) for t in inter["ts"]] == list(np.flip(g["ts"]))
+    assert [int(t[0]) for t in inter["ts_next"]] == list(np.flip(g["ts"]))[1:] + [int(g["ts"][0])]
+    assert [len(o) for o in inter["old_eps"]] == [0, 1, 2, 3, 3, 3, 3, 3]
+    t = torch.full((3,), int(g["ts"][3]), device=dev)
+    e = s.sample(S=8, batch_size=3, shape=(4, 8, 8), quant_unet=True, cali_data=(x, t, None, c, uc),
+                 unconditional_guidance_scale=float(g["scale"]))
+    fl = FakeLD()
+    want = fl.apply_model(x, t, uc) + float(g["scale"]) * (fl.apply_model(x, t, c) - fl.apply_model(x, t, uc))
+    np.testing.assert_allclose(e.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("which", ["bedroom", "church", "coco_plms", "coco_ddim"])
+def test_tdac_generators_ldm(golden, which):
+    """the remaining TDAC generators (scripts/calibration.py:156,263,502) on a fixture-sized LDM:
+    tuple layout and shapes, finite samples, `t` is the DDIM timestep of `index` for every row, `t_next` (coco) the
+    following one, conditioning / unconditional embeddings carried through (the allocation itself is pinned by G9)."""
+    from edadm.latent import LatentDiffusionLite
+    from qdiff.utils import seed_everything
+    import scripts.calibration as cal
+    g = golden("g13_ldm_%s" % ("church" if which in ("bedroom", "church") else "imagenet"))
+    unet = build_ldm(g)
+    coco = which.startswith("coco")
+
+    class Prompts(torch.nn.Module):                     # stand-in text encoder: prompt -> [1, 16] embedding
+        def forward(self, prompts):
+            return torch.stack([torch.full((1, 16), float(len(p) % 7) * 0.1) for p in prompts]).cuda()
+
+    ld = LatentDiffusionLite(unet, linear_start=0.0015, linear_end=0.0155,
+                             conditioning_key="crossattn" if coco else None,
+                             cond_stage_model=Prompts() if coco else None).cuda().eval()
+    if coco:
+        ld.get_learned_conditioning = lambda prompts: Prompts()(prompts)
+    C, S = unet.in_channels, 10
+    unet.image_size = 8
+    N, nb = 32, 16
+    if coco:
+        args = SimpleNamespace(scale=7.5, custom_steps=S, ddim_eta=0.0, lamda=1.2, C=C, H=64, W=64, f=8, plms=(which == "coco_plms"),
+                               list_prompts=["a photo %d" % (i * i) for i in range(N)])
+        fn = cal.TDAC_coco_calib_data_generator
+    else:
+        args = SimpleNamespace(custom_steps=S, eta=0.0, lamda=1.2)
+        fn = cal.TDAC_bedroom_calib_data_generator if which == "bedroom" else cal.TDAC_church_calib_data_generator
+    seed_everything(7)
+    out = fn(ld, args, N, nb, torch.device("cuda"), S)
+    assert len(out) == (6 if coco else 3)
+    x, t, index = out[0], out[1], out[2]
+    assert x.shape == (N, C, 8, 8) and t.shape == (N,) and index.shape == (N,)
+    assert torch.isfinite(x).all() and int(index.min()) >= 0 and int(index.max()) <= S - 1
+    from edadm.schedule import make_ddim_timesteps
+    steps = make_ddim_timesteps("uniform", S, 1000, verbose=False)
+    assert all(int(tt) == int(steps[int(i)]) for tt, i in zip(t, index))          # t is the timestep of ddim index
+    if coco:
+        assert out[3].shape == (N, 1, 16) and out[4].shape == (N, 1, 16) and out[5].shape == (N,)
+        nxt = [int(steps[max(int(i) - 1, 0)]) for i in index]
+        assert [int(v) for v in out[5]] == nxt
