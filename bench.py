@@ -72,6 +72,31 @@ def build_quantised_unet(device, calib_rows=16, seed=1234):
     return qnn, sd_cpu, dict(weight_init_s=t1 - t0, act_init_s=t2 - t1, calib_rows=calib_rows)
 
 
+VQF4 = dict(ch=128, out_ch=3, ch_mult=(1, 2, 4), num_res_blocks=2, attn_resolutions=[], dropout=0.0, in_channels=3,
+            resolution=256, z_channels=3)        # models/first_stage_models/vq-f4/config.yaml (embed_dim 3, 8192 codes)
+
+
+def time_decoder(dev, B):
+    """SURVEY 8(f)-3, reported next to the headline (never part of `value`): the VQ-f4 first-stage decoder
+    (55.3 M parameters, 318 GMAC per image, fp32) on the HIP fp32 kernels, B latents -> B images of 256x256."""
+    from edadm.nets.vq_decoder import Decoder
+    from edadm.decoder import DecoderEngine
+    torch.manual_seed(4321)
+    dec = Decoder(**VQF4).to(dev).eval()
+    pq = torch.nn.Conv2d(3, 3, 1).to(dev)
+    eng = DecoderEngine(dec, pq, codebook=torch.randn(8192, 3, device=dev))
+    z = torch.randn(B, 3, 64, 64, device=dev)
+    eng(z[:2])
+    torch.cuda.synchronize()
+    t0 = time.time()
+    img = eng(z)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    assert img.shape == (B, 3, 256, 256) and bool(torch.isfinite(img).all())
+    return {"images": B, "wall_s": dt, "ms_per_image": 1e3 * dt / B, "tflops_fp32": B * 2 * 318.1e9 / dt / 1e12,
+            "config": "VQ-f4 decoder, fp32 MFMA (v_mfma_f32_32x32x2_f32), random-init weights"}
+
+
 def time_calibration(qnn, dev, n_calib=64, iters=2):
     """Bounded run of the calibration hot loop (H1) on the same full-size UNet: the conditional
     reconstruction walk (qdiff_control.recon_block_Qmodel, every unit of the model) with `n_calib`
@@ -153,6 +178,7 @@ def main():
     ap.add_argument("--batch", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-calib", action="store_true", help="skip the bounded reconstruction timing")
+    ap.add_argument("--no-decode", action="store_true", help="skip the first-stage decoder timing")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -257,6 +283,13 @@ def main():
                 line["calibration"]["reconstruction"] = time_calibration(qnn, dev)
             except Exception as e:
                 line["calibration"]["reconstruction"] = {"error": repr(e)}
+        if world == 1 and not args.no_decode:
+            try:
+                d = time_decoder(dev, B)
+                d["images_per_sec_unet_plus_decode"] = 1.0 / (elapsed / (B * args.steps) + d["wall_s"] / B)
+                line["first_stage_decode"] = d
+            except Exception as e:
+                line["first_stage_decode"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(qnn, sd_cpu)

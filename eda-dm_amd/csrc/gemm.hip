@@ -1353,4 +1353,21 @@ extern "C" int edadm_gemm_f32_nt(const float* A, int64_t lda, int64_t strideA, c
     return launch_gemm<2>(A, lda * 4, strideA * 4, Bm, ldb * 4, strideB * 4, M, N, K * 4, g, nullptr, bias, nullptr, 1,
                           residual, ldr, C, ldc, strideC, batch, alpha, (hipStream_t)stream);
 }
+
+// fp32 convolution as an implicit GEMM over an NHWC input (the first-stage decoder; also the forward
+// of the calibration graph): the K4 gather with byte geometry (a pixel is 4 C bytes), exact-fp32 MFMA, zero padding,
+// optional nearest-2x upsample folded into the gather, bias and residual in the epilogue.
+extern "C" int edadm_conv2d_f32_nhwc(const float* x, const float* w, const float* bias, const float* residual,
+                                     float* out, int64_t B, int64_t H, int64_t W, int64_t C, int64_t Ho, int64_t Wo,
+                                     int64_t N, int KH, int KW, int stride, int pad, int ups, void* stream) {
+    if (!x || !w || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || Ho <= 0 || Wo <= 0 || N <= 0 || KH < 1 ||
+        KW < 1 || stride < 1 || pad < 0)
+        return EDADM_EINVAL;
+    if (((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return EDADM_EINVAL;
+    if (B * H * W * C * 4 >= (1ll << 31)) return EDADM_EINVAL;          // 32-bit byte offsets in the gather
+    const int64_t M = B * Ho * Wo, K = (int64_t)KH * KW * C;
+    ConvGeom g{1, (int)B, (int)H, (int)W, (int)(C * 4), (int)Ho, (int)Wo, KH, KW, stride, pad, ups ? 1 : 0, 0, 0, 0, 0};
+    return launch_gemm<2>(x, 0, 0, w, K * 4, 0, M, N, K * 4, g, nullptr, bias, nullptr, 1, residual, N, out, N, 0, 1, 1.0f,
+                          (hipStream_t)stream);
+}
 #endif

@@ -648,6 +648,52 @@ extern "C" int edadm_softmax_quant_f16(const float* s, void* out, int64_t rows, 
     return edadm_launch_status();
 }
 
+// plain fp32 row softmax (the first-stage decoder's attention block, model.py:193-195): register-resident row
+__global__ void __launch_bounds__(256) k_softmax_f32(const float* __restrict__ s, float* __restrict__ out, int64_t rows,
+                                                     int64_t cols) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int Q = (int)(cols >> 2);
+    const float4* sr = reinterpret_cast<const float4*>(s + row * cols);
+    float4 v[SM_MAXV4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < SM_MAXV4; ++j) {
+        const int c = j * 64 + lane;
+        if (c < Q) {
+            v[j] = sr[c];
+            mx = fmaxf(mx, fmaxf(fmaxf(v[j].x, v[j].y), fmaxf(v[j].z, v[j].w)));
+        }
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < SM_MAXV4; ++j) {
+        const int c = j * 64 + lane;
+        if (c < Q) {
+            v[j].x = expf(v[j].x - mx); v[j].y = expf(v[j].y - mx); v[j].z = expf(v[j].z - mx); v[j].w = expf(v[j].w - mx);
+            sum += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+        }
+    }
+    sum = wave_sum(sum);
+#pragma unroll
+    for (int j = 0; j < SM_MAXV4; ++j) {
+        const int c = j * 64 + lane;
+        if (c < Q) {
+            float4 o;
+            o.x = v[j].x / sum; o.y = v[j].y / sum; o.z = v[j].z / sum; o.w = v[j].w / sum;
+            reinterpret_cast<float4*>(out + row * cols)[c] = o;
+        }
+    }
+}
+extern "C" int edadm_softmax_f32(const float* s, float* out, int64_t rows, int64_t cols, void* stream) {
+    if (!s || !out || rows <= 0 || cols <= 0 || (cols & 3) || cols > 256 * SM_MAXV4 || ((uintptr_t)s & 15) || ((uintptr_t)out & 15))
+        return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_softmax_f32, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, s, out, rows, cols);
+    return edadm_launch_status();
+}
+
 // f16 [b][n][d] -> [b][d][n]  (B operand of the PV product); pads n up to ldo with zeros
 __global__ void __launch_bounds__(256) k_transpose_f16(const __half* __restrict__ x, int64_t ldx, int64_t strideX,
                                                        __half* __restrict__ out, int64_t ldo, int64_t strideO,

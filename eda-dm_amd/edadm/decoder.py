@@ -1,0 +1,107 @@
+"""First-stage decoder on the HIP kernels: the graph of ldm/modules/diffusionmodules/model.py:465-572
+(+ the 1x1 `post_quant_conv` of VQModelInterface.decode, ldm/models/autoencoder.py:274-282) executed in NHWC fp32:
+
+    3x3 / 1x1 convolutions .... edadm_conv2d_f32_nhwc (implicit GEMM, exact-fp32 MFMA; bias, residual and the
+                                 nearest-2x upsample of `Upsample` folded into the same launch)
+    GroupNorm (+ swish) ....... edadm_groupnorm_stats / _apply  (K5)
+    attention block ........... edadm_gemm_f32_nt (q k^T, p v) + edadm_softmax_f32
+    layout .................... NCHW <-> NHWC once at the boundary
+
+The vector-quantisation lookup of VQModelInterface.decode (taming's VectorQuantizer2, not vendored by the
+reference: parity unpinned) is `nearest_code`, a plain argmin over the codebook."""
+import torch
+
+from . import ops
+
+
+def _w(conv):
+    """Conv2d weight [N][C][KH][KW] -> [N][KH][KW][C4] (input channels zero-padded to a multiple of 4)."""
+    w = conv.weight.detach().float().permute(0, 2, 3, 1)
+    pad = (-w.shape[-1]) % 4
+    if pad:
+        w = torch.nn.functional.pad(w, (0, pad))
+    return w.contiguous()
+
+
+class DecoderEngine:
+    def __init__(self, decoder, post_quant_conv=None, codebook=None, chunk_pixels=1 << 20):
+        self.dec, self.pq = decoder, post_quant_conv
+        self.codebook = None if codebook is None else codebook.detach().float().contiguous()
+        self.chunk_pixels = chunk_pixels            # output pixels per batch chunk: keeps every activation under the gather's 2 GiB (32-bit byte offsets) and bounds the attention scores
+        self._wc = {}
+
+    def w(self, conv):
+        if id(conv) not in self._wc:
+            self._wc[id(conv)] = (_w(conv), None if conv.bias is None else conv.bias.detach().float().contiguous())
+        return self._wc[id(conv)]
+
+    def conv(self, conv, x, residual=None, ups=False):
+        w, b = self.w(conv)
+        if x.shape[-1] != w.shape[-1]:                          # latent channels (3) -> 4
+            x = torch.nn.functional.pad(x, (0, w.shape[-1] - x.shape[-1])).contiguous()
+        return ops.conv2d_f32_nhwc(x, w, b, residual=residual, stride=1, pad=conv.padding[0], ups=ups)
+
+    def gn(self, norm, x, silu):
+        st = ops.groupnorm_stats(x, norm.num_groups, norm.eps)
+        y, _ = ops.groupnorm_apply(x, st, norm.weight, norm.bias, norm.num_groups, silu, want_f32=True)
+        return y
+
+    def res(self, blk, x):
+        h = self.conv(blk.conv1, self.gn(blk.norm1, x, True))
+        a = self.gn(blk.norm2, h, True)
+        if blk.in_channels != blk.out_channels:
+            x = self.conv(blk.conv_shortcut if blk.use_conv_shortcut else blk.nin_shortcut, x)
+        return self.conv(blk.conv2, a, residual=x)
+
+    def attn(self, blk, x):
+        B, H, W, C = x.shape
+        N = H * W
+        h = self.gn(blk.norm, x, False)
+        q, k, v = (self.conv(m, h).reshape(B, N, C) for m in (blk.q, blk.k, blk.v))
+        s = ops.gemm_f32_nt(q, k, N, N, C, alpha=int(C) ** (-0.5), batch=B, strideA=N * C, strideB=N * C, strideC=N * N)
+        p = ops.softmax_f32(s.reshape(B * N, N)).reshape(B, N, N)
+        vt = ops.nhwc_to_nchw(v.reshape(B, N, 1, C)).reshape(B, C, N)                  # [B][C][N]: B operand of p . v
+        o = ops.gemm_f32_nt(p, vt, N, C, N, batch=B, strideA=N * N, strideB=C * N, strideC=N * C)
+        return self.conv(blk.proj_out, o.reshape(B, H, W, C), residual=x)
+
+    def nearest_code(self, z_nhwc):
+        """z -> codebook[argmin ||z - e||^2] (the VectorQuantizer2 lookup); identity when no codebook is attached."""
+        if self.codebook is None:
+            return z_nhwc
+        flat = z_nhwc.reshape(-1, z_nhwc.shape[-1])
+        d = (flat * flat).sum(1, keepdim=True) - 2 * flat @ self.codebook.t() + (self.codebook * self.codebook).sum(1)[None]
+        return self.codebook[d.argmin(1)].reshape(z_nhwc.shape)
+
+    @torch.no_grad()
+    def decode_nhwc(self, z):
+        d = self.dec
+        h = self.nearest_code(z)
+        if self.pq is not None:
+            h = self.conv(self.pq, h)
+        h = self.conv(d.conv_in, h)
+        h = self.res(d.mid.block_2, self.attn(d.mid.attn_1, self.res(d.mid.block_1, h)))
+        for i_level in reversed(range(d.num_resolutions)):
+            up = d.up[i_level]
+            for i_block in range(d.num_res_blocks + 1):
+                h = self.res(up.block[i_block], h)
+                if len(up.attn) > 0:
+                    h = self.attn(up.attn[i_block], h)
+            if i_level != 0:
+                h = self.conv(up.upsample.conv, h, ups=True) if up.upsample.with_conv else ops.upsample2_nhwc(h)
+        if d.give_pre_end:
+            return h
+        h = self.conv(d.conv_out, self.gn(d.norm_out, h, True))
+        return torch.tanh(h) if d.tanh_out else h
+
+    @torch.no_grad()
+    def __call__(self, z_nchw):
+        """z [B][zc][h][w] -> image [B][out_ch][H][W], decoded in batch chunks."""
+        B = z_nchw.shape[0]
+        up = 2 ** (self.dec.num_resolutions - 1)
+        per = z_nchw.shape[2] * z_nchw.shape[3] * up * up
+        nb = max(1, min(B, self.chunk_pixels // per))
+        outs = []
+        for b0 in range(0, B, nb):
+            zc = ops.nchw_to_nhwc(z_nchw[b0:b0 + nb].contiguous().float())
+            outs.append(ops.nhwc_to_nchw(self.decode_nhwc(zc)))
+        return torch.cat(outs)

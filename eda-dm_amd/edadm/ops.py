@@ -507,3 +507,22 @@ def sum_slabs(slabs):
     out = torch.empty(slabs.shape[1:], dtype=torch.float32, device=slabs.device)
     lib.call("edadm_sum_slabs", _pf(slabs), _pf(out), n, S, _stream())
     return out
+
+
+def conv2d_f32_nhwc(x, w, bias=None, residual=None, stride=1, pad=1, ups=False):
+    """x [B,H,W,C] fp32, w [N,KH,KW,C] -> [B,Ho,Wo,N] (implicit GEMM on the fp32 MFMA; `ups`: conv of the nearest-2x
+    upsampled input without materialising it)."""
+    B, H, W, C = x.shape
+    N, KH, KW, _ = w.shape
+    Hl, Wl = (2 * H, 2 * W) if ups else (H, W)
+    Ho, Wo = (Hl + 2 * pad - KH) // stride + 1, (Wl + 2 * pad - KW) // stride + 1
+    out = torch.empty(B, Ho, Wo, N, dtype=torch.float32, device=x.device)
+    lib.call("edadm_conv2d_f32_nhwc", _pf(x), _pf(w), _pf(bias), _pf(residual), _pf(out), B, H, W, C, Ho, Wo, N, int(KH), int(KW),
+             int(stride), int(pad), 1 if ups else 0, _stream())
+    return out
+
+
+def softmax_f32(s2d):
+    out = torch.empty_like(s2d)
+    lib.call("edadm_softmax_f32", _pf(s2d), _pf(out), s2d.shape[0], s2d.shape[1], _stream())
+    return out

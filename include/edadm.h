@@ -230,6 +230,14 @@ int edadm_softmax_quant_f16(const float* s, void* out, int64_t rows, int64_t col
 int edadm_transpose_f16(const void* x, int64_t ldx, int64_t strideX, void* out, int64_t ldo,
                         int64_t strideO, int64_t batch, int64_t n, int64_t d, void* stream);
 /* weight packing: int4 nibble codes <-> int8 operand (code - zp_row) */
+/* ---- fp32 NHWC graph pieces of the first-stage decoder (ldm/modules/diffusionmodules/model.py:35-205,465-572) ----
+ * convolution as an implicit GEMM on the exact-fp32 MFMA: x [B][H][W][C] (C % 4 == 0), w [N][KH][KW][C], zero padding,
+ * optional nearest-2x upsample of x folded into the gather (Upsample, model.py:43-60), out [B][Ho][Wo][N]
+ * (+bias[n]) (+residual[m][n]); plain row softmax of the attention block (model.py:193-195). */
+int edadm_conv2d_f32_nhwc(const float* x, const float* w, const float* bias, const float* residual, float* out,
+                          int64_t B, int64_t H, int64_t W, int64_t C, int64_t Ho, int64_t Wo, int64_t N, int KH, int KW,
+                          int stride, int pad, int ups, void* stream);
+int edadm_softmax_f32(const float* s, float* out, int64_t rows, int64_t cols, void* stream);
 int edadm_unpack_w4(const uint8_t* packed, const float* zp, int8_t* out, int64_t rows, int64_t cols,
                     void* stream);
 int edadm_pack_w4(const int8_t* w, const float* zp, uint8_t* packed, int64_t rows, int64_t cols, void* stream);

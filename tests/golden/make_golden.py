@@ -742,11 +742,38 @@ def g14_plms():
     save("g14_plms", d)
 
 
+def g15_decoder():
+    """G15: the first-stage decoder (ldm/modules/diffusionmodules/model.py:465-572 Decoder with its ResnetBlock /
+    AttnBlock / Upsample, plus the 1x1 post_quant_conv of VQModelInterface.decode, autoencoder.py:274-282) on a
+    fixture-sized config: state dict, latent input, image output, and the output of the middle stage."""
+    from ldm.modules.diffusionmodules.model import Decoder
+    torch.manual_seed(1515)
+    cfg = dict(ch=32, out_ch=3, ch_mult=(1, 2, 2), num_res_blocks=1, attn_resolutions=[], dropout=0.0, in_channels=3,
+               resolution=32, z_channels=3)
+    dec = Decoder(**cfg).eval()
+    pq = torch.nn.Conv2d(3, 3, 1)
+    g = torch.Generator().manual_seed(15)
+    with torch.no_grad():
+        for prm in list(dec.parameters()) + list(pq.parameters()):
+            prm.copy_(prm + 0.05 * torch.randn(prm.shape, generator=g))
+        z = torch.randn(2, 3, 8, 8, generator=g)
+        out = dec(pq(z))
+        dec.give_pre_end = True
+        pre = dec(pq(z))
+    d = {"z": z, "out": out, "pre_end": pre}
+    for k, v in cfg.items():
+        d["cfg/" + k] = np.asarray(v)
+    for k, v in dec.state_dict().items():
+        d["sd/" + k] = v
+    d["pq/weight"], d["pq/bias"] = pq.weight.detach(), pq.bias.detach()
+    save("g15_decoder", d)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     jobs = dict(g1=g1_weight_init, g2=g2_act_init, g3=g3_uaq_forward, g4=g4_adaround, g5=g5_loss,
                 g6=g6_quant_module, g7=g7_blocks, g8=g8_g12_recon, g9=g9_tdac, g10=g10_steps,
-                g13c=g13_cifar_unet, g13i=lambda: g13_ldm_unet("imagenet"), g13h=lambda: g13_ldm_unet("church"), g14=g14_plms)
+                g13c=g13_cifar_unet, g13i=lambda: g13_ldm_unet("imagenet"), g13h=lambda: g13_ldm_unet("church"), g14=g14_plms, g15=g15_decoder)
     for k, fn in jobs.items():
         if not only or k in only:
             print("==", k)
