@@ -218,6 +218,20 @@ __device__ __forceinline__ void gemm_epilogue(typename Acc<DT>::type (&acc)[TM][
 // segments, and the address is a wave-uniform row pointer (SGPR pair, bumped on the scalar unit) + one fixed
 // 32-bit lane offset.  Residual loads use the same layout and run DEPTH row-groups ahead of the stores, so the
 // in-order vmcnt never makes a load wait behind a store issued before it.
+// The fp32 output and residual streams are touched once per launch: with the default policy they evict the operand
+// rows that the 3x3 gather re-reads nine times through the 4 MiB L2 of an XCD.  EDADM_EPI_NT=1 marks them
+// non-temporal (streaming).
+#ifndef EDADM_EPI_NT
+#define EDADM_EPI_NT 1
+#endif
+#if EDADM_EPI_NT
+#define EDADM_NT_LOAD(p) __builtin_nontemporal_load(p)
+#define EDADM_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
+#else
+#define EDADM_NT_LOAD(p) (*(p))
+#define EDADM_NT_STORE(v, p) (*(p) = (v))
+#endif
+
 template <int TN>
 struct EpiRegs {
     float s[TN], b[TN], ra0[TN], ra1[TN];
@@ -268,7 +282,7 @@ __device__ __forceinline__ void epilogue_direct_body(typename Acc<DT>::type (&ac
         for (int e = 0; e < 4; ++e) {
             const char* rp = resb + uniform_i64(rbase + (int64_t)(i * 32 + 8 * g + e) * ldr * 4);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) rr[gi][e][j] = *reinterpret_cast<const float*>(rp + roff + j * 128);
+            for (int j = 0; j < TN; ++j) rr[gi][e][j] = EDADM_NT_LOAD(reinterpret_cast<const float*>(rp + roff + j * 128));
         }
     };
     if constexpr (HAS_RES) {
@@ -294,7 +308,7 @@ __device__ __forceinline__ void epilogue_direct_body(typename Acc<DT>::type (&ac
                 float v = (float)a * er.s[j] + er.b[j];
                 if constexpr (HAS_RA) v += late ? er.ra1[j] : er.ra0[j];
                 if constexpr (HAS_RES) v += rr[gi][e][j];
-                *reinterpret_cast<float*>(op + ooff + j * 128) = v;
+                EDADM_NT_STORE(v, reinterpret_cast<float*>(op + ooff + j * 128));
             }
         }
         asm volatile("" ::: "memory");

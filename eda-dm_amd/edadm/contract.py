@@ -113,16 +113,22 @@ class _Conv2dFn(torch.autograd.Function):
         else:
             Cp, wsrc = C, weight
         one = KH == 1 and KW == 1 and stride == 1 and pad == 0
-        cols = xh.reshape(B * H * W, Cp) if one else ops.im2col_f32(xh, KH, KW, stride, pad, Ho, Wo)
-        w2 = wsrc.permute(0, 2, 3, 1).reshape(O, KH * KW * Cp).contiguous()
-        out = _matmul_nt(cols, w2, bias)                                            # [M][O] (NHWC rows)
-        ctx.save_for_backward(cols, w2)
+        w4 = wsrc.permute(0, 2, 3, 1).contiguous()                                  # [O][KH][KW][Cp]
+        # forward as an implicit GEMM (edadm_conv2d_f32_nhwc): no im2col matrix, the gather re-reads x through L2;
+        # the im2col matrix is only rebuilt in backward, for the weight gradient
+        M = B * Ho * Wo
+        if ((M + 127) // 128) * ((O + 127) // 128) >= 128:
+            out = ops.conv2d_f32_nhwc(xh, w4, bias, stride=stride, pad=pad)         # [B][Ho][Wo][O]
+        else:                                                # few tiles (8x8 / 16x16 levels): im2col + split-K GEMM
+            cols = xh.reshape(M, Cp) if one else ops.im2col_f32(xh, KH, KW, stride, pad, Ho, Wo)
+            out = _matmul_nt(cols, w4.reshape(O, KH * KW * Cp), bias).reshape(B, Ho, Wo, O)
+        ctx.save_for_backward(xh, w4.reshape(O, KH * KW * Cp))
         ctx.meta = (B, C, Cp, H, W, O, KH, KW, stride, pad, Ho, Wo, one, bias is not None)
-        return ops.nhwc_to_nchw(out.reshape(B, Ho, Wo, O))
+        return ops.nhwc_to_nchw(out)
 
     @staticmethod
     def backward(ctx, gy):
-        cols, w2 = ctx.saved_tensors
+        xh, w2 = ctx.saved_tensors
         B, C, Cp, H, W, O, KH, KW, stride, pad, Ho, Wo, one, has_bias = ctx.meta
         gyh = ops.nchw_to_nhwc(gy.contiguous()).reshape(B * Ho * Wo, O)
         gx = gw = gb = None
@@ -133,6 +139,7 @@ class _Conv2dFn(torch.autograd.Function):
             dxh = dcols.reshape(B, H, W, Cp) if one else ops.col2im_f32(dcols, B, H, W, Cp, KH, KW, stride, pad, Ho, Wo)
             gx = ops.nhwc_to_nchw(dxh[..., :C].contiguous() if Cp != C else dxh)
         if ctx.needs_input_grad[1]:
+            cols = xh.reshape(B * H * W, Cp) if one else ops.im2col_f32(xh, KH, KW, stride, pad, Ho, Wo)
             gw2 = _wgrad(gyh, cols)                                                   # [O][KH*KW*Cp]
             gw = gw2.reshape(O, KH, KW, Cp)[..., :C].permute(0, 3, 1, 2).contiguous()
         if has_bias and ctx.needs_input_grad[2]:
