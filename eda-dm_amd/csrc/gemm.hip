@@ -263,9 +263,18 @@ __device__ __forceinline__ int64_t uniform_i64(int64_t v) {  // pin a wave-unifo
 template <int DT, int TM, int TN, bool HAS_RA, bool HAS_RES>
 __device__ __forceinline__ void epilogue_direct_body(typename Acc<DT>::type (&acc)[TM][TN], const EpiRegs<TN>& er, int lane,
                                                      int64_t row0, int64_t col0, const float* __restrict__ residual,
-                                                     int64_t ldr, float* __restrict__ out, int64_t ldo) {
+                                                     int64_t ldr, float* __restrict__ out, int64_t ldo,
+                                                     float* gacc, float* __restrict__ gn_ws, int64_t N) {
     const int fr = lane & 31, fh4 = (lane >> 5) * 4;
     constexpr int NG = TM * 4;                             // row groups: 4 rows x TN columns per lane each
+    // GroupNorm partials of this output for the layer that normalises it next (K5 pass 1 folded into the producer):
+    // per row group the four values of a column are summed in registers and added to the wave's own LDS slots
+    // (sum, sum of squares per column) -- no accumulator lives across the store loop (the kernel is at its
+    // register limit), the LDS pipe is idle during this epilogue.
+    if (gn_ws && lane < 32) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) *reinterpret_cast<float2*>(gacc + (j * 32 + fr) * 2) = make_float2(0.f, 0.f);
+    }
     constexpr int DEPTH = 2;
     const uint32_t ooff = (uint32_t)(fh4 * (int)ldo + fr) * 4u;
     const uint32_t roff = (uint32_t)(fh4 * (int)ldr + fr) * 4u;
@@ -296,6 +305,9 @@ __device__ __forceinline__ void epilogue_direct_body(typename Acc<DT>::type (&ac
             if (gi + DEPTH < NG) issue(gi + DEPTH);
         }
         asm volatile("" ::: "memory");
+        float ps[TN], pq[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) ps[j] = pq[j] = 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int rl = i * 32 + 8 * g + e;
@@ -309,9 +321,28 @@ __device__ __forceinline__ void epilogue_direct_body(typename Acc<DT>::type (&ac
                 if constexpr (HAS_RA) v += late ? er.ra1[j] : er.ra0[j];
                 if constexpr (HAS_RES) v += rr[gi][e][j];
                 EDADM_NT_STORE(v, reinterpret_cast<float*>(op + ooff + j * 128));
+                ps[j] += v;
+                pq[j] += v * v;
+            }
+        }
+        if (gn_ws) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                atomicAdd(gacc + (j * 32 + fr) * 2, ps[j]);
+                atomicAdd(gacc + (j * 32 + fr) * 2 + 1, pq[j]);
             }
         }
         asm volatile("" ::: "memory");
+    }
+    if (gn_ws) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane < 32) {
+            const int64_t slab = row0 / (TM * 32);         // = b * (hw / 64) + chunk: images are whole numbers of slabs
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                *reinterpret_cast<float2*>(gn_ws + (slab * N + col0 + j * 32 + fr) * 2) =
+                    *reinterpret_cast<const float2*>(gacc + (j * 32 + fr) * 2);
+        }
     }
 }
 
@@ -319,13 +350,14 @@ template <int DT, int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue_direct(typename Acc<DT>::type (&acc)[TM][TN], const EpiRegs<TN>& er, int lane,
                                                      int64_t row0, int64_t col0, bool has_rowadd,
                                                      const float* __restrict__ residual, int64_t ldr,
-                                                     float* __restrict__ out, int64_t ldo) {
+                                                     float* __restrict__ out, int64_t ldo, float* gacc = nullptr,
+                                                     float* __restrict__ gn_ws = nullptr, int64_t N = 0) {
     if (residual) {
-        if (has_rowadd) epilogue_direct_body<DT, TM, TN, true, true>(acc, er, lane, row0, col0, residual, ldr, out, ldo);
-        else epilogue_direct_body<DT, TM, TN, false, true>(acc, er, lane, row0, col0, residual, ldr, out, ldo);
+        if (has_rowadd) epilogue_direct_body<DT, TM, TN, true, true>(acc, er, lane, row0, col0, residual, ldr, out, ldo, gacc, gn_ws, N);
+        else epilogue_direct_body<DT, TM, TN, false, true>(acc, er, lane, row0, col0, residual, ldr, out, ldo, gacc, gn_ws, N);
     } else {
-        if (has_rowadd) epilogue_direct_body<DT, TM, TN, true, false>(acc, er, lane, row0, col0, residual, ldr, out, ldo);
-        else epilogue_direct_body<DT, TM, TN, false, false>(acc, er, lane, row0, col0, residual, ldr, out, ldo);
+        if (has_rowadd) epilogue_direct_body<DT, TM, TN, true, false>(acc, er, lane, row0, col0, residual, ldr, out, ldo, gacc, gn_ws, N);
+        else epilogue_direct_body<DT, TM, TN, false, false>(acc, er, lane, row0, col0, residual, ldr, out, ldo, gacc, gn_ws, N);
     }
 }
 
@@ -425,7 +457,7 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
           const float* __restrict__ scale, const float* __restrict__ bias, const float* __restrict__ rowadd,
           int64_t rows_per_batch, const float* __restrict__ residual, int64_t ldr, float* __restrict__ out,
           int64_t ldo, int64_t strideC, float alpha, int inner, int64_t strideA_i, int64_t strideB_i,
-          int64_t strideC_i, int out_mode, const float* __restrict__ oqp) {
+          int64_t strideC_i, int out_mode, const float* __restrict__ oqp, float* __restrict__ gn_ws) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int NA = BM / 64, NB = BN / 64;   // 16-byte direct-to-LDS loads per thread per K-step
     constexpr int LPT = NA + NB;
@@ -436,9 +468,11 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
     constexpr int EPI_BYTES = 4 * 32 * EST * 4;
     constexpr int RA = BM / 16 + 1;                        // batch entries a tile can span (rows_per_batch >= 16)
     constexpr int MAIN_BYTES = STAGES * TILE > EPI_BYTES ? STAGES * TILE : EPI_BYTES;
-    constexpr int SMEM_BYTES = MAIN_BYTES + (2 + RA) * BN * 4 + 16;
+    constexpr int EC_BYTES = (2 + RA) * BN * 4 + 16;
+    constexpr int SMEM_BYTES = MAIN_BYTES + EC_BYTES + (BM / (TM * 32)) * BN * 2 * 4;   // + GroupNorm partial slots per wave row
     __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM_BYTES];
     float* ec = reinterpret_cast<float*>(smem + MAIN_BYTES);
+    float* gacc_all = reinterpret_cast<float*>(smem + MAIN_BYTES + EC_BYTES);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -616,7 +650,7 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
         EpiRegs<TN> er;
         load_epi_regs<TN, BN>(er, ec, lane, m0, m0 + wm * (TM * 32), wn * (TN * 32), rows_per_batch);
         gemm_epilogue_direct<DT, TM, TN>(acc, er, lane, m0 + wm * (TM * 32), n0 + wn * (TN * 32), rowadd != nullptr, residual,
-                                         ldr, out, ldo);
+                                         ldr, out, ldo, gacc_all + (wm * BN + wn * (TN * 32)) * 2, gn_ws, N);
         return;
     }
     gemm_epilogue<DT, TM, TN, BN, RA, (TN % 2 == 0 || TN == 3) ? 4 : 2>(acc, smem, ec, wave, lane, m0, m0 + wm * (TM * 32), n0 + wn * (TN * 32),
@@ -633,7 +667,7 @@ k_gemm_nt8(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, cons
            const float* __restrict__ scale, const float* __restrict__ bias, const float* __restrict__ rowadd,
            int64_t rows_per_batch, const float* __restrict__ residual, int64_t ldr, float* __restrict__ out,
            int64_t ldo, int64_t strideC, float alpha, int inner, int64_t strideA_i, int64_t strideB_i,
-           int64_t strideC_i, int out_mode, const float* __restrict__ oqp) {
+           int64_t strideC_i, int out_mode, const float* __restrict__ oqp, float* __restrict__ gn_ws) {
     constexpr int TM = 2;
     constexpr int BM = 256, BN = 64 * TN;
     constexpr int NA = 4, NB = TN;                 // 64-row passes per operand (512 threads x 16 B = 64 rows x 128 B)
@@ -644,9 +678,11 @@ k_gemm_nt8(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, cons
     constexpr int EPI_BYTES = 8 * 32 * EST * 4;
     constexpr int RA = BM / 16 + 1;
     constexpr int MAIN_BYTES = STAGES * TILE > EPI_BYTES ? STAGES * TILE : EPI_BYTES;
-    constexpr int SMEM_BYTES = MAIN_BYTES + (2 + RA) * BN * 4 + 16;
+    constexpr int EC_BYTES = (2 + RA) * BN * 4 + 16;
+    constexpr int SMEM_BYTES = MAIN_BYTES + EC_BYTES + (BM / (TM * 32)) * BN * 2 * 4;   // + GroupNorm partial slots per wave row
     __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM_BYTES];
     float* ec = reinterpret_cast<float*>(smem + MAIN_BYTES);
+    float* gacc_all = reinterpret_cast<float*>(smem + MAIN_BYTES + EC_BYTES);
 
     const int tid = threadIdx.x, lane = tid & 63;
     STAMP(t_entry);
@@ -812,7 +848,7 @@ k_gemm_nt8(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, cons
         EpiRegs<TN> er;
         load_epi_regs<TN, BN>(er, ec, lane, m0, m0 + wm * 64, wn * (TN * 32), rows_per_batch);
         gemm_epilogue_direct<DT, TM, TN>(acc, er, lane, m0 + wm * 64, n0 + wn * (TN * 32), rowadd != nullptr, residual, ldr,
-                                         out, ldo);
+                                         out, ldo, gacc_all + (wm * BN + wn * (TN * 32)) * 2, gn_ws, N);
     } else
         gemm_epilogue<DT, TM, TN, BN, RA, 1>(acc, smem, ec, wave, lane, m0, m0 + wm * 64, n0 + wn * (TN * 32), wn * (TN * 32),
                                              M, N, rows_per_batch, rowadd != nullptr, residual, ldr, out, ldo, out_mode);
@@ -1153,8 +1189,17 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
                        int64_t M, int64_t N, int64_t Kb, const ConvGeom& g, const float* scale, const float* bias,
                        const float* rowadd, int64_t rpb, const float* residual, int64_t ldr, float* out, int64_t ldo,
                        int64_t sC, int64_t batch, float alpha, hipStream_t st, int inner = 1, int64_t sAi = 0,
-                       int64_t sBi = 0, int64_t sCi = 0, int out_mode = 0, const float* oqp = nullptr) {
+                       int64_t sBi = 0, int64_t sCi = 0, int out_mode = 0, const float* oqp = nullptr,
+                       float* gn_ws = nullptr, int64_t gn_hw = 0) {
     if (out_mode != 0 && (!oqp || (N & 3) || (ldo & 3))) return EDADM_EINVAL;   // quantised outputs use the 16-byte path
+    if (gn_ws) {
+        // GroupNorm partials come from the register-direct epilogue only: every tile must be full and the 64-row wave
+        // slabs must not straddle images (gn_ws is [M / 64][N][2])
+        const int tn_ = N % 192 == 0 ? 3 : 2;
+        if (out_mode != 0 || batch != 1 || M % 256 || N % (64 * tn_) || gn_hw <= 0 || gn_hw % 64 || M % gn_hw ||
+            (rowadd && rpb < 64))
+            return EDADM_EINVAL;
+    }
     if (!rowadd) rpb = M;                                    // one (unused) batch entry
     static bool pad_ready = false;
     if (!pad_ready) {       // stream-ordered ahead of the first GEMM; idempotent if it lands inside a captured graph
@@ -1178,7 +1223,7 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
         // the long-K convolutions run as fast or faster on k_gemm_nt8 (tools/gemm_table.py)
         const int kstep = force == 6 ? 128 : 64;
         const int64_t ptiles = (M / 256) * (N / (64 * tn));
-        if (force != 2 && force != 3 && batch == 1 && inner == 1 && tn >= 2 && M % 256 == 0 && N % (64 * tn) == 0 &&
+        if (force != 2 && force != 3 && !gn_ws && batch == 1 && inner == 1 && tn >= 2 && M % 256 == 0 && N % (64 * tn) == 0 &&
             (Kb + kstep - 1) / kstep >= 3 && (!rowadd || rpb >= 64) && (out_mode == 0 || (!rowadd && (!residual || !(ldr & 3)))) &&
             (force >= 5 || (ptiles >= 224 && Kb <= 1024)) && (g.mode == 0 || (int64_t)g.B * g.H * g.W * g.Cin < (1ll << 31))) {
             static int ncu = 0;
@@ -1208,7 +1253,7 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
         if (tn == TN_) {                                                                                       \
             hipLaunchKernelGGL((k_gemm_nt8<DT, TN_>), grid8, dim3(512), 0, st, (const uint8_t*)A, lda_b, sA,   \
                                (const uint8_t*)Bm, ldb_b, sB, M, N, Kb, g, scale, bias, rowadd, rpb, residual, \
-                               ldr, out, ldo, sC, alpha, inner, sAi, sBi, sCi, out_mode, oqp);                 \
+                               ldr, out, ldo, sC, alpha, inner, sAi, sBi, sCi, out_mode, oqp, gn_ws);      \
             return edadm_launch_status();                                                                      \
         }
         EDADM_GEMM8_CASE(3)
@@ -1223,7 +1268,7 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
                         (unsigned)batch);                                                                      \
         hipLaunchKernelGGL((k_gemm_nt<DT, TM_, TN_>), grid, blk, 0, st, (const uint8_t*)A, lda_b, sA,          \
                            (const uint8_t*)Bm, ldb_b, sB, M, N, Kb, g, scale, bias, rowadd, rpb, residual, ldr, \
-                           out, ldo, sC, alpha, inner, sAi, sBi, sCi, out_mode, oqp);                          \
+                           out, ldo, sC, alpha, inner, sAi, sBi, sCi, out_mode, oqp, gn_ws);                   \
         return edadm_launch_status();                                                                          \
     }
     EDADM_GEMM_CASE(2, 3)
@@ -1237,10 +1282,10 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
 }
 
 #if EDADM_GEMM_DT == 0
-extern "C" int edadm_qgemm_i8(const int8_t* A, int64_t lda, const int8_t* Wt, int64_t ldw, int64_t M, int64_t N,
-                              int64_t K, const int32_t* geom, const float* scale, const float* bias,
-                              const float* rowadd, int64_t rows_per_batch, const float* residual, int64_t ldr,
-                              float* out, int64_t ldo, void* stream) {
+extern "C" int edadm_qgemm_i8_gn(const int8_t* A, int64_t lda, const int8_t* Wt, int64_t ldw, int64_t M, int64_t N,
+                                 int64_t K, const int32_t* geom, const float* scale, const float* bias,
+                                 const float* rowadd, int64_t rows_per_batch, const float* residual, int64_t ldr,
+                                 float* out, int64_t ldo, float* gn_ws, int64_t gn_hw, void* stream) {
     if (!A || !Wt || !out || !scale || M <= 0 || N <= 0 || K <= 0 || (K & 15) || (ldw & 15)) return EDADM_EINVAL;
     if (((uintptr_t)A & 15) || ((uintptr_t)Wt & 15)) return EDADM_EINVAL;
     ConvGeom g;
@@ -1259,7 +1304,14 @@ extern "C" int edadm_qgemm_i8(const int8_t* A, int64_t lda, const int8_t* Wt, in
     }
     if (rowadd && rows_per_batch < 16) return EDADM_EINVAL;   // the epilogue stages <= BM/16+1 row-add rows in LDS
     return launch_gemm<0>(A, lda, 0, Wt, ldw, 0, M, N, K, g, scale, bias, rowadd, rows_per_batch, residual, ldr,
-                             out, ldo, 0, 1, 1.0f, (hipStream_t)stream);
+                             out, ldo, 0, 1, 1.0f, (hipStream_t)stream, 1, 0, 0, 0, 0, nullptr, gn_ws, gn_hw);
+}
+extern "C" int edadm_qgemm_i8(const int8_t* A, int64_t lda, const int8_t* Wt, int64_t ldw, int64_t M, int64_t N,
+                              int64_t K, const int32_t* geom, const float* scale, const float* bias,
+                              const float* rowadd, int64_t rows_per_batch, const float* residual, int64_t ldr,
+                              float* out, int64_t ldo, void* stream) {
+    return edadm_qgemm_i8_gn(A, lda, Wt, ldw, M, N, K, geom, scale, bias, rowadd, rows_per_batch, residual, ldr, out, ldo,
+                             nullptr, 0, stream);
 }
 #endif
 

@@ -208,7 +208,9 @@ __global__ void __launch_bounds__(256) k_gn_partial(const float* __restrict__ x,
         }
     }
 }
-__global__ void __launch_bounds__(64) k_gn_final(const float* __restrict__ ws, float* __restrict__ stats,
+// ws2 != nullptr: channels [C1, C) come from a second partials buffer (the other half of a skip concatenation)
+__global__ void __launch_bounds__(64) k_gn_final(const float* __restrict__ ws, const float* __restrict__ ws2, int64_t C1,
+                                                 float* __restrict__ stats,
                                                  int64_t HW, int64_t C, int64_t G, int nchunk, float eps) {
     const int64_t b = blockIdx.y, g = blockIdx.x;
     const int cpg = (int)(C / G);
@@ -216,7 +218,8 @@ __global__ void __launch_bounds__(64) k_gn_final(const float* __restrict__ ws, f
     const int items = nchunk * cpg;
     for (int i = threadIdx.x; i < items; i += 64) {
         const int ch = i / cpg, c = (int)(g * cpg) + i % cpg;
-        const float* p = ws + ((b * nchunk + ch) * C + c) * 2;
+        const float* p = (!ws2 || c < C1) ? ws + ((b * nchunk + ch) * (ws2 ? C1 : C) + c) * 2
+                                          : ws2 + ((b * nchunk + ch) * (C - C1) + (c - C1)) * 2;
         s += (double)p[0];
         ss += (double)p[1];
     }
@@ -243,8 +246,17 @@ extern "C" int edadm_groupnorm_stats_cat(const float* x1, int64_t C1, const floa
     const size_t smem = Q <= 256 ? (size_t)RS * C * 2 * sizeof(float) : 0;
     hipLaunchKernelGGL(k_gn_partial, dim3(nchunk, (unsigned)B), dim3(256), smem, (hipStream_t)stream, x1, x2, C1, ws, HW,
                        C, nchunk);
-    hipLaunchKernelGGL(k_gn_final, dim3((unsigned)G, (unsigned)B), dim3(64), 0, (hipStream_t)stream, ws, stats, HW,
-                       C, G, nchunk, eps);
+    hipLaunchKernelGGL(k_gn_final, dim3((unsigned)G, (unsigned)B), dim3(64), 0, (hipStream_t)stream, ws, (const float*)nullptr,
+                       C, stats, HW, C, G, nchunk, eps);
+    return edadm_launch_status();
+}
+// pass 2 alone, over per-channel partials [B][nchunk][C][2] that a producer already wrote (edadm_qgemm_i8_gn)
+extern "C" int edadm_groupnorm_final_cat(const float* ws1, int64_t C1, const float* ws2, int64_t C2, float* stats, int64_t B,
+                                         int64_t HW, int64_t G, int64_t nchunk, float eps, void* stream) {
+    const int64_t C = C1 + (ws2 ? C2 : 0);
+    if (!ws1 || !stats || B <= 0 || HW <= 0 || C1 <= 0 || (ws2 && C2 <= 0) || G <= 0 || (C % G) || nchunk <= 0) return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_gn_final, dim3((unsigned)G, (unsigned)B), dim3(64), 0, (hipStream_t)stream, ws1, ws2, C1, stats, HW, C,
+                       G, (int)nchunk, eps);
     return edadm_launch_status();
 }
 extern "C" int edadm_groupnorm_stats(const float* x, float* stats, float* ws, int64_t B, int64_t HW, int64_t C,

@@ -18,6 +18,7 @@ from the O(B x 192) sinusoidal timestep table.  The whole forward is graph-captu
 (`Engine.capture`) because every launch goes to the current stream and nothing synchronises.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -110,6 +111,7 @@ class Engine:
             if isinstance(m, QuantModule):
                 self.layers[id(m)] = FrozenLayer(m, name)
         self._attn_cache = {}
+        self.gn_from_producer = os.environ.get("EDADM_GN_FROM_PRODUCER", "0") == "1"   # measured slower (58.4 vs 61.7 img/s): off
         self.graph = None
         self.prof = None
         # GEGLU is computed in the ff.net[0].proj epilogue: its output channels are re-ordered so that
@@ -233,7 +235,7 @@ class Engine:
             return ops.quant_f16(x2d, L.qp)
         return x2d
 
-    def _gemm(self, L, a, M, geom=None, rowadd=None, rpb=1, residual=None, out_mode=0, oqp=None):
+    def _gemm(self, L, a, M, geom=None, rowadd=None, rpb=1, residual=None, out_mode=0, oqp=None, gn_hw=0):
         if out_mode:
             # the only consumer is an activation quantizer: emit its operand from the epilogue
             assert L.mode == "i8" and len(L.segs) == 1 and geom is None
@@ -245,12 +247,23 @@ class Engine:
             return run()
         out = torch.empty(M, L.N, dtype=torch.float32, device=self.dev)
         fn = ops.qgemm_i8 if L.mode == "i8" else ops.qgemm_f16
+        # GroupNorm partials of the output, written by the epilogue of the (last) launch for the layer that
+        # normalises it next: that layer then runs only the tiny final pass (K5 pass 1 folded into K4).  Long-K
+        # layers only: the short-K ones run on the persistent kernel, which has no register room for it.
+        # Correct (tests/test_gemm_paths_gpu.py) but OFF by default: the LDS atomics lengthen every producing epilogue
+        # by more than the saved statistics pass (EDADM_GN_FROM_PRODUCER=1: 58.4 vs 61.7 images/s).
+        gkw = {}
+        if self.gn_from_producer and gn_hw and L.mode == "i8" and L.K > 1024 and \
+                ops.gn_partials_ok(M, L.N, gn_hw, rpb if rowadd is not None else None):
+            ws = torch.empty(M // 64, L.N, 2, dtype=torch.float32, device=self.dev)
+            gkw = dict(gn_ws=ws, gn_hw=gn_hw)
+            out._gn = (ws, gn_hw)
         if geom is not None:
             s = L.segs[0]
 
             def run():
                 fn(a, s["w"], M, L.N, s["K"], s["scale"], L.bias, out, geom=geom, rowadd=rowadd, rows_per_batch=rpb,
-                   residual=residual)
+                   residual=residual, **gkw)
         else:
             ctot = a.shape[-1]
 
@@ -258,7 +271,8 @@ class Engine:
                 for i, s in enumerate(L.segs):
                     av = a if len(L.segs) == 1 else a[:, s["lo"]:s["hi"]]
                     fn(av, s["w"], M, L.N, s["K"], s["scale"], L.bias if i == 0 else None, out, lda=ctot,
-                       rowadd=rowadd if i == 0 else None, rows_per_batch=rpb, residual=residual if i == 0 else out)
+                       rowadd=rowadd if i == 0 else None, rows_per_batch=rpb, residual=residual if i == 0 else out,
+                       **(gkw if i == len(L.segs) - 1 else {}))
         if self.prof is not None:
             self.prof.append((L.mode, L.name, M, L.N, L.K, 2.0 * M * L.N * L.K, run))
         run()
@@ -275,8 +289,8 @@ class Engine:
         L = self.L(qm)
         if L.kind == "dense":
             out = self._gemm(L, a.reshape(B * H * W, -1), B * H * W, rowadd=rowadd, rpb=H * W,
-                             residual=None if residual is None else residual.reshape(B * H * W, -1))
-            return out.reshape(B, H, W, L.N)
+                             residual=None if residual is None else residual.reshape(B * H * W, -1), gn_hw=H * W)
+            return self._keep_gn(out, out.reshape(B, H, W, L.N))
         Hl, Wl = (2 * H, 2 * W) if ups else (H, W)
         if L.stride == 1:
             Ho, Wo, pad0 = Hl, Wl, L.pad
@@ -287,12 +301,31 @@ class Engine:
         geom = ops.make_geom(B, H, W, L.cin, Ho, Wo, L.kh, L.kh, L.stride, pad0, ups, padval)
         M = B * Ho * Wo
         out = self._gemm(L, a, M, geom=geom, rowadd=rowadd, rpb=Ho * Wo,
-                         residual=None if residual is None else residual.reshape(M, -1))
-        return out.reshape(B, Ho, Wo, L.N)
+                         residual=None if residual is None else residual.reshape(M, -1), gn_hw=Ho * Wo)
+        return self._keep_gn(out, out.reshape(B, Ho, Wo, L.N))
+
+    @staticmethod
+    def _keep_gn(src, view):
+        """carry the producer's GroupNorm partials over a reshape (torch views drop python attributes)"""
+        g = getattr(src, "_gn", None)
+        if g is not None:
+            view._gn = g
+        return view
+
+    def _gn_stats(self, norm, x):
+        """statistics pass: from the producers' partials when every half of x has them, else the two-pass kernels"""
+        parts = (x.a, x.b) if isinstance(x, ops.Cat) else (x,)
+        gs = [getattr(p, "_gn", None) for p in parts]
+        B = parts[0].shape[0]
+        HW = parts[0].numel() // (B * parts[0].shape[-1])
+        if all(g is not None and g[1] == HW for g in gs):
+            ws2 = gs[1][0] if len(gs) == 2 else None
+            return ops.groupnorm_final(gs[0][0], parts[0].shape[-1], ws2, parts[-1].shape[-1], B, HW, norm.num_groups, norm.eps)
+        return ops.groupnorm_stats(x, norm.num_groups, norm.eps)
 
     def gn(self, norm, x, silu, qms=(), want_f32=False, scale_shift=None):
         """GroupNorm(+SiLU) of NHWC x -> (fp32 or None, [int8 operand per layer in qms])."""
-        st = ops.groupnorm_stats(x, norm.num_groups, norm.eps)
+        st = self._gn_stats(norm, x)
         Ls = [self.L(q) for q in qms]
         assert all(l.mode == "i8" and not l.split for l in Ls)
         qp = torch.cat([l.qp for l in Ls]) if Ls else None

@@ -356,12 +356,32 @@ def make_geom(B, H, W, Cin, Ho, Wo, KH, KW, stride, pad0, ups, padval):
     return (ctypes.c_int32 * 16)(1, B, H, W, Cin, Ho, Wo, KH, KW, stride, pad0, 1 if ups else 0, int(padval), 0, 0, 0)
 
 
+def gn_partials_ok(M, N, hw, rowadd_rpb=None):
+    """Can the GEMM that writes out[M][N] also emit the GroupNorm partials of its output (edadm_qgemm_i8_gn)?"""
+    tile_n = 192 if N % 192 == 0 else 128
+    return M % 256 == 0 and N % tile_n == 0 and hw > 0 and hw % 64 == 0 and M % hw == 0 and \
+        (rowadd_rpb is None or rowadd_rpb >= 64)
+
+
+def groupnorm_final(ws1, C1, ws2, C2, B, HW, G, eps):
+    """stats[B][G][2] from producer-written partials [B][HW/64][C][2] (ws2: second half of a concatenation)."""
+    stats = torch.empty(B, G, 2, dtype=torch.float32, device=ws1.device)
+    lib.call("edadm_groupnorm_final_cat", _pf(ws1), C1, _pf(ws2), C2 if ws2 is not None else 0, _pf(stats), B, HW, G,
+             HW // 64, float(eps), _stream())
+    return stats
+
+
 def qgemm_i8(A, Wt, M, N, K, scale, bias, out, geom=None, lda=None, ldw=None, rowadd=None, rows_per_batch=1,
-             residual=None):
+             residual=None, gn_ws=None, gn_hw=0):
     """out[M][N] (fp32, contiguous rows of length N) = scale[n] * (A . Wt^T) + bias[n] [+rowadd] [+residual]."""
     lda = K if lda is None else lda
     ldw = K if ldw is None else ldw
     gptr = ctypes.cast(geom, ctypes.c_void_p) if geom is not None else None
+    if gn_ws is not None:
+        lib.call("edadm_qgemm_i8_gn", ctypes.c_void_p(A.data_ptr()), int(lda), ctypes.c_void_p(Wt.data_ptr()), int(ldw),
+                 int(M), int(N), int(K), gptr, _pf(scale), _pf(bias), _pf(rowadd), int(rows_per_batch), _pf(residual),
+                 int(N), _pf(out), int(N), _pf(gn_ws), int(gn_hw), _stream())
+        return out
     lib.call("edadm_qgemm_i8", ctypes.c_void_p(A.data_ptr()), int(lda), ctypes.c_void_p(Wt.data_ptr()), int(ldw),
              int(M), int(N), int(K), gptr, _pf(scale), _pf(bias), _pf(rowadd), int(rows_per_batch), _pf(residual),
              int(N), _pf(out), int(N), _stream())
