@@ -274,6 +274,10 @@ def main():
                          "frac": achieved / I8_PEAK_TFLOPS, "traffic": traffic,
                          "kernel": "int8 GEMM (edadm_qgemm_i8/_q: k_gemm_nt8, k_gemm_p, k_gemm_nt): %d launches per UNet call, %.1f GFLOP, %.2f ms summed"
                                    % (len(i8), gemm_flop / 1e9, gemm_ms),
+                         "hbm": {"note": "same launches against the HBM roof: PMC bytes per launch x launches / summed time",
+                                 "achieved_GBps": (traffic * len(i8) / (gemm_ms * 1e-3) / 1e9) if traffic else None,
+                                 "peak_GBps": 8000.0,
+                                 "frac": (traffic * len(i8) / (gemm_ms * 1e-3) / 8e12) if traffic else None},
                          "unet_call_ms": unet_ms,
                          "unet_algorithmic_tflops": 2 * B * UNET_GFLOP_PER_ROW / unet_ms},
             "calibration": calib,

@@ -886,9 +886,14 @@ k_gemm_p(const uint8_t* __restrict__ A, int64_t lda_b, const uint8_t* __restrict
     constexpr int TILE = (BM + BN) * KSTEP;
     constexpr int RA = 5;                        // row-add entries a tile can span (rows_per_batch >= 64)
     constexpr int ECN = (2 + RA) * BN + 4;       // floats per epilogue-constant buffer (+ output quantiser)
-    constexpr int SMEM_BYTES = S * TILE + 3 * ECN * 4;
+    constexpr int SMEM_BYTES = S * TILE + 3 * ECN * 4 + 2 * S * 4;
     __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM_BYTES];
     float* ec_all = reinterpret_cast<float*>(smem + S * TILE);
+    // hand-off words, one pair per ring slot: FULL counts loader waves that have written the slot (4 per use), FREE
+    // counts MFMA waves that have read it (8 per use).  No workgroup barrier in the steady state: a barrier per K-step
+    // ties the MFMA waves to the loader's cadence even when the ring already holds the next steps.
+    int* full_w = reinterpret_cast<int*>(smem + S * TILE + 3 * ECN * 4);
+    int* free_w = full_w + S;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -899,6 +904,22 @@ k_gemm_p(const uint8_t* __restrict__ A, int64_t lda_b, const uint8_t* __restrict
     const int ntl = logical < tiles_total ? (tiles_total - 1 - logical) / nwg + 1 : 0;
     const int nk = (int)((Kb + KSTEP - 1) / KSTEP);
     const int G = ntl * nk;                                          // K-steps this workgroup runs in total
+    if (tid < 2 * S) full_w[tid] = 0;
+    __syncthreads();
+    bool dead = false;                                               // a hand-off that never arrives: stop waiting (wrong
+                                                                     // results, which the tests see) instead of hanging
+    auto wait_at_least = [&](int* word, int target) {
+        if (dead) return;
+        for (int spins = 0;; ++spins) {
+            const int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+            if (v >= target) return;
+            if (spins > (1 << 22)) { dead = true; return; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
+    auto signal = [&](int* word) {
+        if (lane == 0) __hip_atomic_fetch_add(word, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
 
     if (wave >= 8) {
         // ------------------------------------------------------------------ loader waves
@@ -1045,31 +1066,21 @@ k_gemm_p(const uint8_t* __restrict__ A, int64_t lda_b, const uint8_t* __restrict
         int nl = 0, nw = 0;
         if (nl < G) { load_step(S0{}); ++nl; }
         if (D > 1 && nl < G) { load_step(S1{}); ++nl; }
-        // fill S-1 ring slots (steps 0 .. S-2)
-        if (nw < G) { write_step(S0{}); ++nw; if (nl < G) { load_step(S0{}); ++nl; } }
-        static_assert(D == 1 || (S & 1), "two register slots: the first in-loop write must land on slot 0");
-#pragma unroll
-        for (int p = 1; p < S - 1; ++p) {
-            if (nw < G) {
-                if ((p & 1) && D > 1) { write_step(S1{}); ++nw; if (nl < G) { load_step(S1{}); ++nl; } }
-                else { write_step(S0{}); ++nw; if (nl < G) { load_step(S0{}); ++nl; } }
-            }
-        }
-        // in-loop: after barrier gs, write step gs+S-1 (slot (gs+S-1) % D) and reload that slot
 #ifdef EDADM_STAMPS
         unsigned long long l_wait = 0, l_bar = 0, l_issue = 0;
         const unsigned long long l_t0 = __builtin_amdgcn_s_memtime();
 #endif
+        // step x: wait until the MFMA waves have released the slot's previous use, write it from the registers that were
+        // loaded D steps ago, publish, and refill those registers with step x + D
         auto turn = [&](auto slot) {
             STAMP(ls0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
+            const int rs = nw % S;
+            if (nw >= S) wait_at_least(free_w + rs, 8 * (nw / S));
             STAMP(ls1);
-            if (nw < G) { write_step(slot); ++nw; }
-#ifdef EDADM_STAMPS
+            write_step(slot);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
+            signal(full_w + rs);
+            ++nw;
             STAMP(ls2);
             if (nl < G) { load_step(slot); ++nl; }
 #ifdef EDADM_STAMPS
@@ -1077,12 +1088,11 @@ k_gemm_p(const uint8_t* __restrict__ A, int64_t lda_b, const uint8_t* __restrict
 #endif
         };
         if constexpr (D == 1) {
-            for (int gs = 0; gs < G; ++gs) turn(S0{});
+            while (nw < G) turn(S0{});
         } else {
-            // S - 1 = 2 steps were pre-written, so the first in-loop write is step 2 -> slot 0
-            for (int gs = 0; gs < G; gs += 2) {
+            while (nw < G) {
                 turn(S0{});
-                if (gs + 1 < G) turn(S1{});
+                if (nw < G) turn(S1{});
             }
         }
 #ifdef EDADM_STAMPS
@@ -1111,8 +1121,7 @@ k_gemm_p(const uint8_t* __restrict__ A, int64_t lda_b, const uint8_t* __restrict
 #endif
         for (int gs = 0; gs < G; ++gs) {
             STAMP(ms0);
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
+            wait_at_least(full_w + gs % S, 4 * (gs / S + 1));
             STAMP(ms1);
             const uint8_t* As = smem + (gs % S) * TILE;
             const uint8_t* Bs = As + BM * KSTEP;
@@ -1140,6 +1149,7 @@ k_gemm_p(const uint8_t* __restrict__ A, int64_t lda_b, const uint8_t* __restrict
                         else mma_step<DT>(fa[i], fb[j], acc[i][j]);
                     }
             }
+            signal(free_w + gs % S);                                 // release: the slot's fragments are in registers
 #ifdef EDADM_STAMPS
             asm volatile("s_nop 0" ::: "memory");
             STAMP(ms2);
