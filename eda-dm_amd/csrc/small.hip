@@ -27,9 +27,11 @@ __global__ void __launch_bounds__(256) k_conv3x3_smalln(const float* __restrict_
                 wr[n][t][j] = (n < N && c < C) ? w[((int64_t)n * 9 + t) * C + c] : 0.f;
             }
     const int iW = (int)W, iH = (int)H;
-    const int b = (int)(blockIdx.x / (unsigned)iH), y = (int)(blockIdx.x - (unsigned)b * (unsigned)iH);
-    const float* xb = x + (int64_t)b * H * W * C;
     const int nstrips = (iW + SMALLN_P - 1) / SMALLN_P;
+    // a block walks output rows (b, y) with a grid stride: the 9 x N weight vectors are loaded once per block
+    for (unsigned by = blockIdx.x; by < (unsigned)(B * H); by += gridDim.x) {
+    const int b = (int)(by / (unsigned)iH), y = (int)(by - (unsigned)b * (unsigned)iH);
+    const float* xb = x + (int64_t)b * H * W * C;
     for (int sidx = wave; sidx < nstrips; sidx += 4) {
         const int x0 = sidx * SMALLN_P;
         float acc[SMALLN_P][SMALLN_MAX];
@@ -37,21 +39,36 @@ __global__ void __launch_bounds__(256) k_conv3x3_smalln(const float* __restrict_
         for (int p = 0; p < SMALLN_P; ++p)
 #pragma unroll
             for (int n = 0; n < SMALLN_MAX; ++n) acc[p][n] = 0.f;
+        // all 3 x (P + 2) x CJ input values of the strip are requested before the first FMA (clamped addresses, the
+        // padding zeroed afterwards): with a branch per tap the loads of each tap waited out their latency alone
+        float in[3][SMALLN_P + 2][CJ];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int iy = y + ky - 1;
-            if (iy < 0 || iy >= iH) continue;                          // wave-uniform
-            const float* xrow = xb + (int64_t)iy * W * C;
+            const int cy = iy < 0 ? 0 : (iy >= iH ? iH - 1 : iy);
+            const float* xrow = xb + (int64_t)cy * W * C;
 #pragma unroll
             for (int xx = -1; xx <= SMALLN_P; ++xx) {
                 const int ix = x0 + xx;
-                if (ix < 0 || ix >= iW) continue;                      // wave-uniform
-                float v[CJ];
+                const int cx = ix < 0 ? 0 : (ix >= iW ? iW - 1 : ix);
 #pragma unroll
                 for (int j = 0; j < CJ; ++j) {
                     const int c = lane + 64 * j;
-                    v[j] = c < C ? xrow[(int64_t)ix * C + c] : 0.f;
+                    in[ky][xx + 1][j] = c < C ? xrow[(int64_t)cx * C + c] : 0.f;
                 }
+            }
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = y + ky - 1;
+            const bool yok = iy >= 0 && iy < iH;
+#pragma unroll
+            for (int xx = -1; xx <= SMALLN_P; ++xx) {
+                const int ix = x0 + xx;
+                const bool ok = yok && ix >= 0 && ix < iW;                 // wave-uniform
+                float v[CJ];
+#pragma unroll
+                for (int j = 0; j < CJ; ++j) v[j] = ok ? in[ky][xx + 1][j] : 0.f;
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const int p = xx - kx + 1;                         // output pixel this (input, tap) pair feeds
@@ -63,16 +80,34 @@ __global__ void __launch_bounds__(256) k_conv3x3_smalln(const float* __restrict_
                 }
             }
         }
+        // 16 sums (4 pixels x 4 outputs) over the 64 lanes: a halving butterfly -- at each of the four upper lane bits a
+        // lane keeps half of its values and hands the other half to its partner -- needs 8+4+2+1+2 shuffles instead of
+        // 16 x 6 (the shuffles go through the LDS crossbar and were most of this kernel's time)
+        float v16[16];
 #pragma unroll
-        for (int p = 0; p < SMALLN_P; ++p) {
-            if (x0 + p >= iW) continue;
+        for (int p = 0; p < SMALLN_P; ++p)
 #pragma unroll
-            for (int n = 0; n < SMALLN_MAX; ++n) {
-                if (n >= N) continue;
-                const float sum = wave_sum(acc[p][n]);
-                if (lane == 0) out[(((int64_t)b * H + y) * W + x0 + p) * N + n] = sum + (bias ? bias[n] : 0.f);
+            for (int n = 0; n < SMALLN_MAX; ++n) v16[p * 4 + n] = acc[p][n];
+#pragma unroll
+        for (int bit = 5, cnt = 8; bit >= 2; --bit, cnt >>= 1) {
+            const bool up = (lane >> bit) & 1;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (k < cnt) {
+                    const float lo = v16[k], hi = v16[k + cnt];
+                    const float keep = up ? hi : lo, send = up ? lo : hi;
+                    v16[k] = keep + __shfl_xor(send, 1 << bit, 64);
+                }
             }
         }
+        float tot = v16[0];
+        tot += __shfl_xor(tot, 2, 64);
+        tot += __shfl_xor(tot, 1, 64);
+        const int idx = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+        const int p = idx >> 2, n = idx & 3;
+        if ((lane & 3) == 0 && n < N && x0 + p < iW)
+            out[(((int64_t)b * H + y) * W + x0 + p) * N + n] = tot + (bias ? bias[n] : 0.f);
+    }
     }
 }
 extern "C" int edadm_conv3x3_f32_smalln(const float* x, const float* w, const float* bias, float* out, int64_t B,
@@ -80,7 +115,7 @@ extern "C" int edadm_conv3x3_f32_smalln(const float* x, const float* w, const fl
     if (!x || !w || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C > 320 || N <= 0 || N > SMALLN_MAX ||
         B * H > 0x7fffffff)
         return EDADM_EINVAL;
-    const int64_t g = B * H;
+    const int64_t g = B * H < 1536 ? B * H : 1536;
     const int cj = (int)((C + 63) / 64);
     hipStream_t st = (hipStream_t)stream;
 #define SMALLN_CASE(CJ_)                                                                                          \
