@@ -103,14 +103,14 @@ __device__ __forceinline__ float rint_div(float v, float d, float inv_d) {
 
 template <int NV>
 __device__ __forceinline__ void rint_div_n(const float (&v)[NV], float d, float inv_d, float (&r)[NV]) {
-    bool near = false;
+    float worst = 0.f;                                     // max |t - rint(t)| of the group: one compare, one branch
 #pragma unroll
     for (int e = 0; e < NV; ++e) {
         const float t = v[e] * inv_d;
         r[e] = rintf(t);
-        near |= fabsf(t - r[e]) > 0.499f;
+        worst = fmaxf(worst, fabsf(t - r[e]));
     }
-    if (__builtin_expect(near, 0)) {                       // one branch per group
+    if (__builtin_expect(worst > 0.499f, 0)) {
 #pragma unroll
         for (int e = 0; e < NV; ++e) {
             asm volatile("" : "+v"(r[e]));
@@ -118,6 +118,9 @@ __device__ __forceinline__ void rint_div_n(const float (&v)[NV], float d, float 
         }
     }
 }
+
+// clamp to [lo, hi] in one instruction (v_med3_f32)
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 
 // four quantised codes (float, already clamped to [0, 255]) -> int8 operand bytes code - 128
 __device__ __forceinline__ uint32_t pack_codes_i8(const float (&q)[4]) {

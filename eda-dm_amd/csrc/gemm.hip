@@ -407,21 +407,23 @@ __device__ __forceinline__ void gemm_epilogue_qdirect(typename Acc<DT>::type (&a
                         y[1] = v[2] * (0.5f * v[3] * (1.0f + erf_fast(v[3] * 0.70710678118654752440f)));
                         rint_div_n<2>(y, od, oi, r);
                         uint32_t w = 0;
-                        w = __builtin_amdgcn_cvt_pk_u8_f32(fminf(fmaxf(r[0] + oz, 0.f), oq), 0, w);
-                        w = __builtin_amdgcn_cvt_pk_u8_f32(fminf(fmaxf(r[1] + oz, 0.f), oq), 1, w);
+                        w = __builtin_amdgcn_cvt_pk_u8_f32(clampf(r[0] + oz, 0.f, oq), 0, w);
+                        w = __builtin_amdgcn_cvt_pk_u8_f32(clampf(r[1] + oz, 0.f, oq), 1, w);
                         *reinterpret_cast<uint16_t*>(reinterpret_cast<int8_t*>(outv) + ro + (col >> 1)) = (uint16_t)(w ^ 0x8080u);
                     } else {
                         float q[4];
                         rint_div_n<4>(v, od, oi, q);
+                        if constexpr (MODE == 1) {         // f16 operand code - zp: clamp(r + zp, 0, qmax) - zp in one med3
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) q[e] = fminf(fmaxf(q[e] + oz, 0.f), oq);
-                        if constexpr (MODE == 1) {         // f16 operand code - zp (attention products)
-                            __half2 h0 = __floats2half2_rn(q[0] - oz, q[1] - oz), h1 = __floats2half2_rn(q[2] - oz, q[3] - oz);
+                            for (int e = 0; e < 4; ++e) q[e] = clampf(q[e], -oz, oq - oz);
+                            __half2 h0 = __floats2half2_rn(q[0], q[1]), h1 = __floats2half2_rn(q[2], q[3]);
                             uint2 pk;
                             pk.x = *reinterpret_cast<uint32_t*>(&h0);
                             pk.y = *reinterpret_cast<uint32_t*>(&h1);
                             *reinterpret_cast<uint2*>(reinterpret_cast<__half*>(outv) + ro + col) = pk;
                         } else {                           // int8 operand code - 128
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) q[e] = clampf(q[e] + oz, 0.f, oq);
                             *reinterpret_cast<uint32_t*>(reinterpret_cast<int8_t*>(outv) + ro + col) = pack_codes_i8(q);
                         }
                     }

@@ -30,7 +30,7 @@ __device__ __forceinline__ uint32_t quant4(const float4& v, const QP& q) {
     float r[4];
     rint_div_n<4>(x, q.d, q.inv, r);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) r[e] = fminf(fmaxf(r[e] + q.z, 0.f), q.qmax);
+    for (int e = 0; e < 4; ++e) r[e] = clampf(r[e] + q.z, 0.f, q.qmax);
     return pack_codes_i8(r);
 }
 
