@@ -119,6 +119,26 @@ __device__ __forceinline__ void rint_div_n(const float (&v)[NV], float d, float 
     }
 }
 
+// rint(v / d) + z (z an integer-valued zero point): the addition rides in the multiply (one FMA), exact ties are
+// inside the 0.499 band and take the exact path, so the half-to-even decision is the reference's
+template <int NV>
+__device__ __forceinline__ void rint_div_zp_n(const float (&v)[NV], float d, float inv_d, float z, float (&r)[NV]) {
+    float worst = 0.f;
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+        const float t = fmaf(v[e], inv_d, z);
+        r[e] = rintf(t);
+        worst = fmaxf(worst, fabsf(t - r[e]));
+    }
+    if (__builtin_expect(worst > 0.499f, 0)) {
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+            asm volatile("" : "+v"(r[e]));
+            r[e] = rintf(v[e] / d) + z;
+        }
+    }
+}
+
 // clamp to [lo, hi] in one instruction (v_med3_f32)
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 

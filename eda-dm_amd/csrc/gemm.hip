@@ -376,57 +376,95 @@ __device__ __forceinline__ void gemm_epilogue_qdirect(typename Acc<DT>::type (&a
     const float oi = 1.0f / od;
     // element offset of (row0 + fr, col0 + fh4) in the output matrix (GEGLU halves the column index)
     const int64_t rbase = (row0 + fr) * ldo;
+    // Stores: a lane's four columns are 4 (int8), 8 (f16) or 2 (GEGLU) bytes per register group -- 32 separate rows per
+    // store instruction, and the L2 request rate, not the ALU, bound this epilogue.  The two lanes that share a row
+    // (lane and lane ^ 32 hold alternating 4-column groups) first trade half of their packed words, so each writes one
+    // contiguous 16-byte (int8), 2 x 16-byte (f16) or 8-byte (GEGLU) piece per 32-column block: 4x / 2x / 4x fewer
+    // requests.
+    const bool hi = fh4 != 0;
     auto body = [&](auto mode_tag) {
         constexpr int MODE = decltype(mode_tag)::value;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int ecol = ecol0 + j * 32 + 8 * g + fh4;
-                const float4 s4 = *reinterpret_cast<const float4*>(ec + ecol);
-                const float4 b4 = *reinterpret_cast<const float4*>(ec + BN + ecol);
+            for (int i = 0; i < TM; ++i) {
+                uint32_t pk[4][2];                          // packed words per register group g (f16: 2 words, else 1)
+                const int64_t ro = rbase + (int64_t)(i * 32) * ldo;
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
+                for (int g = 0; g < 4; ++g) {
+                    const int ecol = ecol0 + j * 32 + 8 * g + fh4;
+                    const float4 s4 = *reinterpret_cast<const float4*>(ec + ecol);
+                    const float4 b4 = *reinterpret_cast<const float4*>(ec + BN + ecol);
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        auto a = acc[i][j][4 * g + e];
-                        asm volatile("" : "+v"(a));
-                        v[e] = (float)a;
+                        asm volatile("" : "+v"(acc[i][j][4 * g + e]));     // read here (in place: no copy), not hoisted
+                        v[e] = (float)acc[i][j][4 * g + e];
                     }
                     v[0] = v[0] * s4.x + b4.x; v[1] = v[1] * s4.y + b4.y; v[2] = v[2] * s4.z + b4.z; v[3] = v[3] * s4.w + b4.w;
-                    const int64_t col = col0 + j * 32 + 8 * g + fh4;
                     if (residual) {                        // the lane's four columns are one 16-byte piece of its row
+                        const int64_t col = col0 + j * 32 + 8 * g + fh4;
                         const float4 r4 = *reinterpret_cast<const float4*>(residual + (row0 + i * 32 + fr) * ldr + col);
                         v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
                     }
-                    const int64_t ro = rbase + (int64_t)(i * 32) * ldo;
-                    if constexpr (MODE == 3) {             // GEGLU on interleaved (a, gate) columns -> int8 operand
+                    if constexpr (MODE == 3) {             // GEGLU on interleaved (a, gate) columns -> two int8 codes
                         float y[2], r[2];
                         y[0] = v[0] * (0.5f * v[1] * (1.0f + erf_fast(v[1] * 0.70710678118654752440f)));
                         y[1] = v[2] * (0.5f * v[3] * (1.0f + erf_fast(v[3] * 0.70710678118654752440f)));
-                        rint_div_n<2>(y, od, oi, r);
+                        rint_div_zp_n<2>(y, od, oi, oz, r);
                         uint32_t w = 0;
-                        w = __builtin_amdgcn_cvt_pk_u8_f32(clampf(r[0] + oz, 0.f, oq), 0, w);
-                        w = __builtin_amdgcn_cvt_pk_u8_f32(clampf(r[1] + oz, 0.f, oq), 1, w);
-                        *reinterpret_cast<uint16_t*>(reinterpret_cast<int8_t*>(outv) + ro + (col >> 1)) = (uint16_t)(w ^ 0x8080u);
+                        w = __builtin_amdgcn_cvt_pk_u8_f32(clampf(r[0], 0.f, oq), 0, w);
+                        w = __builtin_amdgcn_cvt_pk_u8_f32(clampf(r[1], 0.f, oq), 1, w);
+                        pk[g][0] = w ^ 0x8080u;
                     } else {
                         float q[4];
-                        rint_div_n<4>(v, od, oi, q);
+                        if constexpr (MODE == 1) rint_div_n<4>(v, od, oi, q);
+                        else rint_div_zp_n<4>(v, od, oi, oz, q);
                         if constexpr (MODE == 1) {         // f16 operand code - zp: clamp(r + zp, 0, qmax) - zp in one med3
 #pragma unroll
                             for (int e = 0; e < 4; ++e) q[e] = clampf(q[e], -oz, oq - oz);
                             __half2 h0 = __floats2half2_rn(q[0], q[1]), h1 = __floats2half2_rn(q[2], q[3]);
-                            uint2 pk;
-                            pk.x = *reinterpret_cast<uint32_t*>(&h0);
-                            pk.y = *reinterpret_cast<uint32_t*>(&h1);
-                            *reinterpret_cast<uint2*>(reinterpret_cast<__half*>(outv) + ro + col) = pk;
+                            pk[g][0] = *reinterpret_cast<uint32_t*>(&h0);
+                            pk[g][1] = *reinterpret_cast<uint32_t*>(&h1);
                         } else {                           // int8 operand code - 128
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) q[e] = clampf(q[e] + oz, 0.f, oq);
-                            *reinterpret_cast<uint32_t*>(reinterpret_cast<int8_t*>(outv) + ro + col) = pack_codes_i8(q);
+                            for (int e = 0; e < 4; ++e) q[e] = clampf(q[e], 0.f, oq);
+                            pk[g][0] = pack_codes_i8(q);
                         }
                     }
+                }
+                // this lane keeps groups {0,1} (low lane) or {2,3} (high lane) of both lanes, interleaved by column
+                const int64_t cb = col0 + j * 32;          // first column of the 32-column block
+                if constexpr (MODE == 2) {
+                    const uint32_t s0 = hi ? pk[0][0] : pk[2][0], s1 = hi ? pk[1][0] : pk[3][0];
+                    const uint32_t r0 = __shfl_xor(s0, 32, 64), r1 = __shfl_xor(s1, 32, 64);
+                    uint4 w;                               // columns 16 hi .. 16 hi + 15: [lo g, hi g, lo g+1, hi g+1]
+                    w.x = hi ? r0 : pk[0][0]; w.y = hi ? pk[2][0] : r0; w.z = hi ? r1 : pk[1][0]; w.w = hi ? pk[3][0] : r1;
+                    *reinterpret_cast<uint4*>(reinterpret_cast<int8_t*>(outv) + ro + cb + (hi ? 16 : 0)) = w;
+                } else if constexpr (MODE == 3) {
+                    const uint32_t mine = hi ? (pk[2][0] | (pk[3][0] << 16)) : (pk[0][0] | (pk[1][0] << 16));
+                    const uint32_t send = hi ? (pk[0][0] | (pk[1][0] << 16)) : (pk[2][0] | (pk[3][0] << 16));
+                    const uint32_t got = __shfl_xor(send, 32, 64);
+                    // output bytes 8 hi .. 8 hi + 7 of the block's 16: [lo g (2 B), hi g (2 B), lo g+1, hi g+1]
+                    const uint32_t lo_w = hi ? got : mine, hi_w = hi ? mine : got;
+                    uint2 w;
+                    w.x = (lo_w & 0xffffu) | (hi_w << 16);
+                    w.y = (lo_w >> 16) | (hi_w & 0xffff0000u);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<int8_t*>(outv) + ro + (cb >> 1) + (hi ? 8 : 0)) = w;
+                } else {
+                    uint32_t rcv[4];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+                            rcv[2 * k + h] = __shfl_xor(hi ? pk[k][h] : pk[2 + k][h], 32, 64);
+                    // f16 columns 16 hi .. 16 hi + 15 (32 bytes): [lo g (8 B), hi g (8 B), lo g+1, hi g+1]
+                    uint4 w0, w1;
+                    w0.x = hi ? rcv[0] : pk[0][0]; w0.y = hi ? rcv[1] : pk[0][1]; w0.z = hi ? pk[2][0] : rcv[0]; w0.w = hi ? pk[2][1] : rcv[1];
+                    w1.x = hi ? rcv[2] : pk[1][0]; w1.y = hi ? rcv[3] : pk[1][1]; w1.z = hi ? pk[3][0] : rcv[2]; w1.w = hi ? pk[3][1] : rcv[3];
+                    uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<__half*>(outv) + ro + cb + (hi ? 16 : 0));
+                    dst[0] = w0;
+                    dst[1] = w1;
                 }
             }
         }

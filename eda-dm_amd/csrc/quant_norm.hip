@@ -28,9 +28,9 @@ __device__ __forceinline__ uint32_t pack4_i8(int a, int b, int c, int d) {
 __device__ __forceinline__ uint32_t quant4(const float4& v, const QP& q) {
     const float x[4] = {v.x, v.y, v.z, v.w};
     float r[4];
-    rint_div_n<4>(x, q.d, q.inv, r);
+    rint_div_zp_n<4>(x, q.d, q.inv, q.z, r);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) r[e] = clampf(r[e] + q.z, 0.f, q.qmax);
+    for (int e = 0; e < 4; ++e) r[e] = clampf(r[e], 0.f, q.qmax);
     return pack_codes_i8(r);
 }
 
