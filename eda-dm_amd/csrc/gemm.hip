@@ -1262,6 +1262,12 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
     else if (N <= 64) tn = 1;
     int tm = 2;
     if (M <= 64) tm = 1;
+    {   // few 128-row tiles (the 8x8 level: 250 for 256 CUs with room for two workgroups each): 64-row tiles double the
+        // resident workgroups per CU, which is what hides the operand latency there
+        static const int64_t thr = getenv("EDADM_GEMM_TM1_BELOW") ? atoll(getenv("EDADM_GEMM_TM1_BELOW")) : 0;
+        const int64_t t128 = ((M + 127) / 128) * ((N + 64 * tn - 1) / (64 * tn)) * batch;
+        if (t128 < thr) tm = 1;
+    }
     // large-M layers: 256-row, 8-wave tile when it still fills the 256 CUs
     const int64_t tiles8 = ((M + 255) / 256) * ((N + 64 * tn - 1) / (64 * tn)) * batch;
     // convolutions whose Cin is a multiple of 64 but not of 128 keep scalar tap arithmetic only with 64-byte K-steps
