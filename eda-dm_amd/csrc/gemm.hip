@@ -370,7 +370,7 @@ template <int DT, int TM, int TN, int BN, int RA>
 __device__ __forceinline__ void gemm_epilogue_qdirect(typename Acc<DT>::type (&acc)[TM][TN], const float* ec, int lane,
                                                       int64_t row0, int64_t col0, int ecol0, void* __restrict__ outv,
                                                       int64_t ldo, int out_mode, const float* __restrict__ residual = nullptr,
-                                                      int64_t ldr = 0) {
+                                                      int64_t ldr = 0, int64_t rows_per_batch = 1, int64_t N = 0) {
     const int fr = lane & 31, fh4 = (lane >> 5) * 4;
     const float od = ec[(2 + RA) * BN], oz = ec[(2 + RA) * BN + 1], oq = ec[(2 + RA) * BN + 2];
     const float oi = 1.0f / od;
@@ -416,6 +416,18 @@ __device__ __forceinline__ void gemm_epilogue_qdirect(typename Acc<DT>::type (&a
                         w = __builtin_amdgcn_cvt_pk_u8_f32(clampf(r[0], 0.f, oq), 0, w);
                         w = __builtin_amdgcn_cvt_pk_u8_f32(clampf(r[1], 0.f, oq), 1, w);
                         pk[g][0] = w ^ 0x8080u;
+                    } else if constexpr (MODE == 4) {
+                        // f16 codes stored TRANSPOSED per image: out[b][col][row in image] -- the B operand of the
+                        // attention P.V product, written by the v projection itself (no transpose pass).  A lane's
+                        // 32 neighbours hold consecutive rows: 64 contiguous bytes per column.
+                        float q[4];
+                        rint_div_n<4>(v, od, oi, q);
+                        const int64_t m = row0 + i * 32;                           // wave-uniform: 32 | rows_per_batch
+                        const int64_t bimg = m / rows_per_batch;
+                        __half* dst = reinterpret_cast<__half*>(outv) + (bimg * N + col0 + j * 32 + 8 * g + fh4) * ldo +
+                                      (m - bimg * rows_per_batch) + fr;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dst[e * ldo] = __float2half(clampf(q[e], -oz, oq - oz));
                     } else {
                         float q[4];
                         if constexpr (MODE == 1) rint_div_n<4>(v, od, oi, q);
@@ -441,6 +453,8 @@ __device__ __forceinline__ void gemm_epilogue_qdirect(typename Acc<DT>::type (&a
                     uint4 w;                               // columns 16 hi .. 16 hi + 15: [lo g, hi g, lo g+1, hi g+1]
                     w.x = hi ? r0 : pk[0][0]; w.y = hi ? pk[2][0] : r0; w.z = hi ? r1 : pk[1][0]; w.w = hi ? pk[3][0] : r1;
                     *reinterpret_cast<uint4*>(reinterpret_cast<int8_t*>(outv) + ro + cb + (hi ? 16 : 0)) = w;
+                } else if constexpr (MODE == 4) {
+                    // stored per register group above
                 } else if constexpr (MODE == 3) {
                     const uint32_t mine = hi ? (pk[2][0] | (pk[3][0] << 16)) : (pk[0][0] | (pk[1][0] << 16));
                     const uint32_t send = hi ? (pk[0][0] | (pk[1][0] << 16)) : (pk[2][0] | (pk[3][0] << 16));
@@ -471,6 +485,7 @@ __device__ __forceinline__ void gemm_epilogue_qdirect(typename Acc<DT>::type (&a
     };
     if (out_mode == 1) body(std::integral_constant<int, 1>{});
     else if (out_mode == 2) body(std::integral_constant<int, 2>{});
+    else if (out_mode == 4) body(std::integral_constant<int, 4>{});
     else body(std::integral_constant<int, 3>{});
 }
 
@@ -683,7 +698,7 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
 
     if (qdirect) {
         gemm_epilogue_qdirect<DT, TM, TN, BN, RA>(acc, ec, lane, m0 + wm * (TM * 32), n0 + wn * (TN * 32), wn * (TN * 32), out, ldo,
-                                                  out_mode, residual, ldr);
+                                                  out_mode, residual, ldr, rows_per_batch, N);
         return;
     }
     if (direct) {
@@ -883,7 +898,7 @@ k_gemm_nt8(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, cons
     STAMP(t_main);
     if (qdirect) {
         gemm_epilogue_qdirect<DT, TM, TN, BN, RA>(acc, ec, lane, m0 + wm * 64, n0 + wn * (TN * 32), wn * (TN * 32), out, ldo, out_mode,
-                                                  residual, ldr);
+                                                  residual, ldr, rows_per_batch, N);
     } else if (direct) {
         EpiRegs<TN> er;
         load_epi_regs<TN, BN>(er, ec, lane, m0, m0 + wm * 64, wn * (TN * 32), rows_per_batch);
@@ -1202,7 +1217,7 @@ k_gemm_p(const uint8_t* __restrict__ A, int64_t lda_b, const uint8_t* __restrict
                 const float* ec = ec_all + (T % 3) * ECN;
                 if constexpr (decltype(swp)::value) {
                     gemm_epilogue_qdirect<DT, TM, TN, BN, RA>(acc, ec, lane, m0 + wm * 64, n0 + wn * (TN * 32), wn * (TN * 32), out,
-                                                              ldo, out_mode, residual, ldr);
+                                                              ldo, out_mode, residual, ldr, rows_per_batch, N);
                 } else {
                     EpiRegs<TN> er;
                     load_epi_regs<TN, BN>(er, ec, lane, m0, m0 + wm * 64, wn * (TN * 32), rows_per_batch);
@@ -1241,7 +1256,11 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
                        int64_t sC, int64_t batch, float alpha, hipStream_t st, int inner = 1, int64_t sAi = 0,
                        int64_t sBi = 0, int64_t sCi = 0, int out_mode = 0, const float* oqp = nullptr,
                        float* gn_ws = nullptr, int64_t gn_hw = 0) {
-    if (out_mode != 0 && (!oqp || (N & 3) || (ldo & 3))) return EDADM_EINVAL;   // quantised outputs use the 16-byte path
+    if (out_mode != 0 && (!oqp || (N & 3) || (out_mode != 4 && (ldo & 3)))) return EDADM_EINVAL;   // quantised outputs use the 16-byte path
+    if (out_mode == 4) {                             // the transposed store exists in the register-direct epilogue only
+        const int tn_ = N % 192 == 0 ? 3 : 2;
+        if (batch != 1 || M % 128 || N % (64 * tn_)) return EDADM_EINVAL;
+    }
     if (gn_ws) {
         // GroupNorm partials come from the register-direct epilogue only: every tile must be full and the 64-row wave
         // slabs must not straddle images (gn_ws is [M / 64][N][2])
@@ -1250,7 +1269,7 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
             (rowadd && rpb < 64))
             return EDADM_EINVAL;
     }
-    if (!rowadd) rpb = M;                                    // one (unused) batch entry
+    if (!rowadd && out_mode != 4) rpb = M;                   // one (unused) batch entry (mode 4: rows of one image)
     static bool pad_ready = false;
     if (!pad_ready) {       // stream-ordered ahead of the first GEMM; idempotent if it lands inside a captured graph
         hipLaunchKernelGGL(k_init_pad_rows, dim3(1), dim3(256), 0, st);
@@ -1303,7 +1322,8 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
 #undef EDADM_GEMMP_CASE
         }
     }
-    if (force != 2 && EDADM_USE_NT8 && (force == 3 || (tiles8 >= 224 && Kb >= 256)) && nt8_gather_ok) {
+    if (force != 2 && EDADM_USE_NT8 && (force == 3 || (tiles8 >= 224 && Kb >= 256)) && nt8_gather_ok &&
+        !(out_mode == 4 && M % 256)) {
         const dim3 grid8((unsigned)((N + 64 * tn - 1) / (64 * tn)), (unsigned)((M + 255) / 256), (unsigned)batch);
 #define EDADM_GEMM8_CASE(TN_)                                                                                  \
         if (tn == TN_) {                                                                                       \
@@ -1422,7 +1442,10 @@ extern "C" int edadm_qgemm_i8_q(const int8_t* A, int64_t lda, const int8_t* Wt, 
                                 const float* rowadd, int64_t rows_per_batch, const float* residual, int64_t ldr,
                                 void* out, int64_t ldo, int out_mode, const float* oqp, void* stream) {
     if (!A || !Wt || !out || !scale || M <= 0 || N <= 0 || K <= 0 || (K & 15) || (ldw & 15)) return EDADM_EINVAL;
-    if (out_mode < 1 || out_mode > 3 || !oqp) return EDADM_EINVAL;
+    if (out_mode < 1 || out_mode > 4 || !oqp) return EDADM_EINVAL;
+    if (out_mode == 4 && (rowadd || residual || rows_per_batch <= 0 || (rows_per_batch & 31) || M % rows_per_batch ||
+                          ldo < rows_per_batch))
+        return EDADM_EINVAL;                       // transposed f16 codes: out[b][n][m - b rows_per_batch], ld = ldo
     if (((uintptr_t)A & 15) || ((uintptr_t)Wt & 15)) return EDADM_EINVAL;
     ConvGeom g{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (geom) {

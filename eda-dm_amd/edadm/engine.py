@@ -242,7 +242,7 @@ class Engine:
             assert L.mode == "i8" and len(L.segs) == 1 and geom is None
             s0 = L.segs[0]
             run = lambda: ops.qgemm_i8_q(a, s0["w"], M, L.N, s0["K"], s0["scale"], L.bias, out_mode, oqp, lda=a.shape[-1],
-                                         residual=residual)
+                                         residual=residual, rows_per_batch=rpb)
             if self.prof is not None:       # bench.py's roofline pass re-launches each recorded GEMM under HIP events
                 self.prof.append((L.mode, L.name, M, L.N, L.K, 2.0 * M * L.N * L.K, run))
             return run()
@@ -362,7 +362,7 @@ class Engine:
         return self._attn_cache[key]
 
     def attention(self, q2d, k2d, v2d, B, Nq, Nk, heads, d, aq_q, aq_k, aq_v, aq_w, scale, premul=1.0,
-                  qcols=None, kcols=None, vcols=None, coded=False, out_qp=None):
+                  qcols=None, kcols=None, vcols=None, coded=False, out_qp=None, v_transposed=False):
         """q2d [B*Nq][*], k2d/v2d [B*Nk][*]: fp32 (quantised here) or, with coded=True, the f16 operands
         already emitted by the projection epilogues.  Head h of q lives at columns qcols[h]..+d.
         Returns fp32 [B*Nq][heads*d], or the int8 operand of the consumer when out_qp is given."""
@@ -393,9 +393,13 @@ class Engine:
                             strideA_i=d, strideB_i=d)
         nkp = (Nk + 7) // 8 * 8
         p = ops.softmax_quant_f16(s.reshape(B * heads * Nq, Nk), qpw, ldo=nkp)
-        vt = torch.empty(B, heads, d, nkp, dtype=torch.float16, device=self.dev)
-        for h in range(heads):
-            ops.transpose_f16(vh[:, h * d:], hd, Nk * hd, B, Nk, d, nkp, out=vt[:, h], strideO=heads * d * nkp)
+        if v_transposed:                                    # [B][heads*d][Nk] straight from the projection epilogue
+            assert nkp == Nk
+            vt = vh
+        else:
+            vt = torch.empty(B, heads, d, nkp, dtype=torch.float16, device=self.dev)
+            for h in range(heads):
+                ops.transpose_f16(vh[:, h * d:], hd, Nk * hd, B, Nk, d, nkp, out=vt[:, h], strideO=heads * d * nkp)
         kw = dict(inner=heads, strideA_i=Nq * nkp, strideB_i=d * nkp, ldc=hd, strideC=Nq * hd, strideC_i=d)
         if out_qp is not None and hd % 4 == 0:
             out = torch.empty(B * Nq, hd, dtype=torch.int8, device=self.dev)
@@ -539,14 +543,17 @@ class Engine:
         """x2d_q: int8 operand for to_q; ctx_ops: (operand for to_k, operand for to_v)."""
         q = self._gemm(self.L(attn.to_q), x2d_q, B * Nq, out_mode=1, oqp=self._aq(attn.act_quantizer_q)[0])
         k = self._gemm(self.L(attn.to_k), ctx_ops[0], B * Nk, out_mode=1, oqp=self._aq(attn.act_quantizer_k)[0])
-        v = self._gemm(self.L(attn.to_v), ctx_ops[1], B * Nk, out_mode=1, oqp=self._aq(attn.act_quantizer_v)[0])
+        Lv = self.L(attn.to_v)
+        vt_ok = Lv.mode == "i8" and len(Lv.segs) == 1 and ops.vt_mode_ok(B * Nk, Lv.N, Nk)
+        # the v projection writes the P.V product's B operand directly: f16 codes, transposed per image
+        v = self._gemm(Lv, ctx_ops[1], B * Nk, out_mode=4 if vt_ok else 1, oqp=self._aq(attn.act_quantizer_v)[0], rpb=Nk)
         heads = attn.heads
         d = q.shape[1] // heads
         Lo = self.L(attn.to_out[0])
         fuse = Lo.mode == "i8" and not Lo.split
         o = self.attention(q, k, v, B, Nq, Nk, heads, d, attn.act_quantizer_q, attn.act_quantizer_k,
                            attn.act_quantizer_v, attn.act_quantizer_w, attn.scale, coded=True,
-                           out_qp=Lo.qp if fuse else None)
+                           out_qp=Lo.qp if fuse else None, v_transposed=vt_ok)
         return self.lin(attn.to_out[0], None if fuse else o, residual=residual, pre=o if fuse else None)
 
     def ldm_transformer(self, st, x, context):

@@ -414,7 +414,12 @@ def qgemm_f16(A, Wt, M, N, K, scale, bias, out, geom=None, lda=None, ldw=None, r
     return out
 
 
-_OUT_DT = {1: torch.float16, 2: torch.int8, 3: torch.int8}
+_OUT_DT = {1: torch.float16, 2: torch.int8, 3: torch.int8, 4: torch.float16}
+
+
+def vt_mode_ok(M, N, rows_per_batch):
+    """can the v projection write its f16 operand transposed per image (edadm_qgemm_i8_q out_mode 4)?"""
+    return rows_per_batch % 32 == 0 and M % rows_per_batch == 0 and M % 128 == 0 and N % (192 if N % 192 == 0 else 128) == 0
 
 
 def qgemm_i8_q(A, Wt, M, N, K, scale, bias, out_mode, oqp, geom=None, lda=None, ldw=None, rowadd=None,
@@ -424,7 +429,11 @@ def qgemm_i8_q(A, Wt, M, N, K, scale, bias, out_mode, oqp, geom=None, lda=None, 
     lda = K if lda is None else lda
     ldw = K if ldw is None else ldw
     ncol = N // 2 if out_mode == 3 else N
-    out = torch.empty(M, ncol, dtype=_OUT_DT[out_mode], device=A.device)
+    if out_mode == 4:                                      # [B][N][rows_per_batch]
+        out = torch.empty(M // rows_per_batch, N, rows_per_batch, dtype=torch.float16, device=A.device)
+        ncol = rows_per_batch
+    else:
+        out = torch.empty(M, ncol, dtype=_OUT_DT[out_mode], device=A.device)
     gptr = ctypes.cast(geom, ctypes.c_void_p) if geom is not None else None
     lib.call("edadm_qgemm_i8_q", ctypes.c_void_p(A.data_ptr()), int(lda), ctypes.c_void_p(Wt.data_ptr()), int(ldw),
              int(M), int(N), int(K), gptr, _pf(scale), _pf(bias), _pf(rowadd), int(rows_per_batch), _pf(residual),

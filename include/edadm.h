@@ -207,8 +207,11 @@ int edadm_qgemm_f16(const void* A, int64_t lda, const void* Wt, int64_t ldw, int
 /* Variants whose epilogue feeds the consuming activation quantizer directly (no fp32 round trip through
  * HBM): out_mode 1 -> f16 operand (code - zp) [M][N]; 2 -> int8 operand (code - 128) [M][N]; 3 (i8 only)
  * -> GEGLU a*gelu(gate) over INTERLEAVED (a_j, gate_j) output columns, then int8 operand [M][N/2]
- * (ldm/modules/attention.py:37-45 followed by quant_layer.py:266-269).  oqp = device float[3]
- * {delta, zero_point, qmax} of that quantizer; ldo counts output elements. */
+ * (ldm/modules/attention.py:37-45 followed by quant_layer.py:266-269); 4 (i8 only) -> the f16 operand of mode 1
+ * stored TRANSPOSED per image, out[b][n][m - b*rows_per_batch] with row length ldo: the [d][Nk] B operand of the
+ * attention P.V product written by the v projection itself (rows_per_batch % 32 == 0, M % 128 == 0, N a multiple
+ * of the 128/192 tile, no rowadd / residual).  oqp = device float[3] {delta, zero_point, qmax} of that quantizer;
+ * ldo counts output elements. */
 int edadm_qgemm_i8_q(const int8_t* A, int64_t lda, const int8_t* Wt, int64_t ldw, int64_t M, int64_t N,
                      int64_t K, const int32_t* geom, const float* scale, const float* bias,
                      const float* rowadd, int64_t rows_per_batch, const float* residual, int64_t ldr,

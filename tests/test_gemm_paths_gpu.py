@@ -119,3 +119,17 @@ def test_qgemm_groupnorm_partials(ops, B, HW, N, K):
     want = ops.groupnorm_stats(ops.Cat(x, other), G, 1e-5)
     got = ops.groupnorm_final(ws, N, ws_o, 64, B, HW, G, 1e-5)
     assert ((got - want).abs() <= 2e-5 * want.abs().clamp_min(1.0)).all(), float((got - want).abs().max())
+
+
+@pytest.mark.parametrize("B,Nk,N,K", [(56, 1024, 384, 384), (50, 64, 960, 960), (7, 256, 576, 192)])
+def test_qgemm_transposed_f16_output(ops, B, Nk, N, K):
+    """out_mode 4: the f16 operand of mode 1, stored transposed per image ([B][N][Nk]) -- bit-identical codes."""
+    M = B * Nk
+    A, W, scale, bias, g = _mk(M, N, K, M + 7 * N + K)
+    qp = ops.qp_tensor([(0.041, 123.0, 255.0)], "cuda")
+    args = (A.cuda(), W.cuda(), M, N, K, (scale * 4).cuda(), bias.cuda())
+    assert ops.vt_mode_ok(M, N, Nk)
+    plain = ops.qgemm_i8_q(*args, 1, qp)                                   # [M][N]
+    tr = ops.qgemm_i8_q(*args, 4, qp, rows_per_batch=Nk)                   # [B][N][Nk]
+    assert tr.shape == (B, N, Nk)
+    assert torch.equal(tr, plain.reshape(B, Nk, N).transpose(1, 2))
