@@ -111,6 +111,7 @@ class Engine:
             if isinstance(m, QuantModule):
                 self.layers[id(m)] = FrozenLayer(m, name)
         self._attn_cache = {}
+        self.one_token_context = os.environ.get("EDADM_ONE_TOKEN_CONTEXT", "1") != "0"
         self.gn_from_producer = os.environ.get("EDADM_GN_FROM_PRODUCER", "0") == "1"   # measured slower (58.4 vs 61.7 img/s): off
         self.graph = None
         self.prof = None
@@ -566,15 +567,27 @@ class Engine:
             oq, ok, ov = self.ln(blk.norm1, t, (a1.to_q, a1.to_k, a1.to_v))
             t = self.ldm_cross_attn(a1, oq, (ok, ov), B, N, N, residual=t)
             a2 = blk.attn2
-            (oq,) = self.ln(blk.norm2, t, (a2.to_q,))
-            if context is None:
-                ok, ov = self.ln(blk.norm2, t, (a2.to_k, a2.to_v))
-                nk = N
-            else:
+            if context is not None and context.shape[1] == 1 and self.one_token_context:
+                # One-token context (class-conditional LDM): softmax over a single key is exactly 1 for every query,
+                # so the branch's output is ONE vector per image.  It is computed for one query row per image through
+                # the same kernels (q/k/v projections, products, quantisers, to_out -- the same codes) and broadcast:
+                # bit-identical to evaluating it for all N tokens, at 1/N of the work.
+                t0 = t.reshape(B, N, C)[:, 0].contiguous()
+                (oq,) = self.ln(blk.norm2, t0, (a2.to_q,))
                 c2 = context.reshape(-1, context.shape[-1]).contiguous()
                 ok, ov = self._quant(self.L(a2.to_k), c2), self._quant(self.L(a2.to_v), c2)
-                nk = context.shape[1]
-            t = self.ldm_cross_attn(a2, oq, (ok, ov), B, N, nk, residual=t)
+                r = self.ldm_cross_attn(a2, oq, (ok, ov), B, 1, 1, residual=None)             # [B][C]
+                t = ops.add_rowbcast(t, r, N)
+            else:
+                (oq,) = self.ln(blk.norm2, t, (a2.to_q,))
+                if context is None:
+                    ok, ov = self.ln(blk.norm2, t, (a2.to_k, a2.to_v))
+                    nk = N
+                else:
+                    c2 = context.reshape(-1, context.shape[-1]).contiguous()
+                    ok, ov = self._quant(self.L(a2.to_k), c2), self._quant(self.L(a2.to_v), c2)
+                    nk = context.shape[1]
+                t = self.ldm_cross_attn(a2, oq, (ok, ov), B, N, nk, residual=t)
             ff0, ff2 = blk.ff.net[0].proj, blk.ff.net[2]
             (of,) = self.ln(blk.norm3, t, (ff0,))
             L0, L2 = self.L(ff0), self.L(ff2)

@@ -329,6 +329,14 @@ def add(a, b):
     return out
 
 
+def add_rowbcast(x2d, r, rows_per_batch, out=None):
+    """x2d[m] + r[m // rows_per_batch] (a per-image vector added to every row of the image)."""
+    rows, C = x2d.shape
+    out = torch.empty_like(x2d) if out is None else out
+    lib.call("edadm_add_rowbcast", _pf(x2d), _pf(r), _pf(out), rows, C, int(rows_per_batch), _stream())
+    return out
+
+
 def concat_c(a, b):
     Ca, Cb = a.shape[-1], b.shape[-1]
     rows = a.numel() // Ca

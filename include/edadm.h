@@ -165,6 +165,11 @@ int edadm_geglu_quant_i8(const float* x, int8_t* out, int64_t rows, int64_t inne
                          void* stream);
 int edadm_silu(const float* x, float* out, int64_t n, void* stream);
 int edadm_add(const float* a, const float* b, float* out, int64_t n, void* stream);
+/* out[m][c] = x[m][c] + r[m / rows_per_batch][c] (C % 4 == 0): the cross-attention branch over a ONE-token context
+ * (class-conditional LDM, ldm/modules/attention.py:168-194 with context [B,1,D]) is one vector per image -- softmax over
+ * a single key is exactly 1 for every query -- so it is computed for one query row per image and broadcast */
+int edadm_add_rowbcast(const float* x, const float* r, float* out, int64_t rows, int64_t C, int64_t rows_per_batch,
+                       void* stream);
 int edadm_concat_c(const float* a, int64_t Ca, const float* b, int64_t Cb, float* out, int64_t rows,
                    void* stream);
 int edadm_avgpool2_nhwc(const float* x, float* out, int64_t B, int64_t H, int64_t W, int64_t C, void* stream);

@@ -44,3 +44,20 @@ def test_quantised_forward_matches_reference(golden, kind):
         assert qnn.engine is not None
         _cmp("int8 engine vs reference", out, g["out_q"], 5e-2, 5e-3)
         _cmp("int8 engine vs fake-quant graph", out, fq.cpu().numpy(), 5e-2, 5e-3)
+
+
+def test_one_token_context_shortcut_is_bit_exact(golden):
+    """Class-conditional LDM: the context is ONE token, softmax over a single key is exactly 1 for every query, so the
+    cross-attention branch is one vector per image.  The engine computes it for one query row per image and
+    broadcasts (edadm_add_rowbcast); evaluating it for all tokens must give the same bits."""
+    g = golden("g13_ldm_imagenet")
+    qnn, (x, t, ctx), _ = quantize_like_reference(build_ldm(g), g, "ldm")
+    assert ctx.shape[1] == 1
+    qnn.set_quant_state(True, True)
+    with torch.no_grad():
+        eng = qnn.freeze()
+        assert eng.one_token_context
+        short = eng(x, t, ctx)
+        eng.one_token_context = False
+        full = eng(x, t, ctx)
+    assert torch.equal(short, full)
