@@ -533,7 +533,7 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
     const int wm = wave >> 1, wn = wave & 1;
-    const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+    const int64_t m0 = (int64_t)blockIdx.y * BM + g.r0, n0 = (int64_t)blockIdx.x * BN;   // g.r0: first row of a tail launch
     {   // batch index z = outer * inner + head: (batch, head) views of [B][N][heads*d] tensors
         const int64_t zo = blockIdx.z / inner, zi = blockIdx.z % inner;
         A += zo * strideA_b + zi * strideA_i;
@@ -1324,7 +1324,44 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
     }
     if (force != 2 && EDADM_USE_NT8 && (force == 3 || (tiles8 >= 224 && Kb >= 256)) && nt8_gather_ok &&
         !(out_mode == 4 && M % 256)) {
-        const dim3 grid8((unsigned)((N + 64 * tn - 1) / (64 * tn)), (unsigned)((M + 255) / 256), (unsigned)batch);
+        // Tail re-tiling: one workgroup per CU means the launch runs in rounds of #CU tiles, and a last round that is
+        // mostly empty costs a full round (300 tiles on 256 CUs: 2 rounds for 1.17 rounds of work).  The m-tiles that
+        // fill whole rounds go to this kernel; the remaining rows go to the 128-row, two-per-CU kernel in a second
+        // launch (same arithmetic, same epilogue, rows offset by g.r0).
+        static const int tailsplit = getenv("EDADM_GEMM_TAILSPLIT") ? atoi(getenv("EDADM_GEMM_TAILSPLIT")) : 1;
+        int64_t m_main = M;
+        if (DT == 0 && tailsplit && batch == 1 && M % 256 == 0 && !gn_ws && tn >= 2) {
+            static int ncu8 = 0;
+            if (!ncu8) {
+                int dev = 0;
+                (void)hipGetDevice(&dev);
+                (void)hipDeviceGetAttribute(&ncu8, hipDeviceAttributeMultiprocessorCount, dev);
+            }
+            const int64_t nt_ = (N + 64 * tn - 1) / (64 * tn);
+            const int64_t rounds = tiles8 / ncu8, rem = tiles8 % ncu8;
+            const int64_t mt_main = rounds * ncu8 / nt_;
+            if (rounds >= 1 && rem > 0 && rem * 10 <= (int64_t)ncu8 * 6 && mt_main > 0 && mt_main * 256 < M)
+                m_main = mt_main * 256;
+        }
+        const dim3 grid8((unsigned)((N + 64 * tn - 1) / (64 * tn)), (unsigned)((m_main + 255) / 256), (unsigned)batch);
+        if (m_main != M) {
+            ConvGeom gt = g;
+            gt.r0 = (int)m_main;
+            const dim3 gridt(grid8.x, (unsigned)((M - m_main) / 128), 1);
+#define EDADM_GEMM8T_CASE(TN_)                                                                                 \
+            if (tn == TN_) {                                                                                   \
+                hipLaunchKernelGGL((k_gemm_nt8<DT, TN_>), grid8, dim3(512), 0, st, (const uint8_t*)A, lda_b, sA, \
+                                   (const uint8_t*)Bm, ldb_b, sB, m_main, N, Kb, g, scale, bias, rowadd, rpb,  \
+                                   residual, ldr, out, ldo, sC, alpha, inner, sAi, sBi, sCi, out_mode, oqp, gn_ws); \
+                hipLaunchKernelGGL((k_gemm_nt<DT, 2, TN_>), gridt, dim3(256), 0, st, (const uint8_t*)A, lda_b, sA, \
+                                   (const uint8_t*)Bm, ldb_b, sB, M, N, Kb, gt, scale, bias, rowadd, rpb, residual, \
+                                   ldr, out, ldo, sC, alpha, inner, sAi, sBi, sCi, out_mode, oqp, gn_ws);     \
+                return edadm_launch_status();                                                                  \
+            }
+            EDADM_GEMM8T_CASE(3)
+            EDADM_GEMM8T_CASE(2)
+#undef EDADM_GEMM8T_CASE
+        }
 #define EDADM_GEMM8_CASE(TN_)                                                                                  \
         if (tn == TN_) {                                                                                       \
             hipLaunchKernelGGL((k_gemm_nt8<DT, TN_>), grid8, dim3(512), 0, st, (const uint8_t*)A, lda_b, sA,   \
