@@ -1322,7 +1322,11 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
 #undef EDADM_GEMMP_CASE
         }
     }
-    if (force != 2 && EDADM_USE_NT8 && (force == 3 || (tiles8 >= 224 && Kb >= 256)) && nt8_gather_ok &&
+    // K <= 2048 (the 192-channel 3x3 convolutions, ff.net.2): with the register-direct epilogues the 4-wave tile at two
+    // workgroups per CU overlaps one workgroup's output burst with the other's main loop and wins; longer K amortises
+    // the 8-wave tile's smaller operand traffic per flop (tools/gemm_table.py, EDADM_GEMM_FORCE=2 vs 3)
+    static const int64_t nt8_min_kb = getenv("EDADM_NT8_MIN_KB") ? atoll(getenv("EDADM_NT8_MIN_KB")) : 2049;
+    if (force != 2 && EDADM_USE_NT8 && (force == 3 || (tiles8 >= 224 && Kb >= nt8_min_kb)) && nt8_gather_ok &&
         !(out_mode == 4 && M % 256)) {
         // Tail re-tiling: one workgroup per CU means the launch runs in rounds of #CU tiles, and a last round that is
         // mostly empty costs a full round (300 tiles on 256 CUs: 2 rounds for 1.17 rounds of work).  The m-tiles that
