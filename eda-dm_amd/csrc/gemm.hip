@@ -1293,14 +1293,16 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
     const bool nt8_gather_ok = true;
     static const int force = getenv("EDADM_GEMM_FORCE") ? atoi(getenv("EDADM_GEMM_FORCE")) : 0;   // diagnostics only
     if constexpr (DT == 0) {
-        // persistent wave-specialised kernel: full 256-row tiles of the short-K layers (projections, 1x1), where a
-        // per-tile launch spends most of its life in prologue latency and epilogue; measured on the LDM-4 layer mix
-        // the long-K convolutions run as fast or faster on k_gemm_nt8 (tools/gemm_table.py)
+        // persistent wave-specialised kernel: full 256-row tiles of the short-K, wide-N layers (the GEGLU projections:
+        // many N tiles re-use each A block from L2), where a per-tile launch spends most of its life in prologue latency
+        // and epilogue.  Measured on the LDM-4 layer mix (tools/gemm_table.py, EDADM_GEMM_FORCE=2/3/5): narrow short-K
+        // layers are as fast or faster on the 4-wave kernel since the register-direct epilogues, long-K convolutions
+        // on k_gemm_nt8.
         const int kstep = force == 6 ? 128 : 64;
         const int64_t ptiles = (M / 256) * (N / (64 * tn));
         if (force != 2 && force != 3 && !gn_ws && batch == 1 && inner == 1 && tn >= 2 && M % 256 == 0 && N % (64 * tn) == 0 &&
             (Kb + kstep - 1) / kstep >= 3 && (!rowadd || rpb >= 64) && (out_mode == 0 || (!rowadd && (!residual || !(ldr & 3)))) &&
-            (force >= 5 || (ptiles >= 224 && Kb <= 1024)) && (g.mode == 0 || (int64_t)g.B * g.H * g.W * g.Cin < (1ll << 31))) {
+            (force >= 5 || (ptiles >= 224 && Kb <= 1024 && N >= 1024)) && (g.mode == 0 || (int64_t)g.B * g.H * g.W * g.Cin < (1ll << 31))) {
             static int ncu = 0;
             if (!ncu) {
                 int dev = 0;
