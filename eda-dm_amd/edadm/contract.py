@@ -7,9 +7,13 @@ edadm_im2col_f32 / edadm_col2im_f32 and a split-K transposed product for the wei
     dX        dcols    = dY[m][o] . W^T[k][o]  -> col2im
     dW        dW[o][k] = sum_m dY^T[o][m] . cols^T[k][m]   split over m into S slabs, summed in order
 """
+import os
+
 import torch
 
 from . import ops
+
+IMPLICIT_DGRAD = os.environ.get("EDADM_IMPLICIT_DGRAD", "1") != "0"
 
 
 def _split(M, O, K):
@@ -133,10 +137,18 @@ class _Conv2dFn(torch.autograd.Function):
         gyh = ops.nchw_to_nhwc(gy.contiguous()).reshape(B * Ho * Wo, O)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gyp, _ = _pad4(gyh)
-            w2t, _ = _pad4(ops.transpose_f32(w2))                                     # [K][O]
-            dcols = _matmul_nt(gyp, w2t)                                               # [M][K]
-            dxh = dcols.reshape(B, H, W, Cp) if one else ops.col2im_f32(dcols, B, H, W, Cp, KH, KW, stride, pad, Ho, Wo)
+            M = B * Ho * Wo
+            big = ((B * H * W + 127) // 128) * ((Cp + 127) // 128) >= 512      # few tiles: the split-K GEMM + col2im wins
+            if IMPLICIT_DGRAD and (not one) and stride == 1 and KH == KW and 2 * pad == KH - 1 and O % 4 == 0 and big:
+                # input gradient of a stride-1 "same" convolution = the same convolution of gy with the spatially
+                # flipped, transposed filter: one implicit GEMM, no [M][K] gradient-of-columns matrix, no col2im pass
+                wf = w2.reshape(O, KH, KW, Cp).flip(1, 2).permute(3, 1, 2, 0).contiguous()      # [Cp][KH][KW][O]
+                dxh = ops.conv2d_f32_nhwc(gyh.reshape(B, Ho, Wo, O), wf, None, stride=1, pad=pad)
+            else:
+                gyp, _ = _pad4(gyh)
+                w2t, _ = _pad4(ops.transpose_f32(w2))                                 # [K][O]
+                dcols = _matmul_nt(gyp, w2t)                                           # [M][K]
+                dxh = dcols.reshape(B, H, W, Cp) if one else ops.col2im_f32(dcols, B, H, W, Cp, KH, KW, stride, pad, Ho, Wo)
             gx = ops.nhwc_to_nchw(dxh[..., :C].contiguous() if Cp != C else dxh)
         if ctx.needs_input_grad[1]:
             cols = xh.reshape(B * H * W, Cp) if one else ops.im2col_f32(xh, KH, KW, stride, pad, Ho, Wo)
