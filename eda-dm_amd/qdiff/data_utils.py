@@ -5,7 +5,16 @@ Per calibration batch: an FP forward up to the unit (its input = `cur_sym`, its 
 and a quantised-prefix forward up to the unit (its input = `cur_inp`).  Everything stays in HBM
 (288 GB per MI355X: `keep_gpu` is accepted for source compatibility and ignored), and with
 torch.distributed initialised the calibration batches are sharded across ranks and the slabs
-all-gathered (edadm/dist.py)."""
+all-gathered (edadm/dist.py).
+
+The FP half of that work does not depend on the quantisation state, so it is not repeated per unit: one FP
+prefix pass per calibration batch records (input, output) of the unit asked for AND of the not yet
+reconstructed units that execute before the pass stops, as many as fit a byte budget (`EDADM_FP_TRACE_GB`,
+default 48 GB of the 288 GB HBM; 0 = one FP pass per unit as in the reference).  Only the quantised-prefix pass,
+whose result changes as units are reconstructed, runs once per unit.  The cached tensors are the same values the
+per-unit pass produces (same kernels, same inputs)."""
+import os
+
 import torch
 
 from qdiff.quant_layer import QuantModule
@@ -76,6 +85,135 @@ class GetLayerInpOut:
         return resblock, input_store, self.data_saver.output_store.detach()
 
 
+def recon_units(module, out=None):
+    """The reconstruction units of a model: first QuantModule / BaseQuantBlock met on every path from the root (the
+    rule both walkers apply, qdiff/recon_block_Qmodel.py:53-76, qdiff_control/recon_block_Qmodel.py:19-36)."""
+    out = [] if out is None else out
+    for m in module.children():
+        if isinstance(m, (QuantModule, BaseQuantBlock)):
+            if not getattr(m, "ignore_reconstruction", False):
+                out.append(m)
+        else:
+            recon_units(m, out)
+    return out
+
+
+STATS = {"fp_passes": 0, "fp_captures": 0, "units_served": 0}    # counters for bench.py / tests
+
+
+class FPTrace:
+    """FP (input, output) pairs of upcoming units, captured ahead of their turn."""
+
+    def __init__(self, key, budget_bytes):
+        self.key, self.budget = key, budget_bytes
+        self.store = {}          # unit -> {batch index: (inputs tuple, output)}
+        self.done = set()
+        self.passes = 0          # FP prefix passes run (one per calibration batch per capture)
+
+    def held_bytes(self):
+        n = 0
+        for per_batch in self.store.values():
+            for inp, out in per_batch.values():
+                n += sum(t.numel() * t.element_size() for t in inp) + out.numel() * out.element_size()
+        return n
+
+    def capture(self, model, layer, batches, device):
+        """One FP pass per batch in `batches` [(index, model_input)]: stores `layer` and every other pending unit
+        that fires before the pass ends, while the projected total stays within the budget."""
+        cands = [u for u in recon_units(model) if u not in self.done and u not in self.store]
+        if layer not in cands:
+            cands.append(layer)
+        held, n_local = self.held_bytes(), max(1, len(batches))
+        group = None
+        model.eval()
+        model.set_quant_state(False, False)
+        eng, model.engine = getattr(model, "engine", None), None
+        try:
+            for i, model_input in batches:
+                first = group is None
+                targets = cands if first else group
+                st = {"bytes": 0, "taken": [], "over": False, "pending": set(targets)}
+
+                def make(u):
+                    def hook(mod, inp, outp):
+                        # clones: the pass continues past the unit, and later in-place ops must not reach the cache
+                        if first:
+                            nb = sum(t.numel() * t.element_size() for t in inp) + outp.numel() * outp.element_size()
+                            if u is not layer and (st["over"] or held + (st["bytes"] + nb) * n_local > self.budget):
+                                st["over"] = True
+                                return
+                            st["bytes"] += nb
+                        tens = tuple(t.detach().clone() for t in inp)
+                        o = outp.detach().clone()
+                        if first:
+                            st["taken"].append(u)
+                            self.store.setdefault(u, {})[i] = (tens, o)
+                            if st["over"] and u is layer:
+                                raise StopForwardException
+                            if u is layer and not any(c is not layer and c not in st["taken"] for c in cands):
+                                raise StopForwardException
+                        else:
+                            self.store[u][i] = (tens, o)
+                            st["pending"].discard(u)
+                            if not st["pending"]:
+                                raise StopForwardException
+                    return hook
+
+                handles = [u.register_forward_hook(make(u)) for u in targets]
+                try:
+                    with torch.no_grad():
+                        model(*[t.to(device) for t in model_input])
+                except StopForwardException:
+                    pass
+                finally:
+                    for h in handles:
+                        h.remove()
+                self.passes += 1
+                STATS["fp_passes"] += 1
+                if first:
+                    if layer not in st["taken"]:
+                        raise RuntimeError("the unit to reconstruct did not execute in the FP forward")
+                    group = list(st["taken"])
+        finally:
+            model.engine = eng
+
+
+def _trace_for(model, cali_data, batch_size, batch_transform):
+    gb = float(os.environ.get("EDADM_FP_TRACE_GB", "48"))
+    if gb <= 0:
+        return None
+    key = (tuple((c.data_ptr(), tuple(c.shape)) for c in cali_data), batch_size, batch_transform)
+    tr = getattr(model, "_fp_trace", None)
+    if tr is None or tr.key != key:
+        tr = FPTrace(key, int(gb * (1 << 30)))
+        model._fp_trace = tr
+    return tr
+
+
+def clear_fp_trace(model):
+    """Drops the look-ahead FP activations (the walkers call this when the walk ends)."""
+    if getattr(model, "_fp_trace", None) is not None:
+        model._fp_trace = None
+
+
+def _quant_prefix_input(model, layer, model_input, device, act_quant):
+    """Input of `layer` under the current quantisation state of the prefix (data_utils.py:141-147 of the reference)."""
+    saver = DataSaverHook(store_input=True, store_output=False, stop_forward=True)
+    model.eval()
+    model.set_quant_state(weight_quant=True, act_quant=act_quant)
+    handle = layer.register_forward_hook(saver)
+    eng, model.engine = getattr(model, "engine", None), None
+    try:
+        with torch.no_grad():
+            model(*[t.to(device) for t in model_input])
+    except StopForwardException:
+        pass
+    finally:
+        model.engine = eng
+        handle.remove()
+    return tuple(t.detach() for t in saver.input_store)
+
+
 def save_inp_oup_data(model, layer, cali_data, asym=False, act_quant=False, batch_size=32, input_prob=False,
                       keep_gpu=True, batch_transform=None):
     """Returns (Resblock, cached_inps, cached_outs) with the reference's tuple nesting (:67-75).
@@ -87,13 +225,30 @@ def save_inp_oup_data(model, layer, cali_data, asym=False, act_quant=False, batc
     mine = edist.shard_batches(n_batches)
     local = {}
     resblock = False
-    for i in mine:
+
+    def batch_of(i):
         batch = [c[i * batch_size:(i + 1) * batch_size] for c in cali_data]
-        if batch_transform is not None:
-            batch = batch_transform(batch)
-        res = get(batch)
-        resblock = res[0]
-        local[i] = res[1:]
+        return batch_transform(batch) if batch_transform is not None else batch
+
+    trace = _trace_for(model, cali_data, batch_size, batch_transform) if mine else None
+    if trace is not None:
+        if layer not in trace.store:
+            trace.capture(model, layer, [(i, batch_of(i)) for i in mine], device)
+            STATS["fp_captures"] += 1
+        STATS["units_served"] += 1
+        fp = trace.store.pop(layer)
+        trace.done.add(layer)
+        pack = GetLayerInpOut._pack
+        for i in mine:
+            sym_in, out = fp.pop(i)
+            resblock = len(sym_in) != 1
+            inp = _quant_prefix_input(model, layer, batch_of(i), device, act_quant) if asym else sym_in
+            local[i] = (pack(inp), out, pack(sym_in)) if input_prob else (pack(inp), out)
+    else:
+        for i in mine:
+            res = get(batch_of(i))
+            resblock = res[0]
+            local[i] = res[1:]
     if n_batches == 0:
         raise ValueError("fewer calibration samples than the caching batch size (%d)" % batch_size)
 

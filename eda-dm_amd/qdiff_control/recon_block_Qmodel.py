@@ -4,6 +4,8 @@ import logging
 
 import torch.nn as nn
 
+from qdiff.data_utils import clear_fp_trace
+
 from qdiff.quant_layer import QuantModule
 from qdiff.quant_block import BaseQuantBlock
 from qdiff_control.block_recon import block_reconstruction
@@ -35,6 +37,9 @@ class recon_block_Qmodel():
                 self.recon_model(m)
 
     def recon(self):
-        self.recon_model(self.model)
+        try:
+            self.recon_model(self.model)
+        finally:
+            clear_fp_trace(self.model)          # look-ahead FP activations of units the walk never reached
         self.model.set_quant_state(weight_quant=True, act_quant=True)
         return self.model

@@ -224,3 +224,62 @@ def test_tdac_generators_ldm(golden, which):
         assert out[3].shape == (N, 1, 16) and out[4].shape == (N, 1, 16) and out[5].shape == (N,)
         nxt = [int(steps[max(int(i) - 1, 0)]) for i in index]
         assert [int(v) for v in out[5]] == nxt
+
+
+def test_fp_trace_matches_per_unit_passes(golden, monkeypatch):
+    """The look-ahead FP activation cache (one FP prefix pass serving several units) returns the tensors of the
+    reference's per-unit double pass (qdiff/data_utils.py:112-150), bit for bit, whatever the byte budget."""
+    from qdiff import QuantModel
+    from qdiff.utils import seed_everything
+    from qdiff_control import set_weight_quantize_params_Conditional, set_act_quantize_params_Conditional
+    from qdiff_control.data_utils import save_inp_oup_data
+    import qdiff.data_utils as du
+    from edadm.latent import LatentDiffusionLite, ClassEmbedder
+    g = golden("g13_ldm_imagenet")
+    seed_everything(7)
+    unet = build_ldm(g)
+    ld = LatentDiffusionLite(unet, linear_start=0.0015, linear_end=0.0195, conditioning_key="crossattn",
+                             cond_stage_model=ClassEmbedder(16, n_classes=1001)).cuda().eval()
+    qnn = QuantModel(ld.model.diffusion_model, WQ4, AQ8, act_quant_mode="qdiff", sm_abit=8).cuda().eval()
+    qnn.set_quant_state(False, False)
+    qnn.set_first_last_layer_to_8bit()
+    qnn.disable_network_output_quantization()
+    qnn.set_grad_ckpt(False)
+    ld.model.diffusion_model = qnn
+    n = 64
+    cali = (torch.randn(n, 3, 8, 8).cuda(), torch.randint(1, 1000, (n,)).cuda(), torch.zeros(n, dtype=torch.long).cuda(),
+            torch.randn(n, 1, 16).cuda(), torch.randn(n, 1, 16).cuda())
+    args = SimpleNamespace(scale=3.0, custom_steps=10, ddim_eta=0.0, lamda=1.2, latent_shape=[3, 8, 8])
+    qnn.model.split_shortcut = True
+    set_weight_quantize_params_Conditional(ld, cali, args)
+    set_act_quantize_params_Conditional(ld, cali, args)
+    units = du.recon_units(qnn)
+    assert len(units) == len(g["units"])
+
+    def flat(r):
+        out = []
+        def walk(v):
+            if torch.is_tensor(v):
+                out.append(v)
+            elif isinstance(v, (list, tuple)):
+                for e in v:
+                    walk(e)
+        walk(r[1:])
+        return r[0], out
+
+    monkeypatch.setenv("EDADM_FP_TRACE_GB", "0")
+    ref = [flat(save_inp_oup_data(qnn, u, cali, True, True, batch_size=32, input_prob=True)) for u in units]
+    for budget, max_sweeps in (("48", 1), ("0.0002", len(units))):       # everything in one sweep / several groups
+        monkeypatch.setenv("EDADM_FP_TRACE_GB", budget)
+        du.clear_fp_trace(qnn)
+        du.STATS.update(fp_passes=0, fp_captures=0, units_served=0)
+        for u, (rb, tens) in zip(units, ref):
+            rb2, tens2 = flat(save_inp_oup_data(qnn, u, cali, True, True, batch_size=32, input_prob=True))
+            assert rb2 == rb and len(tens2) == len(tens)
+            for a, b in zip(tens, tens2):
+                assert a.shape == b.shape and torch.equal(a, b)
+        assert du.STATS["units_served"] == len(units) and 1 <= du.STATS["fp_captures"] <= max_sweeps
+        if budget == "0.0002":
+            assert 1 < du.STATS["fp_captures"] < len(units)
+        assert not qnn._fp_trace.store                                      # everything handed out
+        du.clear_fp_trace(qnn)
