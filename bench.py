@@ -123,7 +123,9 @@ def time_calibration(qnn, dev, n_calib=64, iters=3):
     import qdiff.data_utils as du
     full_gb = float(os.environ.get("EDADM_FP_TRACE_GB", "48"))
     os.environ["EDADM_FP_TRACE_GB"] = repr(full_gb * n_calib / 1024)
-    du.STATS.update(fp_passes=0, fp_captures=0, units_served=0)
+    memo_gb = float(os.environ.get("EDADM_Q_MEMO_GB", "64"))              # memo of reconstructed units: same scaling
+    os.environ["EDADM_Q_MEMO_GB"] = repr(memo_gb * n_calib / 1024)
+    du.STATS.update(fp_passes=0, fp_captures=0, units_served=0, memo_hits=0)
 
     def timed_save(*a, **k):
         torch.cuda.synchronize()
@@ -147,6 +149,7 @@ def time_calibration(qnn, dev, n_calib=64, iters=3):
         cb.save_inp_oup_data, cl.save_inp_oup_data = orig
         timing, er.TIMING = er.TIMING, None
         os.environ["EDADM_FP_TRACE_GB"] = repr(full_gb)
+        os.environ["EDADM_Q_MEMO_GB"] = repr(memo_gb)
     loop = total - t_cache[0]
     units = qnn.block_count
     # steady-state seconds of ONE iteration of every unit (iterations after the first of each unit, edadm/recon.py);
@@ -157,7 +160,8 @@ def time_calibration(qnn, dev, n_calib=64, iters=3):
     return dict(units=units, calib_samples=n_calib, iters_per_unit=iters, wall_s=total, caching_s=t_cache[0],
                 loop_s=loop, unit_setup_s=setup, s_per_iteration_all_units=per_iter_all_units,
                 fp_trace={"budget_gb_at_1024_samples": full_gb, "fp_prefix_sweeps": du.STATS["fp_captures"],
-                          "units_served": du.STATS["units_served"]},
+                          "units_served": du.STATS["units_served"], "memo_budget_gb_at_1024_samples": memo_gb,
+                          "memo_hits": du.STATS["memo_hits"]},
                 extrapolated_full_s={"caching_1024_samples": t_cache[0] * 1024 / n_calib,
                                      "loops_1000_iters": setup + per_iter_all_units * 1000,
                                      "total": t_cache[0] * 1024 / n_calib + setup + per_iter_all_units * 1000})

@@ -11,8 +11,11 @@ The FP half of that work does not depend on the quantisation state, so it is not
 prefix pass per calibration batch records (input, output) of the unit asked for AND of the not yet
 reconstructed units that execute before the pass stops, as many as fit a byte budget (`EDADM_FP_TRACE_GB`,
 default 48 GB of the 288 GB HBM; 0 = one FP pass per unit as in the reference).  Only the quantised-prefix pass,
-whose result changes as units are reconstructed, runs once per unit.  The cached tensors are the same values the
-per-unit pass produces (same kernels, same inputs)."""
+whose result changes as units are reconstructed, runs once per unit -- and inside it the units that are already
+reconstructed are final (so are their inputs), so their outputs are memoised per calibration batch and their
+forward is skipped on later passes, again within a byte budget (`EDADM_Q_MEMO_GB`, default 64; deep, narrow units
+are kept first: most compute per cached byte).  The cached tensors are the values the per-unit passes produce
+(same kernels, same inputs)."""
 import os
 
 import torch
@@ -98,7 +101,7 @@ def recon_units(module, out=None):
     return out
 
 
-STATS = {"fp_passes": 0, "fp_captures": 0, "units_served": 0}    # counters for bench.py / tests
+STATS = {"fp_passes": 0, "fp_captures": 0, "units_served": 0, "memo_hits": 0}    # counters for bench.py / tests
 
 
 class FPTrace:
@@ -109,6 +112,40 @@ class FPTrace:
         self.store = {}          # unit -> {batch index: (inputs tuple, output)}
         self.done = set()
         self.passes = 0          # FP prefix passes run (one per calibration batch per capture)
+        self.memo = {}           # reconstructed unit -> {batch index: output under the quantised prefix}
+        self.memo_admit = {}     # unit -> admitted (bytes reserved for all local batches) or refused
+        self.memo_bytes = 0
+        self.memo_budget = int(float(os.environ.get("EDADM_Q_MEMO_GB", "64")) * (1 << 30))
+
+    @staticmethod
+    def _density(unit, out):
+        """Compute saved per cached byte, up to a constant: weights of the unit / output channels."""
+        n = sum(p.numel() for p in unit.parameters())
+        return n / max(1, out.shape[1] if out.dim() > 1 else 1)
+
+    def memo_offer(self, unit, i, out, n_local):
+        """Called with the freshly computed output of a reconstructed unit for batch i."""
+        ok = self.memo_admit.get(unit)
+        if ok is None:
+            need = out.numel() * out.element_size() * n_local
+            d = self._density(unit, out)
+            if self.memo_bytes + need > self.memo_budget:
+                worse = sorted((u for u in self.memo if self.memo_admit[u][1] < d), key=lambda u: self.memo_admit[u][1])
+                freeable = sum(self.memo_admit[u][2] for u in worse)
+                if need > self.memo_budget or self.memo_bytes - freeable + need > self.memo_budget:
+                    self.memo_admit[unit] = (False, d, 0)
+                    return
+                for u in worse:
+                    if self.memo_bytes + need <= self.memo_budget:
+                        break
+                    self.memo_bytes -= self.memo_admit[u][2]
+                    self.memo_admit[u] = (False, self.memo_admit[u][1], 0)
+                    del self.memo[u]
+            self.memo_admit[unit] = ok = (True, d, need)
+            self.memo_bytes += need
+            self.memo[unit] = {}
+        if ok[0]:
+            self.memo[unit][i] = out.detach().clone()
 
     def held_bytes(self):
         n = 0
@@ -196,19 +233,45 @@ def clear_fp_trace(model):
         model._fp_trace = None
 
 
-def _quant_prefix_input(model, layer, model_input, device, act_quant):
-    """Input of `layer` under the current quantisation state of the prefix (data_utils.py:141-147 of the reference)."""
+def _quant_prefix_input(model, layer, model_input, device, act_quant, trace=None, i=None, n_local=1):
+    """Input of `layer` under the current quantisation state of the prefix (data_utils.py:141-147 of the reference).
+    Units reconstructed earlier in the walk return their memoised output for batch `i` instead of running."""
     saver = DataSaverHook(store_input=True, store_output=False, stop_forward=True)
     model.eval()
     model.set_quant_state(weight_quant=True, act_quant=act_quant)
     handle = layer.register_forward_hook(saver)
     eng, model.engine = getattr(model, "engine", None), None
+    patched, guards = [], []
+    clean = [True]        # no pending unit has executed yet in this pass: everything so far is final
+    if trace is not None and trace.memo_budget > 0:
+        for v in recon_units(model):
+            if v not in trace.done:
+                guards.append(v.register_forward_hook(lambda *_: clean.__setitem__(0, False)))
+        for u in trace.done:
+            if u is layer or "forward" in u.__dict__:
+                continue
+
+            def fwd(*a, _u=u, _orig=u.forward, **k):
+                hit = trace.memo.get(_u, {}).get(i)
+                if hit is not None:
+                    STATS["memo_hits"] += 1
+                    return hit.clone()                      # downstream in-place ops must not reach the memo
+                out = _orig(*a, **k)
+                if torch.is_tensor(out) and clean[0]:          # inputs final only if nothing pending ran before
+                    trace.memo_offer(_u, i, out, n_local)
+                return out
+            u.forward = fwd
+            patched.append(u)
     try:
         with torch.no_grad():
             model(*[t.to(device) for t in model_input])
     except StopForwardException:
         pass
     finally:
+        for u in patched:
+            del u.forward
+        for h in guards:
+            h.remove()
         model.engine = eng
         handle.remove()
     return tuple(t.detach() for t in saver.input_store)
@@ -242,7 +305,8 @@ def save_inp_oup_data(model, layer, cali_data, asym=False, act_quant=False, batc
         for i in mine:
             sym_in, out = fp.pop(i)
             resblock = len(sym_in) != 1
-            inp = _quant_prefix_input(model, layer, batch_of(i), device, act_quant) if asym else sym_in
+            inp = (_quant_prefix_input(model, layer, batch_of(i), device, act_quant, trace, i, len(mine)) if asym
+                   else sym_in)
             local[i] = (pack(inp), out, pack(sym_in)) if input_prob else (pack(inp), out)
     else:
         for i in mine:

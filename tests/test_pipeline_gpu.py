@@ -267,19 +267,48 @@ def test_fp_trace_matches_per_unit_passes(golden, monkeypatch):
         walk(r[1:])
         return r[0], out
 
-    monkeypatch.setenv("EDADM_FP_TRACE_GB", "0")
-    ref = [flat(save_inp_oup_data(qnn, u, cali, True, True, batch_size=32, input_prob=True)) for u in units]
-    for budget, max_sweeps in (("48", 1), ("0.0002", len(units))):       # everything in one sweep / several groups
-        monkeypatch.setenv("EDADM_FP_TRACE_GB", budget)
+    from qdiff.quant_layer import QuantModule
+
+    def walk_all(trace_gb, memo_gb):
+        """save_inp_oup_data for every unit in walk order; after each unit its weight scales are perturbed, standing
+        in for the reconstruction that changes what the units after it see."""
+        monkeypatch.setenv("EDADM_FP_TRACE_GB", trace_gb)
+        monkeypatch.setenv("EDADM_Q_MEMO_GB", memo_gb)
         du.clear_fp_trace(qnn)
-        du.STATS.update(fp_passes=0, fp_captures=0, units_served=0)
-        for u, (rb, tens) in zip(units, ref):
-            rb2, tens2 = flat(save_inp_oup_data(qnn, u, cali, True, True, batch_size=32, input_prob=True))
+        du.STATS.update(fp_passes=0, fp_captures=0, units_served=0, memo_hits=0)
+        undo, res = [], []
+        try:
+            for u in units:
+                res.append(flat(save_inp_oup_data(qnn, u, cali, True, True, batch_size=32, input_prob=True)))
+                for m in u.modules():
+                    if isinstance(m, QuantModule):
+                        d = m.weight_quantizer.delta
+                        undo.append((d, d.detach().clone()))
+                        d.data.mul_(1.07)
+        finally:
+            for d, keep in undo:
+                d.data.copy_(keep)
+        stats = dict(du.STATS)
+        left = bool(qnn._fp_trace.store) if getattr(qnn, "_fp_trace", None) is not None else False
+        du.clear_fp_trace(qnn)
+        return res, stats, left
+
+    ref, st0, _ = walk_all("0", "0")
+    assert st0["fp_captures"] == 0 and st0["memo_hits"] == 0
+    for trace_gb, memo_gb in (("48", "0"), ("0.0002", "0"), ("48", "64"), ("0.0002", "0.004")):
+        got, st, left = walk_all(trace_gb, memo_gb)
+        for (rb, tens), (rb2, tens2) in zip(ref, got):
             assert rb2 == rb and len(tens2) == len(tens)
             for a, b in zip(tens, tens2):
                 assert a.shape == b.shape and torch.equal(a, b)
-        assert du.STATS["units_served"] == len(units) and 1 <= du.STATS["fp_captures"] <= max_sweeps
-        if budget == "0.0002":
-            assert 1 < du.STATS["fp_captures"] < len(units)
-        assert not qnn._fp_trace.store                                      # everything handed out
-        du.clear_fp_trace(qnn)
+        assert st["units_served"] == len(units) and not left
+        if trace_gb == "48":
+            assert st["fp_captures"] == 1                                   # one FP sweep serves the whole walk
+        else:
+            assert 1 < st["fp_captures"] < len(units)                       # several look-ahead groups
+        assert (st["memo_hits"] > 0) == (memo_gb != "0")
+        if memo_gb == "64":
+            full_hits = st["memo_hits"]
+        elif memo_gb != "0":
+            assert st["memo_hits"] < full_hits                              # a partial memo: some units recompute
+        print("trace", trace_gb, "memo", memo_gb, st)
