@@ -602,3 +602,137 @@ extern "C" int edadm_mse_select(const float* score, int64_t nc, int64_t rows, co
                        xmin, xmax, mode, one_side, 1 << n_bits, num, channel_clamp, run_min, run_max, first, delta, zp);
     return edadm_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------ fp32 as two f16 terms
+// The calibration graph contracts in fp32 (quant_layer.py:434 on fake-quantised fp32 operands).  The exact-fp32 MFMA
+// (v_mfma_f32_32x32x2_f32) peaks at 157 TFLOP/s; the f16 MFMA at 2.5 PFLOP/s.  An fp32 value scaled by a power of two
+// so that |x s| < 2^14 splits exactly into hi = f16(x s) and lo = f16(x s - hi) (22 significant bits for everything
+// above 2^-17 of the scale's maximum, absolute error below 2^-39 of that maximum for the rest), and
+//   a . b = s_a^-1 s_b^-1 (a_hi . b_hi + a_lo . b_hi + a_hi . b_lo)        (the lo . lo term is below 2^-22 relative)
+// is ONE f16 GEMM over a three times longer K with fp32 accumulation: operand A is laid out [hi | lo | hi] and operand
+// B [hi | hi | lo] per K group (a group = the channels of one filter tap, so the implicit-GEMM gather sees an NHWC
+// tensor with 3 C f16 channels).  Measured error against an fp64 product: the same as the fp32 MFMA path's own
+// accumulation error (tests/test_contract_gpu.py).
+__global__ void __launch_bounds__(256) k_absmax_part(const float* __restrict__ x, int64_t n4, float* __restrict__ part) {
+    __shared__ float sm[4];
+    float m = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+}
+
+// power-of-two scale that brings amax into [2^13, 2^14); 1 for an all-zero or non-finite tensor
+__device__ __forceinline__ void split_scale(float amax, float& s, float& inv) {
+    int e = 0;
+    if (amax > 0.f && amax < INFINITY) frexpf(amax, &e); else e = 14;
+    s = ldexpf(1.0f, 14 - e);
+    inv = ldexpf(1.0f, e - 14);
+}
+
+__device__ __forceinline__ void split4(const float4 v, float s, uint2& hi, uint2& lo) {
+    const float a[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
+    _Float16 h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = (_Float16)a[e];
+        l[e] = (_Float16)(a[e] - (float)h[e]);
+    }
+    hi = *reinterpret_cast<uint2*>(h);
+    lo = *reinterpret_cast<uint2*>(l);
+}
+
+// x [R][T][C] fp32 -> out [R][T][3][C] f16.  order 0: (hi, lo, hi) = operand A; 1: (hi, hi, lo) = operand B.
+// PER_ROW: one scale per row r (a GEMM row of B: one output channel), computed here; else one scale for the tensor from
+// the partial maxima `part[0..g)`.  inv[r] (or inv[0]) = 1 / scale; with `comb`, block 0 also writes the GEMM's
+// per-column factor comb[n] = inv[0] * other[n] (other = the per-row inverse scales of operand B, or other[0] when
+// n_other == 1).
+template <bool PER_ROW>
+__global__ void __launch_bounds__(256) k_split_f16(const float* __restrict__ x, int64_t R, int64_t T, int64_t C4, int order,
+                                                   const float* __restrict__ part, int g, uint2* __restrict__ out,
+                                                   float* __restrict__ inv, const float* __restrict__ other,
+                                                   int64_t n_other, float* __restrict__ comb, int64_t N) {
+    __shared__ float sm[4];
+    __shared__ float s_amax;
+    const int64_t row4 = T * C4;                              // float4 groups per row
+    if (PER_ROW) {
+        for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
+            const float4* xr = reinterpret_cast<const float4*>(x) + r * row4;
+            float m = 0.f;
+            for (int64_t i = threadIdx.x; i < row4; i += 256) {
+                const float4 v = xr[i];
+                m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+            }
+            m = wave_max(m);
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+            __syncthreads();
+            float s, iv;
+            split_scale(fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3])), s, iv);
+            if (threadIdx.x == 0) inv[r] = iv;
+            uint2* orow = out + r * row4 * 3;
+            for (int64_t i = threadIdx.x; i < row4; i += 256) {
+                const int64_t t = i / C4, c = i - t * C4;
+                uint2 hi, lo;
+                split4(xr[i], s, hi, lo);
+                uint2* o = orow + t * 3 * C4 + c;
+                o[0] = hi;
+                o[C4] = order ? hi : lo;
+                o[2 * C4] = order ? lo : hi;
+            }
+        }
+    } else {
+        float m = 0.f;
+        for (int i = threadIdx.x; i < g; i += 256) m = fmaxf(m, part[i]);
+        m = wave_max(m);
+        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) s_amax = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+        __syncthreads();
+        float s, iv;
+        split_scale(s_amax, s, iv);
+        if (blockIdx.x == 0) {
+            if (threadIdx.x == 0) inv[0] = iv;
+            if (comb)
+                for (int64_t n = threadIdx.x; n < N; n += 256) comb[n] = iv * other[n_other == 1 ? 0 : n];
+        }
+        const int64_t total = R * row4, stride = (int64_t)gridDim.x * 256;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+            const int64_t rt = i / C4, c = i - rt * C4;       // rt = r * T + t
+            uint2 hi, lo;
+            split4(reinterpret_cast<const float4*>(x)[i], s, hi, lo);
+            uint2* o = out + rt * 3 * C4 + c;
+            o[0] = hi;
+            o[C4] = order ? hi : lo;
+            o[2 * C4] = order ? lo : hi;
+        }
+    }
+}
+
+extern "C" int edadm_split_f16(const float* x, int64_t R, int64_t T, int64_t C, int order, int per_row, void* out,
+                               float* inv, const float* other, int64_t n_other, float* comb, int64_t N, float* ws,
+                               void* stream) {
+    if (!x || !out || !inv || !ws || R <= 0 || T <= 0 || C <= 0 || (C & 3) || (order != 0 && order != 1))
+        return EDADM_EINVAL;
+    if (comb && (!other || N <= 0 || (n_other != 1 && n_other != N) || per_row)) return EDADM_EINVAL;
+    if (((uintptr_t)x & 15) || ((uintptr_t)out & 7)) return EDADM_EINVAL;
+    const int64_t C4 = C / 4, n4 = R * T * C4;
+    hipStream_t st = (hipStream_t)stream;
+    if (per_row) {
+        const int grid = (int)(R < 2048 ? R : 2048);
+        hipLaunchKernelGGL(k_split_f16<true>, dim3(grid), dim3(256), 0, st, x, R, T, C4, order, (const float*)nullptr, 0,
+                           (uint2*)out, inv, (const float*)nullptr, (int64_t)0, (float*)nullptr, (int64_t)0);
+    } else {
+        int g = edadm_grid(n4, 256);
+        if (g > EDADM_RED_BLOCKS) g = EDADM_RED_BLOCKS;
+        hipLaunchKernelGGL(k_absmax_part, dim3(g), dim3(256), 0, st, x, n4, ws);
+        hipLaunchKernelGGL(k_split_f16<false>, dim3(edadm_grid(n4, 256)), dim3(256), 0, st, x, R, T, C4, order,
+                           (const float*)ws, g, (uint2*)out, inv, other, n_other, comb, N);
+    }
+    return edadm_launch_status();
+}

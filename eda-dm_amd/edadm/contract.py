@@ -14,6 +14,14 @@ import torch
 from . import ops
 
 IMPLICIT_DGRAD = os.environ.get("EDADM_IMPLICIT_DGRAD", "1") != "0"
+# large products run as ONE f16-MFMA GEMM over the two-term f16 expansion of both fp32 operands (three products,
+# fp32 accumulation: fp32-grade result at 2x the exact-fp32 MFMA's rate, csrc/elem.hip); 0 = exact-fp32 MFMA only
+F16X3 = os.environ.get("EDADM_F16X3", "1") != "0"
+
+
+def _f16x3_linear(M, N, K):
+    """worth the two conversion passes: enough output columns per converted operand byte"""
+    return F16X3 and K % 8 == 0 and N >= 256 and N * K >= 512 * 512 and M >= 2048
 
 
 def _split(M, O, K):
@@ -36,6 +44,8 @@ def _matmul_nt(a2d, w2d, bias=None):
     while tiles * S < 192 and K % (S * 2 * 16) == 0 and K // (S * 2) >= 512:
         S *= 2
     if S == 1:
+        if _f16x3_linear(M, N, K):
+            return ops.matmul_f16x3_nt(a2d, w2d, bias)
         return ops.gemm_f32_nt(a2d, w2d, M, N, K, bias=bias)
     Ks = K // S
     slabs = ops.gemm_f32_nt(a2d, w2d, M, N, Ks, lda=K, ldb=K, batch=S, strideA=Ks, strideB=Ks)
@@ -122,7 +132,8 @@ class _Conv2dFn(torch.autograd.Function):
         # the im2col matrix is only rebuilt in backward, for the weight gradient
         M = B * Ho * Wo
         if ((M + 127) // 128) * ((O + 127) // 128) >= 128:
-            out = ops.conv2d_f32_nhwc(xh, w4, bias, stride=stride, pad=pad)         # [B][Ho][Wo][O]
+            conv = ops.conv2d_f16x3_nhwc if F16X3 and ops.f16x3_conv_ok(xh, w4) else ops.conv2d_f32_nhwc
+            out = conv(xh, w4, bias, stride=stride, pad=pad)                        # [B][Ho][Wo][O]
         else:                                                # few tiles (8x8 / 16x16 levels): im2col + split-K GEMM
             cols = xh.reshape(M, Cp) if one else ops.im2col_f32(xh, KH, KW, stride, pad, Ho, Wo)
             out = _matmul_nt(cols, w4.reshape(O, KH * KW * Cp), bias).reshape(B, Ho, Wo, O)
@@ -143,7 +154,9 @@ class _Conv2dFn(torch.autograd.Function):
                 # input gradient of a stride-1 "same" convolution = the same convolution of gy with the spatially
                 # flipped, transposed filter: one implicit GEMM, no [M][K] gradient-of-columns matrix, no col2im pass
                 wf = w2.reshape(O, KH, KW, Cp).flip(1, 2).permute(3, 1, 2, 0).contiguous()      # [Cp][KH][KW][O]
-                dxh = ops.conv2d_f32_nhwc(gyh.reshape(B, Ho, Wo, O), wf, None, stride=1, pad=pad)
+                gy4 = gyh.reshape(B, Ho, Wo, O)
+                conv = ops.conv2d_f16x3_nhwc if F16X3 and ops.f16x3_conv_ok(gy4, wf) else ops.conv2d_f32_nhwc
+                dxh = conv(gy4, wf, None, stride=1, pad=pad)
             else:
                 gyp, _ = _pad4(gyh)
                 w2t, _ = _pad4(ops.transpose_f32(w2))                                 # [K][O]

@@ -1,8 +1,10 @@
 """First-stage decoder on the HIP kernels: the graph of ldm/modules/diffusionmodules/model.py:465-572
 (+ the 1x1 `post_quant_conv` of VQModelInterface.decode, ldm/models/autoencoder.py:274-282) executed in NHWC fp32:
 
-    3x3 / 1x1 convolutions .... edadm_conv2d_f32_nhwc (implicit GEMM, exact-fp32 MFMA; bias, residual and the
-                                 nearest-2x upsample of `Upsample` folded into the same launch)
+    3x3 / 1x1 convolutions .... implicit GEMM; bias, residual and the nearest-2x upsample of `Upsample` folded into
+                                 the same launch.  Large layers: edadm_split_f16 + edadm_qgemm_f16 (fp32 operands as
+                                 two-term f16 expansions, three products on the f16 MFMA, fp32-grade result); the
+                                 rest: edadm_conv2d_f32_nhwc (exact-fp32 MFMA)
     GroupNorm (+ swish) ....... edadm_groupnorm_stats / _apply  (K5)
     attention block ........... edadm_gemm_f32_nt (q k^T, p v) + edadm_softmax_f32
     layout .................... NCHW <-> NHWC once at the boundary
@@ -12,6 +14,7 @@ reference: parity unpinned) is `nearest_code`, a plain argmin over 
 import torch
 
 from . import ops
+from .contract import F16X3
 
 
 def _w(conv):
@@ -39,6 +42,12 @@ class DecoderEngine:
         w, b = self.w(conv)
         if x.shape[-1] != w.shape[-1]:                          # latent channels (3) -> 4
             x = torch.nn.functional.pad(x, (0, w.shape[-1] - x.shape[-1])).contiguous()
+        if F16X3 and ops.f16x3_conv_ok(x, w) and x.shape[0] * x.shape[1] * x.shape[2] * (4 if ups else 1) >= 16384:
+            key = ("h", id(conv))
+            if key not in self._wc:                              # the filter's two-term f16 expansion, once
+                self._wc[key] = ops.split_f16(w, w.shape[0], w.shape[1] * w.shape[2], w.shape[3], 1, True)[:2]
+            return ops.conv2d_f16x3_nhwc(x, w, b, residual=residual, stride=1, pad=conv.padding[0], ups=ups,
+                                         presplit=self._wc[key])
         return ops.conv2d_f32_nhwc(x, w, b, residual=residual, stride=1, pad=conv.padding[0], ups=ups)
 
     def gn(self, norm, x, silu):

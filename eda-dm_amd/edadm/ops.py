@@ -515,6 +515,49 @@ def gemm_f32_nt(A, Bm, M, N, K, alpha=1.0, bias=None, residual=None, out=None, l
     return out
 
 
+def split_f16(x, R, T, C, order, per_row, other=None, N=0):
+    """fp32 [R][T][C] -> f16 [R][T][3][C] two-term expansion (edadm_split_f16).  Returns (planes, inv, comb)."""
+    out = torch.empty(R, T * 3 * C, dtype=torch.float16, device=x.device)
+    inv = torch.empty(R if per_row else 1, dtype=torch.float32, device=x.device)
+    comb = torch.empty(N, dtype=torch.float32, device=x.device) if other is not None else None
+    lib.call("edadm_split_f16", _pf(x), int(R), int(T), int(C), int(order), 1 if per_row else 0,
+             ctypes.c_void_p(out.data_ptr()), _pf(inv), _pf(other), int(other.numel()) if other is not None else 0,
+             _pf(comb), int(N), _pf(workspace(x.device)), _stream())
+    return out, inv, comb
+
+
+def f16x3_conv_ok(x, w, ups=False):
+    """shapes the three-product f16 path takes: 16-byte f16 channel groups and 32-bit gather offsets"""
+    B, H, W, C = x.shape
+    return C % 8 == 0 and B * H * W * C * 6 < (1 << 31) and w.shape[0] >= 16
+
+
+def conv2d_f16x3_nhwc(x, w, bias=None, residual=None, stride=1, pad=1, ups=False, presplit=None):
+    """conv2d_f32_nhwc's contract on the f16 MFMA: both operands as two-term f16 expansions, three products in one
+    implicit GEMM over K = KH KW 3C, fp32 accumulation (fp32-grade result, see csrc/elem.hip)."""
+    B, H, W, C = x.shape
+    N, KH, KW, _ = w.shape
+    Hl, Wl = (2 * H, 2 * W) if ups else (H, W)
+    Ho, Wo = (Hl + 2 * pad - KH) // stride + 1, (Wl + 2 * pad - KW) // stride + 1
+    wb, inv_b = presplit if presplit is not None else split_f16(w, N, KH * KW, C, 1, True)[:2]   # static weights: split once
+    xa, _, comb = split_f16(x, B * H * W, 1, C, 0, False, other=inv_b, N=N)
+    out = torch.empty(B, Ho, Wo, N, dtype=torch.float32, device=x.device)
+    geom = (ctypes.c_int32 * 12)(1, B, H, W, 3 * C, Ho, Wo, KH, KW, stride, pad, 1 if ups else 0)
+    qgemm_f16(xa, wb, B * Ho * Wo, N, KH * KW * 3 * C, comb, bias, out, geom=geom, residual=residual)
+    return out
+
+
+def matmul_f16x3_nt(a2d, w2d, bias=None, residual=None):
+    """[M][K] . [N][K]^T (+bias) (+residual) through the same expansion (K % 8 == 0)."""
+    M, K = a2d.shape
+    N = w2d.shape[0]
+    wb, inv_b, _ = split_f16(w2d, N, 1, K, 1, True)
+    xa, _, comb = split_f16(a2d, M, 1, K, 0, False, other=inv_b, N=N)
+    out = torch.empty(M, N, dtype=torch.float32, device=a2d.device)
+    qgemm_f16(xa, wb, M, N, 3 * K, comb, bias, out, residual=residual)
+    return out
+
+
 def im2col_f32(x_nhwc, KH, KW, stride, pad, Ho, Wo):
     B, H, W, C = x_nhwc.shape
     cols = torch.empty(B * Ho * Wo, KH * KW * C, dtype=torch.float32, device=x_nhwc.device)

@@ -230,6 +230,14 @@ int edadm_gemm_f16_nt_q(const void* A, int64_t lda, int64_t strideA, int64_t str
  * (block_recon.py:197): C[z] = alpha * A[z] . B[z]^T (+ bias[n]) (+ residual[m][n]) on the exact-fp32 MFMA
  * (v_mfma_f32_32x32x2_f32); convolutions through im2col (forward), col2im (input gradient) and a
  * split-K transposed product + slab sum (weight gradient); all NHWC, deterministic. */
+/* fp32 operand -> two-term f16 expansion for the three-product fp32 emulation on the f16 MFMA:
+ * x [R][T][C] fp32 (C % 4 == 0) -> out [R][T][3][C] f16 = (hi, lo, hi) per K group for order 0 (operand A) or
+ * (hi, hi, lo) for order 1 (operand B), of x * 2^e with |x * 2^e| < 2^14: one exponent per row (per_row, operand B:
+ * a row = one output channel) or one for the tensor.  inv[r] (inv[0]) = 2^-e.  comb (per-tensor mode only):
+ * comb[n] = inv[0] * other[n] (other[0] when n_other == 1) = the per-column factor edadm_qgemm_f16 applies to
+ * the accumulators.  ws = EDADM_RED_BLOCKS floats.  The contraction itself is edadm_qgemm_f16 over K = 3 T C. */
+int edadm_split_f16(const float* x, int64_t R, int64_t T, int64_t C, int order, int per_row, void* out, float* inv,
+                    const float* other, int64_t n_other, float* comb, int64_t N, float* ws, void* stream);
 int edadm_gemm_f32_nt(const float* A, int64_t lda, int64_t strideA, const float* Bm, int64_t ldb,
                       int64_t strideB, float* C, int64_t ldc, int64_t strideC, int64_t batch, int64_t M,
                       int64_t N, int64_t K, float alpha, const float* bias, const float* residual,

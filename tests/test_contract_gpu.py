@@ -16,7 +16,8 @@ def _cmp(a, b, tol=3e-5):
 
 
 @pytest.mark.parametrize("B,C,H,O,k,stride,pad", [(4, 32, 8, 48, 3, 1, 1), (2, 64, 16, 64, 3, 2, 1), (2, 64, 9, 32, 3, 2, 0),
-                                                   (3, 64, 8, 32, 1, 1, 0), (2, 3, 16, 32, 3, 1, 1), (32, 192, 16, 192, 3, 1, 1)])
+                                                   (3, 64, 8, 32, 1, 1, 0), (2, 3, 16, 32, 3, 1, 1), (32, 192, 16, 192, 3, 1, 1),
+                                                   (32, 64, 64, 64, 3, 1, 1)])          # last two: f16 three-product path (fwd; fwd + dgrad)
 def test_conv2d_fwd_bwd(B, C, H, O, k, stride, pad):
     from edadm import contract
     g = torch.Generator().manual_seed(B * C + O)
@@ -36,7 +37,7 @@ def test_conv2d_fwd_bwd(B, C, H, O, k, stride, pad):
 def test_linear_and_conv1d_fwd_bwd():
     from edadm import contract
     g = torch.Generator().manual_seed(5)
-    for shape, O in (((100, 768), 192), ((4, 256, 96), 288), ((6, 10), 7)):
+    for shape, O in (((100, 768), 192), ((4, 256, 96), 288), ((6, 10), 7), ((4096, 512), 512)):   # last: f16 three-product path
         x = torch.randn(*shape, generator=g)
         w = torch.randn(O, shape[-1], generator=g) * 0.1
         b = torch.randn(O, generator=g)
@@ -58,3 +59,38 @@ def test_linear_and_conv1d_fwd_bwd():
     out = contract.conv1d_k1(xg, wg)
     out.backward(gy.cuda())
     _cmp(out, ref), _cmp(xg.grad, xd.grad), _cmp(wg.grad, wd.grad, 1e-4)
+
+
+@pytest.mark.parametrize("kind", ["normal", "outliers", "heavy_tail_small", "zeros"])
+def test_f16_three_product_is_fp32_grade(kind):
+    """edadm_split_f16 + edadm_qgemm_f16 (fp32 operands as hi + lo f16 terms, three products, fp32 accumulation) against
+    fp64: no worse than the exact-fp32 MFMA path on the same data, whatever the operand statistics (activation outliers,
+    gradients spread over many decades, all-zero rows)."""
+    from edadm import ops
+    g = torch.Generator().manual_seed(3)
+    M, K, N = 4096, 1152, 384
+    a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.05
+    if kind == "outliers":
+        a = a * torch.where(torch.rand(M, K, generator=g) < 1e-3, 1000.0, 1.0)
+    elif kind == "heavy_tail_small":
+        a = a * 1e-7 * torch.exp(3 * torch.randn(M, K, generator=g))
+        w = w * torch.exp(2 * torch.randn(N, 1, generator=g))
+    elif kind == "zeros":
+        a[:, ::2] = 0
+        w[5] = 0
+    b = torch.randn(N, generator=g) * float(a.abs().mean())
+    ref = a.double() @ w.double().T + b.double()
+    ad, wd, bd = a.cuda(), w.cuda(), b.cuda()
+    y32 = ops.gemm_f32_nt(ad, wd, M, N, K, bias=bd).cpu().double()
+    y16 = ops.matmul_f16x3_nt(ad, wd, bd).cpu().double()
+    rms = float(ref.pow(2).mean().sqrt())
+    e32, e16 = (y32 - ref).abs(), (y16 - ref).abs()
+    print(kind, "fp32 mean %.2e max %.2e | f16x3 mean %.2e max %.2e (of rms)" % (e32.mean() / rms, e32.max() / rms, e16.mean() / rms, e16.max() / rms))
+    assert e16.mean() <= 1.5 * e32.mean() + 1e-9 * rms and e16.max() <= 2.0 * e32.max() + 1e-7 * rms
+    # the expansion itself: hi + lo reproduces x * 2^e to 2^-22 relative (or 2^-25 absolute for the smallest terms)
+    planes, inv, _ = ops.split_f16(ad, M, 1, K, 0, False)
+    p = planes.reshape(M, 3, K).float()
+    assert torch.equal(p[:, 0], p[:, 2])
+    back = (p[:, 0].double() + p[:, 1].double()) * float(inv[0])
+    err = (back.cpu() - a.double()).abs()
+    assert float((err - a.double().abs() * 2.0 ** -21).max()) <= 2.0 ** -24 * float(inv[0])
