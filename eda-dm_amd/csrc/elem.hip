@@ -714,9 +714,9 @@ __global__ void __launch_bounds__(256) k_split_f16(const float* __restrict__ x, 
     }
 }
 
-extern "C" int edadm_split_f16(const float* x, int64_t R, int64_t T, int64_t C, int order, int per_row, void* out,
-                               float* inv, const float* other, int64_t n_other, float* comb, int64_t N, float* ws,
-                               void* stream) {
+extern "C" int edadm_split_f16(const float* x, int64_t R, int64_t T, int64_t C, int order, int per_row,
+                               const float* amax_parts, void* out, float* inv, const float* other, int64_t n_other,
+                               float* comb, int64_t N, float* ws, void* stream) {
     if (!x || !out || !inv || !ws || R <= 0 || T <= 0 || C <= 0 || (C & 3) || (order != 0 && order != 1))
         return EDADM_EINVAL;
     if (comb && (!other || N <= 0 || (n_other != 1 && n_other != N) || per_row)) return EDADM_EINVAL;
@@ -728,11 +728,134 @@ extern "C" int edadm_split_f16(const float* x, int64_t R, int64_t T, int64_t C, 
         hipLaunchKernelGGL(k_split_f16<true>, dim3(grid), dim3(256), 0, st, x, R, T, C4, order, (const float*)nullptr, 0,
                            (uint2*)out, inv, (const float*)nullptr, (int64_t)0, (float*)nullptr, (int64_t)0);
     } else {
-        int g = edadm_grid(n4, 256);
-        if (g > EDADM_RED_BLOCKS) g = EDADM_RED_BLOCKS;
-        hipLaunchKernelGGL(k_absmax_part, dim3(g), dim3(256), 0, st, x, n4, ws);
+        int g = EDADM_RED_BLOCKS;
+        if (!amax_parts) {
+            g = edadm_grid(n4, 256);
+            if (g > EDADM_RED_BLOCKS) g = EDADM_RED_BLOCKS;
+            hipLaunchKernelGGL(k_absmax_part, dim3(g), dim3(256), 0, st, x, n4, ws);
+            amax_parts = ws;
+        }
         hipLaunchKernelGGL(k_split_f16<false>, dim3(edadm_grid(n4, 256)), dim3(256), 0, st, x, R, T, C4, order,
-                           (const float*)ws, g, (uint2*)out, inv, other, n_other, comb, N);
+                           amax_parts, g, (uint2*)out, inv, other, n_other, comb, N);
     }
+    return edadm_launch_status();
+}
+
+// Weight-gradient operands: dW[o][k] = sum_m dY[m][o] X[m][k] reduces over the ROW index of both row-major operands,
+// so the NT GEMM wants them transposed, and the split-K form wants the reduction cut into S slabs of L rows.  One pass
+// does both and the f16 expansion: in [R][C] fp32 -> out [C][S][3][L] f16 (R = S L), i.e. slab s of output row c is the
+// K range [3 L s, 3 L (s + 1)) = (hi, lo, hi) or (hi, hi, lo) of in[s L .. s L + L)[c].  128 x 64 tile through LDS:
+// 256-byte row reads, 256-byte (64 lanes x 2 halves) writes.  One power-of-two scale for the tensor.
+struct GatherGeom { int on, B, H, W, C, Ho, Wo, KH, KW, stride, pad; };
+// With `gg.on` the input is not a matrix but an NHWC activation x [B][H][W][C] (C % 64 == 0) and in[r][c'] is the im2col
+// element of output pixel r and column c' = (ky, kx, c): a 64-column tile lies inside one filter tap, so its 128 rows
+// are 128 pixel rows of 256 contiguous bytes (zero outside the image) -- the [M][KH KW C] matrix is never written.
+__global__ void __launch_bounds__(256) k_transpose_split_f16(const float* __restrict__ in, int64_t R, int64_t C, int64_t L,
+                                                             int order, const float* __restrict__ part, int g,
+                                                             _Float16* __restrict__ out, float* __restrict__ inv,
+                                                             const GatherGeom gg) {
+    __shared__ float tile[128][65];
+    __shared__ float sm[4];
+    __shared__ float s_amax;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < g; i += 256) m = fmaxf(m, part[i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) s_amax = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    __syncthreads();
+    float s, iv;
+    split_scale(s_amax, s, iv);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) inv[0] = iv;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t ctiles = (C + 63) / 64, rtiles = (R + 127) / 128, ntiles = ctiles * rtiles;
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int64_t r0 = (t / ctiles) * 128, c0 = (t % ctiles) * 64;
+        __syncthreads();
+        // load: thread -> (row = it * 16 + tid / 16, 4 columns at (tid % 16) * 4)
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int rr = it * 16 + (threadIdx.x >> 4), cc = (threadIdx.x & 15) * 4;
+            const int64_t r = r0 + rr, c = c0 + cc;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gg.on) {
+                if (r < R) {
+                    const int tap = (int)(c0 / gg.C), cb = (int)(c0 - (int64_t)tap * gg.C);
+                    const int ky = tap / gg.KW, kx = tap - ky * gg.KW;
+                    const int hw = gg.Ho * gg.Wo, b = (int)(r / hw), p = (int)(r - (int64_t)b * hw);
+                    const int yo = p / gg.Wo, xo = p - yo * gg.Wo;
+                    const int iy = yo * gg.stride - gg.pad + ky, ix = xo * gg.stride - gg.pad + kx;
+                    if (iy >= 0 && iy < gg.H && ix >= 0 && ix < gg.W)
+                        v = *reinterpret_cast<const float4*>(in + (((int64_t)b * gg.H + iy) * gg.W + ix) * gg.C + cb + cc);
+                }
+            } else if (r < R) {
+                if (c + 3 < C && (C & 3) == 0) v = *reinterpret_cast<const float4*>(in + r * C + c);
+                else {
+                    if (c < C) v.x = in[r * C + c];
+                    if (c + 1 < C) v.y = in[r * C + c + 1];
+                    if (c + 2 < C) v.z = in[r * C + c + 2];
+                    if (c + 3 < C) v.w = in[r * C + c + 3];
+                }
+            }
+            tile[rr][cc] = v.x; tile[rr][cc + 1] = v.y; tile[rr][cc + 2] = v.z; tile[rr][cc + 3] = v.w;
+        }
+        __syncthreads();
+        const int64_t r = r0 + 2 * lane;                         // this lane's pair of reduction rows (R, L even)
+        if (r < R) {
+            const int64_t sl = r / L, rl = r - sl * L;
+            const int64_t base = sl * 3 * L + rl;
+#pragma unroll 4
+            for (int j = 0; j < 16; ++j) {
+                const int cc = w * 16 + j;
+                if (c0 + cc >= C) break;
+                const float a0 = tile[2 * lane][cc] * s, a1 = tile[2 * lane + 1][cc] * s;
+                const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
+                const _Float16 l0 = (_Float16)(a0 - (float)h0), l1 = (_Float16)(a1 - (float)h1);
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                const h2 hi = {h0, h1}, lo = {l0, l1};
+                _Float16* o = out + (c0 + cc) * 3 * R + base;
+                *reinterpret_cast<h2*>(o) = hi;
+                *reinterpret_cast<h2*>(o + L) = order ? hi : lo;
+                *reinterpret_cast<h2*>(o + 2 * L) = order ? lo : hi;
+            }
+        }
+    }
+}
+
+extern "C" int edadm_absmax_parts(const float* x, int64_t n, float* parts, void* stream) {
+    if (!x || !parts || n <= 0 || (n & 3) || ((uintptr_t)x & 15)) return EDADM_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    int g = edadm_grid(n / 4, 256);
+    if (g > EDADM_RED_BLOCKS) g = EDADM_RED_BLOCKS;
+    if (hipMemsetAsync(parts, 0, EDADM_RED_BLOCKS * sizeof(float), st) != hipSuccess) return EDADM_EIO;
+    hipLaunchKernelGGL(k_absmax_part, dim3(g), dim3(256), 0, st, x, n / 4, parts);
+    return edadm_launch_status();
+}
+
+extern "C" int edadm_transpose_split_f16(const float* in, int64_t R, int64_t C, int64_t L, int order, const int32_t* geom,
+                                         const float* amax_parts, void* out, float* inv, float* ws, void* stream) {
+    if (!in || !out || !inv || !ws || R <= 0 || C <= 0 || L <= 0 || (R % L) || (L & 1) || (order != 0 && order != 1))
+        return EDADM_EINVAL;
+    if (((uintptr_t)in & 15) || ((uintptr_t)out & 3)) return EDADM_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    GatherGeom gg{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (geom) {                              // {B, H, W, C, Ho, Wo, KH, KW, stride, pad}: `in` is the NHWC activation
+        gg = GatherGeom{1, geom[0], geom[1], geom[2], geom[3], geom[4], geom[5], geom[6], geom[7], geom[8], geom[9]};
+        if (gg.C <= 0 || gg.C % 64 || (int64_t)gg.B * gg.Ho * gg.Wo != R || (int64_t)gg.KH * gg.KW * gg.C != C || gg.stride < 1 ||
+            gg.pad < 0 || !amax_parts)
+            return EDADM_EINVAL;
+    }
+    int g = EDADM_RED_BLOCKS;
+    if (!amax_parts) {
+        const int64_t n = R * C;
+        if (n & 3) return EDADM_EINVAL;
+        g = edadm_grid(n / 4, 256);
+        if (g > EDADM_RED_BLOCKS) g = EDADM_RED_BLOCKS;
+        hipLaunchKernelGGL(k_absmax_part, dim3(g), dim3(256), 0, st, in, n / 4, ws);
+        amax_parts = ws;
+    }
+    const int64_t ntiles = ((C + 63) / 64) * ((R + 127) / 128);
+    hipLaunchKernelGGL(k_transpose_split_f16, dim3((unsigned)(ntiles < 4096 ? ntiles : 4096)), dim3(256), 0, st, in, R, C, L,
+                       order, amax_parts, g, (_Float16*)out, inv, gg);
     return edadm_launch_status();
 }

@@ -34,7 +34,12 @@ def _split(M, O, K):
     return s
 
 
-def _matmul_nt(a2d, w2d, bias=None):
+def _amax(t):
+    """partial maxima of an operand that may be expanded to f16 terms (shared by every expansion of the tensor)"""
+    return ops.absmax_parts(t) if F16X3 and t.numel() >= (1 << 17) and t.numel() % 4 == 0 else None
+
+
+def _matmul_nt(a2d, w2d, bias=None, amax=None):
     """[M][K] . [N][K]^T; few-tile shapes (the 8x8 / 16x16 levels) are split along K into slabs so that
     the launch still covers the 256 CUs, and the slabs are summed in a fixed order."""
     M, K = a2d.shape
@@ -45,7 +50,7 @@ def _matmul_nt(a2d, w2d, bias=None):
         S *= 2
     if S == 1:
         if _f16x3_linear(M, N, K):
-            return ops.matmul_f16x3_nt(a2d, w2d, bias)
+            return ops.matmul_f16x3_nt(a2d, w2d, bias, amax=amax)
         return ops.gemm_f32_nt(a2d, w2d, M, N, K, bias=bias)
     Ks = K // S
     slabs = ops.gemm_f32_nt(a2d, w2d, M, N, Ks, lda=K, ldb=K, batch=S, strideA=Ks, strideB=Ks)
@@ -53,18 +58,38 @@ def _matmul_nt(a2d, w2d, bias=None):
     return out if bias is None else out.add_(bias)
 
 
-def _wgrad(gy2d, a2d):
-    """dW[o][k] = gy2d^T . a2d  (gy2d [M][O], a2d [M][K])."""
+def _wgrad(gy2d, a2d, amax_g=None, amax_a=None, conv=None):
+    """dW[o][k] = gy2d^T . a2d  (gy2d [M][O], a2d [M][K]).  conv = (x_nhwc, (KH, KW, stride, pad, Ho, Wo)): a2d is the
+    im2col of x_nhwc and is never materialised (f16 three-product path only)."""
     M, O = gy2d.shape
+    if conv is not None:
+        xh, (KH, KW, stride, pad, Ho, Wo) = conv
+        K = KH * KW * xh.shape[-1]
+        S = _split(M, O, K)
+        if F16X3 and xh.shape[-1] % 64 == 0 and (M // S) % 8 == 0 and M % 4 == 0 and amax_a is not None:
+            Ms = M // S
+            gt, inv_g = ops.transpose_split_f16(gy2d, Ms, 0, amax=amax_g)
+            at, inv_a = ops.transpose_split_f16(xh, Ms, 1, amax=amax_a, conv=(KH, KW, stride, pad, Ho, Wo))
+            slabs = ops.gemm_f16_nt(gt, 3 * M, 3 * Ms, at, 3 * M, 3 * Ms, S, O, K, 3 * Ms, 1.0)
+            return (ops.sum_slabs(slabs) if S > 1 else slabs[0]).mul_(inv_g * inv_a)
+        a2d = ops.im2col_f32(xh, KH, KW, stride, pad, Ho, Wo)
     K = a2d.shape[1]
-    if M % 4:                                   # the reduction length must be a multiple of 4 floats: zero rows add 0
+    if M % 4:
+        amax_g = amax_a = None                                   # the reduction length must be a multiple of 4 floats: zero rows add 0
         Mp = (M + 3) // 4 * 4
         gy2d = torch.cat([gy2d, gy2d.new_zeros(Mp - M, O)])
         a2d = torch.cat([a2d, a2d.new_zeros(Mp - M, K)])
         M = Mp
-    gyT, aT = ops.transpose_f32(gy2d), ops.transpose_f32(a2d)            # [O][M], [K][M]
     S = _split(M, O, K)
     Ms = M // S
+    if F16X3 and Ms % 8 == 0 and M >= 2048 and O * K >= 128 * 128:
+        # transposition, slab cut and two-term f16 expansion of both operands in one pass each; S slabs of K = 3 Ms on
+        # the f16 MFMA; the two power-of-two scales come off after the ordered slab sum
+        gt, inv_g = ops.transpose_split_f16(gy2d, Ms, 0, amax=amax_g)    # [O][S][3][Ms]
+        at, inv_a = ops.transpose_split_f16(a2d, Ms, 1, amax=amax_a)     # [K][S][3][Ms]
+        slabs = ops.gemm_f16_nt(gt, 3 * M, 3 * Ms, at, 3 * M, 3 * Ms, S, O, K, 3 * Ms, 1.0)
+        return (ops.sum_slabs(slabs) if S > 1 else slabs[0]).mul_(inv_g * inv_a)
+    gyT, aT = ops.transpose_f32(gy2d), ops.transpose_f32(a2d)            # [O][M], [K][M]
     if S == 1:
         return ops.gemm_f32_nt(gyT, aT, O, K, M)
     slabs = ops.gemm_f32_nt(gyT, aT, O, K, Ms, lda=M, ldb=M, batch=S, strideA=Ms, strideB=Ms)
@@ -88,7 +113,8 @@ class _LinearFn(torch.autograd.Function):
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
         x2p, K = _pad4(x2)
         wp, _ = _pad4(weight.contiguous())
-        out = _matmul_nt(x2p, wp, bias)
+        ctx.px = _amax(x2p)
+        out = _matmul_nt(x2p, wp, bias, amax=ctx.px)
         ctx.save_for_backward(x2p, wp)
         ctx.meta = (x.shape, K, bias is not None)
         return out.reshape(*x.shape[:-1], weight.shape[0])
@@ -99,12 +125,13 @@ class _LinearFn(torch.autograd.Function):
         xshape, K, has_bias = ctx.meta
         gy2 = gy.reshape(-1, gy.shape[-1]).contiguous()
         gy2p, O = _pad4(gy2)
+        pg = _amax(gy2p) if gy2p is gy2 else None
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             wT, _ = _pad4(ops.transpose_f32(wp))                                   # [Kp][O]
-            gx = _matmul_nt(gy2p, wT)[:, :K].reshape(xshape)
+            gx = _matmul_nt(gy2p, wT, amax=pg)[:, :K].reshape(xshape)
         if ctx.needs_input_grad[1]:
-            gw = _wgrad(gy2, x2p)[:, :K].contiguous()
+            gw = _wgrad(gy2, x2p, amax_g=pg, amax_a=ctx.px)[:, :K].contiguous()
         if has_bias and ctx.needs_input_grad[2]:
             gb = gy2.sum(0)
         return gx, gw, gb
@@ -131,13 +158,18 @@ class _Conv2dFn(torch.autograd.Function):
         # forward as an implicit GEMM (edadm_conv2d_f32_nhwc): no im2col matrix, the gather re-reads x through L2;
         # the im2col matrix is only rebuilt in backward, for the weight gradient
         M = B * Ho * Wo
+        px = None
         if ((M + 127) // 128) * ((O + 127) // 128) >= 128:
-            conv = ops.conv2d_f16x3_nhwc if F16X3 and ops.f16x3_conv_ok(xh, w4) else ops.conv2d_f32_nhwc
-            out = conv(xh, w4, bias, stride=stride, pad=pad)                        # [B][Ho][Wo][O]
+            if F16X3 and ops.f16x3_conv_ok(xh, w4):
+                px = _amax(xh)
+                out = ops.conv2d_f16x3_nhwc(xh, w4, bias, stride=stride, pad=pad, amax=px)   # [B][Ho][Wo][O]
+            else:
+                out = ops.conv2d_f32_nhwc(xh, w4, bias, stride=stride, pad=pad)
         else:                                                # few tiles (8x8 / 16x16 levels): im2col + split-K GEMM
             cols = xh.reshape(M, Cp) if one else ops.im2col_f32(xh, KH, KW, stride, pad, Ho, Wo)
             out = _matmul_nt(cols, w4.reshape(O, KH * KW * Cp), bias).reshape(B, Ho, Wo, O)
         ctx.save_for_backward(xh, w4.reshape(O, KH * KW * Cp))
+        ctx.px = px if px is not None else _amax(xh)
         ctx.meta = (B, C, Cp, H, W, O, KH, KW, stride, pad, Ho, Wo, one, bias is not None)
         return ops.nhwc_to_nchw(out)
 
@@ -146,6 +178,7 @@ class _Conv2dFn(torch.autograd.Function):
         xh, w2 = ctx.saved_tensors
         B, C, Cp, H, W, O, KH, KW, stride, pad, Ho, Wo, one, has_bias = ctx.meta
         gyh = ops.nchw_to_nhwc(gy.contiguous()).reshape(B * Ho * Wo, O)
+        pg = _amax(gyh)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             M = B * Ho * Wo
@@ -155,17 +188,21 @@ class _Conv2dFn(torch.autograd.Function):
                 # flipped, transposed filter: one implicit GEMM, no [M][K] gradient-of-columns matrix, no col2im pass
                 wf = w2.reshape(O, KH, KW, Cp).flip(1, 2).permute(3, 1, 2, 0).contiguous()      # [Cp][KH][KW][O]
                 gy4 = gyh.reshape(B, Ho, Wo, O)
-                conv = ops.conv2d_f16x3_nhwc if F16X3 and ops.f16x3_conv_ok(gy4, wf) else ops.conv2d_f32_nhwc
-                dxh = conv(gy4, wf, None, stride=1, pad=pad)
+                if F16X3 and ops.f16x3_conv_ok(gy4, wf):
+                    dxh = ops.conv2d_f16x3_nhwc(gy4, wf, None, stride=1, pad=pad, amax=pg)
+                else:
+                    dxh = ops.conv2d_f32_nhwc(gy4, wf, None, stride=1, pad=pad)
             else:
                 gyp, _ = _pad4(gyh)
                 w2t, _ = _pad4(ops.transpose_f32(w2))                                 # [K][O]
-                dcols = _matmul_nt(gyp, w2t)                                           # [M][K]
+                dcols = _matmul_nt(gyp, w2t, amax=pg if gyp is gyh else None)           # [M][K]
                 dxh = dcols.reshape(B, H, W, Cp) if one else ops.col2im_f32(dcols, B, H, W, Cp, KH, KW, stride, pad, Ho, Wo)
             gx = ops.nhwc_to_nchw(dxh[..., :C].contiguous() if Cp != C else dxh)
         if ctx.needs_input_grad[1]:
-            cols = xh.reshape(B * H * W, Cp) if one else ops.im2col_f32(xh, KH, KW, stride, pad, Ho, Wo)
-            gw2 = _wgrad(gyh, cols)                                                   # [O][KH*KW*Cp]
+            if one:
+                gw2 = _wgrad(gyh, xh.reshape(B * H * W, Cp), amax_g=pg, amax_a=ctx.px)
+            else:                                                                     # [O][KH*KW*Cp]
+                gw2 = _wgrad(gyh, None, amax_g=pg, amax_a=ctx.px, conv=(xh, (KH, KW, stride, pad, Ho, Wo)))
             gw = gw2.reshape(O, KH, KW, Cp)[..., :C].permute(0, 3, 1, 2).contiguous()
         if has_bias and ctx.needs_input_grad[2]:
             gb = gyh.sum(0)

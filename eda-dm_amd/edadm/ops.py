@@ -515,15 +515,41 @@ def gemm_f32_nt(A, Bm, M, N, K, alpha=1.0, bias=None, residual=None, out=None, l
     return out
 
 
-def split_f16(x, R, T, C, order, per_row, other=None, N=0):
+def split_f16(x, R, T, C, order, per_row, other=None, N=0, amax=None):
     """fp32 [R][T][C] -> f16 [R][T][3][C] two-term expansion (edadm_split_f16).  Returns (planes, inv, comb)."""
     out = torch.empty(R, T * 3 * C, dtype=torch.float16, device=x.device)
     inv = torch.empty(R if per_row else 1, dtype=torch.float32, device=x.device)
     comb = torch.empty(N, dtype=torch.float32, device=x.device) if other is not None else None
-    lib.call("edadm_split_f16", _pf(x), int(R), int(T), int(C), int(order), 1 if per_row else 0,
+    lib.call("edadm_split_f16", _pf(x), int(R), int(T), int(C), int(order), 1 if per_row else 0, _pf(amax),
              ctypes.c_void_p(out.data_ptr()), _pf(inv), _pf(other), int(other.numel()) if other is not None else 0,
              _pf(comb), int(N), _pf(workspace(x.device)), _stream())
     return out, inv, comb
+
+
+def absmax_parts(x):
+    """1024 partial maxima of |x| (edadm_absmax_parts): the scan an operand needs before its f16 expansion, kept so that
+    a tensor expanded twice (forward, weight gradient) is scanned once."""
+    parts = torch.empty(1024, dtype=torch.float32, device=x.device)
+    lib.call("edadm_absmax_parts", _pf(x), x.numel(), _pf(parts), _stream())
+    return parts
+
+
+def transpose_split_f16(x2d, L, order, amax=None, conv=None):
+    """[R][C] fp32 -> ([C][R/L][3][L] f16, inv) (edadm_transpose_split_f16).  conv = (KH, KW, stride, pad, Ho, Wo): x2d is
+    the NHWC activation [B][H][W][C] and the matrix its im2col, gathered on the fly."""
+    if conv is not None:
+        B, H, W, Cc = x2d.shape
+        KH, KW, stride, pad, Ho, Wo = conv
+        R, C = B * Ho * Wo, KH * KW * Cc
+        geom = (ctypes.c_int32 * 10)(B, H, W, Cc, Ho, Wo, KH, KW, stride, pad)
+        gptr = ctypes.cast(geom, ctypes.c_void_p)
+    else:
+        (R, C), gptr = x2d.shape, None
+    out = torch.empty(C, 3 * R, dtype=torch.float16, device=x2d.device)
+    inv = torch.empty(1, dtype=torch.float32, device=x2d.device)
+    lib.call("edadm_transpose_split_f16", _pf(x2d), int(R), int(C), int(L), int(order), gptr, _pf(amax),
+             ctypes.c_void_p(out.data_ptr()), _pf(inv), _pf(workspace(x2d.device)), _stream())
+    return out, inv
 
 
 def f16x3_conv_ok(x, w, ups=False):
@@ -532,7 +558,7 @@ def f16x3_conv_ok(x, w, ups=False):
     return C % 8 == 0 and B * H * W * C * 6 < (1 << 31) and w.shape[0] >= 16
 
 
-def conv2d_f16x3_nhwc(x, w, bias=None, residual=None, stride=1, pad=1, ups=False, presplit=None):
+def conv2d_f16x3_nhwc(x, w, bias=None, residual=None, stride=1, pad=1, ups=False, presplit=None, amax=None):
     """conv2d_f32_nhwc's contract on the f16 MFMA: both operands as two-term f16 expansions, three products in one
     implicit GEMM over K = KH KW 3C, fp32 accumulation (fp32-grade result, see csrc/elem.hip)."""
     B, H, W, C = x.shape
@@ -540,19 +566,19 @@ def conv2d_f16x3_nhwc(x, w, bias=None, residual=None, stride=1, pad=1, ups=False
     Hl, Wl = (2 * H, 2 * W) if ups else (H, W)
     Ho, Wo = (Hl + 2 * pad - KH) // stride + 1, (Wl + 2 * pad - KW) // stride + 1
     wb, inv_b = presplit if presplit is not None else split_f16(w, N, KH * KW, C, 1, True)[:2]   # static weights: split once
-    xa, _, comb = split_f16(x, B * H * W, 1, C, 0, False, other=inv_b, N=N)
+    xa, _, comb = split_f16(x, B * H * W, 1, C, 0, False, other=inv_b, N=N, amax=amax)
     out = torch.empty(B, Ho, Wo, N, dtype=torch.float32, device=x.device)
     geom = (ctypes.c_int32 * 12)(1, B, H, W, 3 * C, Ho, Wo, KH, KW, stride, pad, 1 if ups else 0)
     qgemm_f16(xa, wb, B * Ho * Wo, N, KH * KW * 3 * C, comb, bias, out, geom=geom, residual=residual)
     return out
 
 
-def matmul_f16x3_nt(a2d, w2d, bias=None, residual=None):
+def matmul_f16x3_nt(a2d, w2d, bias=None, residual=None, amax=None):
     """[M][K] . [N][K]^T (+bias) (+residual) through the same expansion (K % 8 == 0)."""
     M, K = a2d.shape
     N = w2d.shape[0]
     wb, inv_b, _ = split_f16(w2d, N, 1, K, 1, True)
-    xa, _, comb = split_f16(a2d, M, 1, K, 0, False, other=inv_b, N=N)
+    xa, _, comb = split_f16(a2d, M, 1, K, 0, False, other=inv_b, N=N, amax=amax)
     out = torch.empty(M, N, dtype=torch.float32, device=a2d.device)
     qgemm_f16(xa, wb, M, N, 3 * K, comb, bias, out, residual=residual)
     return out

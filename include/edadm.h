@@ -235,9 +235,22 @@ int edadm_gemm_f16_nt_q(const void* A, int64_t lda, int64_t strideA, int64_t str
  * (hi, hi, lo) for order 1 (operand B), of x * 2^e with |x * 2^e| < 2^14: one exponent per row (per_row, operand B:
  * a row = one output channel) or one for the tensor.  inv[r] (inv[0]) = 2^-e.  comb (per-tensor mode only):
  * comb[n] = inv[0] * other[n] (other[0] when n_other == 1) = the per-column factor edadm_qgemm_f16 applies to
- * the accumulators.  ws = EDADM_RED_BLOCKS floats.  The contraction itself is edadm_qgemm_f16 over K = 3 T C. */
-int edadm_split_f16(const float* x, int64_t R, int64_t T, int64_t C, int order, int per_row, void* out, float* inv,
-                    const float* other, int64_t n_other, float* comb, int64_t N, float* ws, void* stream);
+ * the accumulators.  ws = edadm_reduce_ws_floats() floats.  The contraction itself is edadm_qgemm_f16 over K = 3 T C.
+ * amax_parts: NULL, or the 1024 partial maxima edadm_absmax_parts wrote for this tensor (an operand that is
+ * expanded more than once -- forward and weight gradient -- is scanned once). */
+int edadm_absmax_parts(const float* x, int64_t n, float* parts, void* stream);
+int edadm_split_f16(const float* x, int64_t R, int64_t T, int64_t C, int order, int per_row, const float* amax_parts,
+                    void* out, float* inv, const float* other, int64_t n_other, float* comb, int64_t N, float* ws,
+                    void* stream);
+/* the weight gradient's operands in one pass: in [R][C] fp32 -> out [C][R / L][3][L] f16 (transposed, the reduction
+ * axis R cut into slabs of L rows, each slab the (hi, lo, hi) / (hi, hi, lo) expansion of order 0 / 1 under one
+ * power-of-two scale for the tensor; inv[0] = 1 / scale).  R % L == 0, L even, R C % 4 == 0.  The product is
+ * edadm_gemm_f16_nt over batch = R / L slabs of K = 3 L, summed by edadm_sum_slabs.
+ * geom = host {B, H, W, C, Ho, Wo, KH, KW, stride, pad} (C % 64 == 0; amax_parts required): `in` is the NHWC activation
+ * and the matrix is its im2col, gathered on the fly (R = B Ho Wo, C = KH KW C) -- the convolution's weight gradient
+ * without the [M][KH KW C] matrix. */
+int edadm_transpose_split_f16(const float* in, int64_t R, int64_t C, int64_t L, int order, const int32_t* geom,
+                              const float* amax_parts, void* out, float* inv, float* ws, void* stream);
 int edadm_gemm_f32_nt(const float* A, int64_t lda, int64_t strideA, const float* Bm, int64_t ldb,
                       int64_t strideB, float* C, int64_t ldc, int64_t strideC, int64_t batch, int64_t M,
                       int64_t N, int64_t K, float alpha, const float* bias, const float* residual,
