@@ -94,7 +94,8 @@ def time_decoder(dev, B):
     dt = time.time() - t0
     assert img.shape == (B, 3, 256, 256) and bool(torch.isfinite(img).all())
     return {"images": B, "wall_s": dt, "ms_per_image": 1e3 * dt / B, "tflops_fp32": B * 2 * 318.1e9 / dt / 1e12,
-            "config": "VQ-f4 decoder, fp32 MFMA (v_mfma_f32_32x32x2_f32), random-init weights"}
+            "config": "VQ-f4 decoder, fp32 in / fp32 out; large convolutions as three f16-MFMA products over two-term f16 "
+                      "expansions (fp32-grade, DESIGN.md section 4), the rest on the exact-fp32 MFMA; random-init weights"}
 
 
 def time_calibration(qnn, dev, n_calib=64, iters=3):
