@@ -126,6 +126,11 @@ def time_calibration(qnn, dev, n_calib=64, iters=3):
     os.environ["EDADM_FP_TRACE_GB"] = repr(full_gb * n_calib / 1024)
     memo_gb = float(os.environ.get("EDADM_Q_MEMO_GB", "64"))              # memo of reconstructed units: same scaling
     os.environ["EDADM_Q_MEMO_GB"] = repr(memo_gb * n_calib / 1024)
+    # per-sample FP feature maps (edadm/recon.py fp_features): pays off over the 1000 iterations of the real run, so it
+    # is forced on here, its byte budget scaled like the others, and its time extrapolated with the sample count
+    feat_gb = float(os.environ.get("EDADM_FP_FEAT_GB", "56"))
+    os.environ["EDADM_FP_FEAT_GB"] = repr(feat_gb * n_calib / 1024)
+    os.environ["EDADM_FP_FEAT_FORCE"] = "1"
     du.STATS.update(fp_passes=0, fp_captures=0, units_served=0, memo_hits=0)
 
     def timed_save(*a, **k):
@@ -151,21 +156,26 @@ def time_calibration(qnn, dev, n_calib=64, iters=3):
         timing, er.TIMING = er.TIMING, None
         os.environ["EDADM_FP_TRACE_GB"] = repr(full_gb)
         os.environ["EDADM_Q_MEMO_GB"] = repr(memo_gb)
+        os.environ["EDADM_FP_FEAT_GB"] = repr(feat_gb)
+        os.environ.pop("EDADM_FP_FEAT_FORCE", None)
     loop = total - t_cache[0]
     units = qnn.block_count
     # steady-state seconds of ONE iteration of every unit (iterations after the first of each unit, edadm/recon.py);
     # what is left of the loop time is per-unit setup (AdaRound init, optimiser state, first-iteration warm-up),
     # paid once per unit whatever the iteration count
     per_iter_all_units = timing["iter_s"] / max(timing["iters"], 1) * units
-    setup = max(loop - timing["iter_s"], 0.0)
+    feat = timing.get("feat_s", 0.0)
+    setup = max(loop - timing["iter_s"] - feat, 0.0)
     return dict(units=units, calib_samples=n_calib, iters_per_unit=iters, wall_s=total, caching_s=t_cache[0],
                 loop_s=loop, unit_setup_s=setup, s_per_iteration_all_units=per_iter_all_units,
+                fp_features={"s": feat, "units_cached": timing.get("feat_units", 0), "budget_gb_at_1024_samples": feat_gb},
                 fp_trace={"budget_gb_at_1024_samples": full_gb, "fp_prefix_sweeps": du.STATS["fp_captures"],
                           "units_served": du.STATS["units_served"], "memo_budget_gb_at_1024_samples": memo_gb,
                           "memo_hits": du.STATS["memo_hits"]},
                 extrapolated_full_s={"caching_1024_samples": t_cache[0] * 1024 / n_calib,
+                                     "fp_features_1024_samples": feat * 1024 / n_calib,
                                      "loops_1000_iters": setup + per_iter_all_units * 1000,
-                                     "total": t_cache[0] * 1024 / n_calib + setup + per_iter_all_units * 1000})
+                                     "total": (t_cache[0] + feat) * 1024 / n_calib + setup + per_iter_all_units * 1000})
 
 
 def cpu_baseline(qnn, sd_cpu):

@@ -7,9 +7,11 @@ backward, Adam on all AdaRound alphas (lr_w) and all activation deltas (lr_a), c
 
 MI355X-native pieces: fake-quant fwd/bwd (K1), AdaRound fwd/bwd (K2), loss (K7), one fused Adam
 launch over a flat parameter slab per group (K8), stochastic input mixing (K10) are HIP kernels;
-cached activations stay in HBM; the fp32 contraction inside the block graph is torch's for now.
+cached activations stay in HBM; the fp32 contraction inside the block graph is edadm/contract.py (f16 three-product
+or exact-fp32 MFMA GEMMs); the FP forward #2 is replaced by per-sample feature maps computed once (fp_features).
 """
 import math
+import os
 import random
 import time
 
@@ -136,6 +138,32 @@ def _attention_quantizers(module):
 TIMING = None
 
 
+def fp_features(unit, hooks, cached_inps, resblock, sz, chunk, budget_bytes):
+    """The FP feature maps of the fine-grained loss (block_recon.py:170-178: an FP forward of the block on `cur_sym`
+    every iteration) are a pure function of the calibration sample, and each of the `sz` cached samples is drawn
+    iters * batch / sz times (16x at the shipped setting): one FP forward per sample, kept in HBM, replaces the
+    per-iteration FP forward when the maps of all samples fit `budget_bytes`.  Returns a list (one [sz, ...] tensor per
+    hooked module but the last, which the loss skips) or None when they do not fit."""
+    if budget_bytes <= 0 or len(hooks) < 2:
+        return None
+    sym = cached_inps[1]
+    feats = None
+    unit.set_quant_state(False, False)
+    with torch.no_grad():
+        for lo in range(0, sz, chunk):
+            hi = min(sz, lo + chunk)
+            unit(*((sym[0][lo:hi], sym[1][lo:hi]) if resblock else (sym[lo:hi],)))
+            outs = [h.out for h in hooks[:-1]]
+            if feats is None:
+                per_row = sum(o[0].numel() * o.element_size() for o in outs)
+                if per_row * sz > budget_bytes:
+                    return None
+                feats = [torch.empty((sz,) + tuple(o.shape[1:]), dtype=o.dtype, device=o.device) for o in outs]
+            for f, o in zip(feats, outs):
+                f[lo:hi] = o
+    return feats
+
+
 def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000, weight=0.01, opt_mode='mse',
                 asym=False, b_range=(20, 2), warmup=0.0, act_quant=False, lr_a=4e-5, lr_w=1e-2, p=2.0,
                 input_prob=1.0, keep_gpu=True, recon_w=False, recon_a=False, add_loss=0.0, cache_batch=32,
@@ -189,6 +217,19 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
     sz = cached_outs.size(0)
     model.block_count = model.block_count + 1
     eng, model.engine = getattr(model, "engine", None), None
+    feats = None
+    # worth it when every sample is drawn more than once (bench.py forces it on its short run and scales the time)
+    if is_block and hooks and (iters * batch_size >= 2 * sz or os.environ.get("EDADM_FP_FEAT_FORCE") == "1"):
+        if TIMING is not None:
+            torch.cuda.synchronize()
+            _t_feat = time.time()
+        feats = fp_features(unit, hooks, cached_inps, resblock, sz, batch_size,
+                            int(float(os.environ.get("EDADM_FP_FEAT_GB", "56")) * (1 << 30)))
+        unit.set_quant_state(True, act_quant)
+        if TIMING is not None:
+            torch.cuda.synchronize()
+            TIMING["feat_s"] = TIMING.get("feat_s", 0.0) + time.time() - _t_feat
+            TIMING["feat_units"] = TIMING.get("feat_units", 0) + (feats is not None)
     for it in range(iters):
         if TIMING is not None and it == 1:                 # steady-state iterations only (bench.py): the first one
             torch.cuda.synchronize()                       # carries allocator warm-up and lazy initialisation
@@ -212,12 +253,15 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
         out_quant = unit(*args_q)
         m_loss = 0.0
         if is_block and hooks:
-            args_fp = (cur_sym, temb_sym) if resblock else (cur_sym,)
-            unit.set_quant_state(False, False)
-            with torch.no_grad():
-                unit(*args_fp)
-            module_r = [h.out for h in hooks]
-            unit.set_quant_state(True, act_quant)
+            if feats is not None:
+                module_r = [f[idx_t] for f in feats] + [None]
+            else:
+                args_fp = (cur_sym, temb_sym) if resblock else (cur_sym,)
+                unit.set_quant_state(False, False)
+                with torch.no_grad():
+                    unit(*args_fp)
+                module_r = [h.out for h in hooks]
+                unit.set_quant_state(True, act_quant)
             unit(*args_q)
             module_q = [h.out for h in hooks]
             for j in range(len(module_r) - 1):

@@ -135,3 +135,39 @@ def test_scale_init_cache_and_reconstruction(golden):
         out = qnn(x[:8], t[:8]).cpu().numpy()
     ref = g["g8/final/out_q"]
     assert np.abs(out - ref).max() < 0.08 * np.abs(ref).max()
+
+
+def test_fp_feature_cache_equals_per_iteration_fp_forward(golden):
+    """edadm/recon.py fp_features: the per-sample FP feature maps computed once equal what the per-iteration FP forward
+    of block_recon.py:170-178 yields for any drawn batch (rows are independent of the batch they ride in; the only
+    batch-dependent quantity is the f16 expansion's power-of-two scale, far below the tolerance)."""
+    from qdiff import QuantModel, set_weight_quantize_params, set_act_quantize_params
+    from qdiff.data_utils import save_inp_oup_data
+    from qdiff.quant_layer import QuantModule
+    from qdiff.utils import AttentionMap
+    from edadm import recon
+    g = golden("g8_recon")
+    aq = dict(AQ8)
+    aq["prob"] = 1.0
+    qnn = QuantModel(build_toynet(g), WQ4, aq, sm_abit=8).cuda().eval()
+    x, t = torch.as_tensor(g["x"]).cuda(), torch.as_tensor(g["t"]).cuda()
+    cali = (x, t)
+    set_weight_quantize_params(qnn, cali)
+    set_act_quantize_params(qnn, cali, batch_size=32)
+    for name in ("rb", "at"):
+        unit = getattr(qnn.model, name)
+        resblock, ci, co = save_inp_oup_data(qnn, unit, cali, True, True, batch_size=32, input_prob=True)
+        hooks = [AttentionMap(m) for m in unit.modules() if isinstance(m, QuantModule)]
+        sz = co.size(0)
+        feats = recon.fp_features(unit, hooks, ci, resblock, sz, 16, 1 << 30)
+        assert feats is not None and len(feats) == len(hooks) - 1 and all(f.shape[0] == sz for f in feats)
+        assert recon.fp_features(unit, hooks, ci, resblock, sz, 16, 1024) is None          # over budget: recompute path
+        idx = torch.tensor(random.Random(5).sample(range(sz), 16), device="cuda")
+        unit.set_quant_state(False, False)
+        with torch.no_grad():
+            unit(*((ci[1][0][idx], ci[1][1][idx]) if resblock else (ci[1][idx],)))
+        for f, h in zip(feats, hooks[:-1]):
+            ref = h.out
+            assert torch.allclose(f[idx], ref, rtol=1e-5, atol=1e-6 * float(ref.abs().max())), name
+        for h in hooks:
+            h.remove()
