@@ -178,6 +178,38 @@ def time_calibration(qnn, dev, n_calib=64, iters=3):
                                      "total": (t_cache[0] + feat) * 1024 / n_calib + setup + per_iter_all_units * 1000})
 
 
+def time_h1_contraction(dev):
+    """H1's dominant contraction on its own: the 3x3 192->192 convolution of the 64x64 level at the reconstruction batch
+    (32 rows), forward, on both contraction paths, timed with events on the launch stream.  fp32-equivalent rate =
+    2 M K N / t; the three-product path executes 3x those flops on the f16 MFMA (peak 2516 TFLOP/s dense), the
+    exact path runs on the fp32 MFMA (peak 157 TFLOP/s)."""
+    from edadm import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(32, 64, 64, 192, generator=g).to(dev)
+    w = (torch.randn(192, 3, 3, 192, generator=g) * 0.05).to(dev)
+    b = torch.randn(192, generator=g).to(dev)
+    flops = 2.0 * 32 * 64 * 64 * 9 * 192 * 192
+    out = {}
+    for name, fn in (("f16_three_product", lambda: ops.conv2d_f16x3_nhwc(x, w, b)), ("exact_fp32_mfma", lambda: ops.conv2d_f32_nhwc(x, w, b))):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        out[name] = {"ms": ms, "fp32_equivalent_tflops": flops / ms / 1e9}
+    t = out["f16_three_product"]
+    t["includes"] = "operand scan + f16 expansion of activations and filter + GEMM"
+    t["f16_mfma_tflops"] = 3 * t["fp32_equivalent_tflops"]
+    t["frac_of_f16_mfma_peak"] = t["f16_mfma_tflops"] / 2516.0
+    out["exact_fp32_mfma"]["frac_of_fp32_mfma_peak"] = out["exact_fp32_mfma"]["fp32_equivalent_tflops"] / 157.0
+    out["workload"] = "conv3x3 192->192, 32 x 64 x 64 NHWC fp32, forward"
+    return out
+
+
 def cpu_baseline(qnn, sd_cpu):
     """The oracle (CPU restatement of the reference's PyTorch fake-quant path) on this box's host
     cores: UNet forwards of one CFG-doubled image (2 rows, 1/20 of an image's work each), repeated until ~12 s of CPU
@@ -323,6 +355,7 @@ def main():
         if world == 1 and not args.no_calib:
             try:
                 line["calibration"]["reconstruction"] = time_calibration(qnn, dev)
+                line["calibration"]["h1_contraction"] = time_h1_contraction(dev)
             except Exception as e:
                 line["calibration"]["reconstruction"] = {"error": repr(e)}
         if world == 1 and not args.no_decode:
