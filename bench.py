@@ -86,12 +86,13 @@ def time_decoder(dev, B):
     pq = torch.nn.Conv2d(3, 3, 1).to(dev)
     eng = DecoderEngine(dec, pq, codebook=torch.randn(8192, 3, device=dev))
     z = torch.randn(B, 3, 64, 64, device=dev)
-    eng(z[:2])
+    eng(z)                                   # untimed pass at the full batch: allocator pools and code objects warm
     torch.cuda.synchronize()
     t0 = time.time()
-    img = eng(z)
+    for _ in range(2):
+        img = eng(z)
     torch.cuda.synchronize()
-    dt = time.time() - t0
+    dt = (time.time() - t0) / 2
     assert img.shape == (B, 3, 256, 256) and bool(torch.isfinite(img).all())
     return {"images": B, "wall_s": dt, "ms_per_image": 1e3 * dt / B, "tflops_fp32": B * 2 * 318.1e9 / dt / 1e12,
             "config": "VQ-f4 decoder, fp32 in / fp32 out; large convolutions as three f16-MFMA products over two-term f16 "

@@ -647,6 +647,23 @@ __device__ __forceinline__ void split4(const float4 v, float s, uint2& hi, uint2
     lo = *reinterpret_cast<uint2*>(l);
 }
 
+// order 2 (C % 16 == 0): out [R][T][C / 16][2][16] -- every 16 k-values as [hi x16 | lo x16], the operand layout of the
+// pair-mode GEMM (gemm.hip, operand type 3): each term crosses memory, L2 and LDS once and the kernel forms the three
+// products from the two fragments.
+__device__ __forceinline__ void split_store(uint2* rowbase, int64_t t, int64_t c, int64_t C4, int order, const uint2 hi,
+                                            const uint2 lo) {
+    if (order == 2) {
+        uint2* o = rowbase + t * 2 * C4 + (c >> 2) * 8 + (c & 3);
+        o[0] = hi;
+        o[4] = lo;
+    } else {
+        uint2* o = rowbase + t * 3 * C4 + c;
+        o[0] = hi;
+        o[C4] = order ? hi : lo;
+        o[2 * C4] = order ? lo : hi;
+    }
+}
+
 // x [R][T][C] fp32 -> out [R][T][3][C] f16.  order 0: (hi, lo, hi) = operand A; 1: (hi, hi, lo) = operand B.
 // PER_ROW: one scale per row r (a GEMM row of B: one output channel), computed here; else one scale for the tensor from
 // the partial maxima `part[0..g)`.  inv[r] (or inv[0]) = 1 / scale; with `comb`, block 0 also writes the GEMM's
@@ -675,15 +692,12 @@ __global__ void __launch_bounds__(256) k_split_f16(const float* __restrict__ x, 
             float s, iv;
             split_scale(fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3])), s, iv);
             if (threadIdx.x == 0) inv[r] = iv;
-            uint2* orow = out + r * row4 * 3;
+            uint2* orow = out + r * row4 * (order == 2 ? 2 : 3);
             for (int64_t i = threadIdx.x; i < row4; i += 256) {
                 const int64_t t = i / C4, c = i - t * C4;
                 uint2 hi, lo;
                 split4(xr[i], s, hi, lo);
-                uint2* o = orow + t * 3 * C4 + c;
-                o[0] = hi;
-                o[C4] = order ? hi : lo;
-                o[2 * C4] = order ? lo : hi;
+                split_store(orow, t, c, C4, order, hi, lo);
             }
         }
     } else {
@@ -706,10 +720,7 @@ __global__ void __launch_bounds__(256) k_split_f16(const float* __restrict__ x, 
             const int64_t rt = i / C4, c = i - rt * C4;       // rt = r * T + t
             uint2 hi, lo;
             split4(reinterpret_cast<const float4*>(x)[i], s, hi, lo);
-            uint2* o = out + rt * 3 * C4 + c;
-            o[0] = hi;
-            o[C4] = order ? hi : lo;
-            o[2 * C4] = order ? lo : hi;
+            split_store(out, rt, c, C4, order, hi, lo);
         }
     }
 }
@@ -717,7 +728,7 @@ __global__ void __launch_bounds__(256) k_split_f16(const float* __restrict__ x, 
 extern "C" int edadm_split_f16(const float* x, int64_t R, int64_t T, int64_t C, int order, int per_row,
                                const float* amax_parts, void* out, float* inv, const float* other, int64_t n_other,
                                float* comb, int64_t N, float* ws, void* stream) {
-    if (!x || !out || !inv || !ws || R <= 0 || T <= 0 || C <= 0 || (C & 3) || (order != 0 && order != 1))
+    if (!x || !out || !inv || !ws || R <= 0 || T <= 0 || C <= 0 || (C & 3) || order < 0 || order > 2 || (order == 2 && (C & 15)))
         return EDADM_EINVAL;
     if (comb && (!other || N <= 0 || (n_other != 1 && n_other != N) || per_row)) return EDADM_EINVAL;
     if (((uintptr_t)x & 15) || ((uintptr_t)out & 7)) return EDADM_EINVAL;
@@ -813,10 +824,16 @@ __global__ void __launch_bounds__(256) k_transpose_split_f16(const float* __rest
                 const _Float16 l0 = (_Float16)(a0 - (float)h0), l1 = (_Float16)(a1 - (float)h1);
                 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
                 const h2 hi = {h0, h1}, lo = {l0, l1};
-                _Float16* o = out + (c0 + cc) * 3 * R + base;
-                *reinterpret_cast<h2*>(o) = hi;
-                *reinterpret_cast<h2*>(o + L) = order ? hi : lo;
-                *reinterpret_cast<h2*>(o + 2 * L) = order ? lo : hi;
+                if (order == 2) {                            // [L / 16][2][16] per slab
+                    _Float16* o = out + (c0 + cc) * 2 * R + sl * 2 * L + (rl >> 4) * 32 + (rl & 15);
+                    *reinterpret_cast<h2*>(o) = hi;
+                    *reinterpret_cast<h2*>(o + 16) = lo;
+                } else {
+                    _Float16* o = out + (c0 + cc) * 3 * R + base;
+                    *reinterpret_cast<h2*>(o) = hi;
+                    *reinterpret_cast<h2*>(o + L) = order ? hi : lo;
+                    *reinterpret_cast<h2*>(o + 2 * L) = order ? lo : hi;
+                }
             }
         }
     }
@@ -834,7 +851,8 @@ extern "C" int edadm_absmax_parts(const float* x, int64_t n, float* parts, void*
 
 extern "C" int edadm_transpose_split_f16(const float* in, int64_t R, int64_t C, int64_t L, int order, const int32_t* geom,
                                          const float* amax_parts, void* out, float* inv, float* ws, void* stream) {
-    if (!in || !out || !inv || !ws || R <= 0 || C <= 0 || L <= 0 || (R % L) || (L & 1) || (order != 0 && order != 1))
+    if (!in || !out || !inv || !ws || R <= 0 || C <= 0 || L <= 0 || (R % L) || (L & 1) || order < 0 || order > 2 ||
+        (order == 2 && (L & 15)))
         return EDADM_EINVAL;
     if (((uintptr_t)in & 15) || ((uintptr_t)out & 3)) return EDADM_EINVAL;
     hipStream_t st = (hipStream_t)stream;

@@ -13,10 +13,10 @@
 // MFMAs (double-buffered LDS, one barrier per K-step).  A and B fragments use the same
 // (lane, byte) -> k map, so the dot product is independent of the hardware's k numbering.
 #include "common.h"
-// This file is compiled once per operand type (Makefile: -DEDADM_GEMM_DT=0 int8, 1 f16, 2 f32); each object holds
-// the kernels and C entry points of that type only, so the three builds run in parallel.
+// This file is compiled once per operand type (Makefile: -DEDADM_GEMM_DT=0 int8, 1 f16, 2 f32, 3 f16 two-term pairs);
+// each object holds the kernels and C entry points of that type only, so the builds run in parallel.
 #ifndef EDADM_GEMM_DT
-#error "compile with -DEDADM_GEMM_DT=0|1|2"
+#error "compile with -DEDADM_GEMM_DT=0|1|2|3"
 #endif
 #include <type_traits>
 #include "../../include/edadm.h"
@@ -52,6 +52,10 @@ struct ConvGeom {
 
 // operand types: 0 = int8 (i32 accumulate), 1 = f16, 2 = f32 (v_mfma_f32_32x32x2_f32: exact fp32 FMA chain; the
 // calibration graph's contraction).  A 16-byte fragment is 16 / 8 / 4 k-values.
+// 3 = fp32 operands as two-term f16 expansions (edadm_split_f16 order 2): every 64 bytes of a row are 16 k-values as
+// [hi x16 | lo x16], and a K-slice contributes a_hi.b_hi + a_lo.b_hi + a_hi.b_lo -- three f16 MFMAs on fragments
+// that went through global memory, L2 and LDS once (the [hi|lo|hi] x [hi|hi|lo] form over a 3x longer K moves each
+// hi term twice).
 template <int DT>
 struct Acc { typedef v16f type; };
 template <>
@@ -62,7 +66,7 @@ __device__ __forceinline__ void mma_step(const uint4& fa, const uint4& fb, typen
     if constexpr (DT == 0) {
         acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const v4i*>(&fa), *reinterpret_cast<const v4i*>(&fb),
                                                     acc, 0, 0, 0);
-    } else if constexpr (DT == 1) {
+    } else if constexpr (DT == 1 || DT == 3) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const v8h*>(&fa), *reinterpret_cast<const v8h*>(&fb),
                                                      acc, 0, 0, 0);
     } else {
@@ -669,6 +673,47 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
         if (kt + STAGES - 1 < nk) issue_tile((int)((kt + STAGES - 1) % STAGES), (kt + STAGES - 1) * 64);
         const uint8_t* As = smem + (int)(kt % STAGES) * TILE;
         const uint8_t* Bs = As + BM * 64;
+        if constexpr (DT == 3) {
+            // one 64-byte K-step = 16 k-values as [hi | lo]: chunks fh (hi) and 2 + fh (lo) of each row
+            uint4 fa[TM], fb[TN], fl[TN > TM ? TN : TM];
+            auto rdA = [&](int i, int c) {
+                const int r = wm * (TM * 32) + i * 32 + fr;
+                return *reinterpret_cast<const uint4*>(As + (r * 4 + (c ^ ((r >> 2) & 3))) * 16);
+            };
+            auto rdB = [&](int j, int c) {
+                const int r = wn * (TN * 32) + j * 32 + fr;
+                return *reinterpret_cast<const uint4*>(Bs + (r * 4 + (c ^ ((r >> 2) & 3))) * 16);
+            };
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = rdA(i, fh);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = rdB(j, fh);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (decltype(swp)::value) mma_step<DT>(fb[j], fa[i], acc[i][j]);
+                    else mma_step<DT>(fa[i], fb[j], acc[i][j]);
+                }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fl[j] = rdB(j, 2 + fh);                 // a_hi . b_lo
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (decltype(swp)::value) mma_step<DT>(fl[j], fa[i], acc[i][j]);
+                    else mma_step<DT>(fa[i], fl[j], acc[i][j]);
+                }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fl[i] = rdA(i, 2 + fh);                 // a_lo . b_hi
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (decltype(swp)::value) mma_step<DT>(fb[j], fl[i], acc[i][j]);
+                    else mma_step<DT>(fl[i], fb[j], acc[i][j]);
+                }
+        } else {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int c = 2 * ks + fh;
@@ -690,6 +735,7 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
                     if constexpr (decltype(swp)::value) mma_step<DT>(fb[j], fa[i], acc[i][j]);
                     else mma_step<DT>(fa[i], fb[j], acc[i][j]);
                 }
+        }
         }
     }
     };
@@ -869,6 +915,50 @@ k_gemm_nt8(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, cons
         if (kt + 1 < nk) issue_tile((int)((kt + 1) & 1), (kt + 1) * 128);
         const uint8_t* As = smem + (int)(kt & 1) * TILE;
         const uint8_t* Bs = As + BM * 128;
+        if constexpr (DT == 3) {
+            // a 128-byte K-step = two [hi x16 | lo x16] groups: chunks 4 g + fh (hi) and 4 g + 2 + fh (lo)
+#pragma unroll
+            for (int gq = 0; gq < 2; ++gq) {
+                uint4 fa[TM], fb[TN], fl[TN > TM ? TN : TM];
+                auto rdA = [&](int i, int c) {
+                    const int r = wm * 64 + i * 32 + fr;
+                    return *reinterpret_cast<const uint4*>(As + r * 128 + ((c ^ ((r >> 1) & 7)) * 16));
+                };
+                auto rdB = [&](int j, int c) {
+                    const int r = wn * (TN * 32) + j * 32 + fr;
+                    return *reinterpret_cast<const uint4*>(Bs + r * 128 + ((c ^ ((r >> 1) & 7)) * 16));
+                };
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = rdA(i, 4 * gq + fh);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j] = rdB(j, 4 * gq + fh);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if constexpr (decltype(swp)::value) mma_step<DT>(fb[j], fa[i], acc[i][j]);
+                        else mma_step<DT>(fa[i], fb[j], acc[i][j]);
+                    }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fl[j] = rdB(j, 4 * gq + 2 + fh);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if constexpr (decltype(swp)::value) mma_step<DT>(fl[j], fa[i], acc[i][j]);
+                        else mma_step<DT>(fa[i], fl[j], acc[i][j]);
+                    }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fl[i] = rdA(i, 4 * gq + 2 + fh);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if constexpr (decltype(swp)::value) mma_step<DT>(fb[j], fl[i], acc[i][j]);
+                        else mma_step<DT>(fl[i], fb[j], acc[i][j]);
+                    }
+            }
+        } else {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int c = 2 * ks + fh;
@@ -890,6 +980,7 @@ k_gemm_nt8(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, cons
                     if constexpr (decltype(swp)::value) mma_step<DT>(fb[j], fa[i], acc[i][j]);
                     else mma_step<DT>(fa[i], fb[j], acc[i][j]);
                 }
+        }
         }
     }
     };
@@ -1520,6 +1611,43 @@ extern "C" int edadm_gemm_f16_nt_q(const void* A, int64_t lda, int64_t strideA, 
     return launch_gemm<1>(A, lda * 2, strideA * 2, Bm, ldb * 2, strideB * 2, M, N, K * 2, g, nullptr, nullptr,
                               nullptr, 1, nullptr, 0, (float*)C, ldc, strideC, batch * inner, alpha, (hipStream_t)stream,
                               (int)inner, strideA_i * 2, strideB_i * 2, strideC_i, out_mode, oqp);
+}
+#endif
+
+#if EDADM_GEMM_DT == 3
+// fp32-grade contraction on the f16 MFMA: operands are the order-2 expansions of edadm_split_f16 /
+// edadm_transpose_split_f16 (per 16 k-values [hi x16 | lo x16], so K2 = 2 K f16 elements per row, K2 % 32 == 0).
+// Same contract as edadm_qgemm_f16 (per-column factor, bias, residual; implicit-GEMM gather with geom[4] = 2 C f16
+// "channels" per pixel) and edadm_gemm_f16_nt (batched, for the weight gradient's split-K slabs).
+extern "C" int edadm_qgemm_f16x3(const void* A, int64_t lda, const void* Wt, int64_t ldw, int64_t M, int64_t N,
+                                 int64_t K2, const int32_t* geom, const float* scale, const float* bias,
+                                 const float* residual, int64_t ldr, float* out, int64_t ldo, void* stream) {
+    if (!A || !Wt || !out || !scale || M <= 0 || N <= 0 || K2 <= 0 || (K2 & 31) || (ldw & 31)) return EDADM_EINVAL;
+    if (((uintptr_t)A & 15) || ((uintptr_t)Wt & 15)) return EDADM_EINVAL;
+    ConvGeom g{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (geom) {
+        const int32_t* p = geom;
+        g = ConvGeom{p[0], p[1], p[2], p[3], p[4] * 2, p[5], p[6], p[7], p[8], p[9], p[10], p[11], 0, 0, 0, 0};
+        if (g.mode != 1 || (g.Cin & 63) || (int64_t)g.KH * g.KW * p[4] != K2 || (int64_t)g.B * g.Ho * g.Wo != M ||
+            (int64_t)g.B * g.H * g.W * g.Cin >= (1ll << 31))
+            return EDADM_EINVAL;
+    } else if (lda & 31) {
+        return EDADM_EINVAL;
+    }
+    return launch_gemm<3>(A, lda * 2, 0, Wt, ldw * 2, 0, M, N, K2 * 2, g, scale, bias, nullptr, 1, residual, ldr, out, ldo,
+                          0, 1, 1.0f, (hipStream_t)stream);
+}
+
+extern "C" int edadm_gemm_f16x3_nt(const void* A, int64_t lda, int64_t strideA, const void* Bm, int64_t ldb,
+                                   int64_t strideB, float* C, int64_t ldc, int64_t strideC, int64_t batch, int64_t M,
+                                   int64_t N, int64_t K2, float alpha, void* stream) {
+    if (!A || !Bm || !C || batch <= 0 || M <= 0 || N <= 0 || K2 <= 0 || (K2 & 31) || (lda & 31) || (ldb & 31) ||
+        (strideA & 31) || (strideB & 31))
+        return EDADM_EINVAL;
+    if (((uintptr_t)A & 15) || ((uintptr_t)Bm & 15)) return EDADM_EINVAL;
+    ConvGeom g{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    return launch_gemm<3>(A, lda * 2, strideA * 2, Bm, ldb * 2, strideB * 2, M, N, K2 * 2, g, nullptr, nullptr, nullptr, 1,
+                          nullptr, 0, C, ldc, strideC, batch, alpha, (hipStream_t)stream);
 }
 #endif
 

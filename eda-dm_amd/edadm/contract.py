@@ -21,7 +21,7 @@ F16X3 = os.environ.get("EDADM_F16X3", "1") != "0"
 
 def _f16x3_linear(M, N, K):
     """worth the two conversion passes: enough output columns per converted operand byte"""
-    return F16X3 and K % 8 == 0 and N >= 256 and N * K >= 512 * 512 and M >= 2048
+    return F16X3 and K % 16 == 0 and N >= 256 and N * K >= 512 * 512 and M >= 2048
 
 
 def _split(M, O, K):
@@ -66,11 +66,11 @@ def _wgrad(gy2d, a2d, amax_g=None, amax_a=None, conv=None):
         xh, (KH, KW, stride, pad, Ho, Wo) = conv
         K = KH * KW * xh.shape[-1]
         S = _split(M, O, K)
-        if F16X3 and xh.shape[-1] % 64 == 0 and (M // S) % 8 == 0 and M % 4 == 0 and amax_a is not None:
+        if F16X3 and xh.shape[-1] % 64 == 0 and (M // S) % 16 == 0 and M % 4 == 0 and amax_a is not None:
             Ms = M // S
-            gt, inv_g = ops.transpose_split_f16(gy2d, Ms, 0, amax=amax_g)
-            at, inv_a = ops.transpose_split_f16(xh, Ms, 1, amax=amax_a, conv=(KH, KW, stride, pad, Ho, Wo))
-            slabs = ops.gemm_f16_nt(gt, 3 * M, 3 * Ms, at, 3 * M, 3 * Ms, S, O, K, 3 * Ms, 1.0)
+            gt, inv_g = ops.transpose_split_f16(gy2d, Ms, 2, amax=amax_g)
+            at, inv_a = ops.transpose_split_f16(xh, Ms, 2, amax=amax_a, conv=(KH, KW, stride, pad, Ho, Wo))
+            slabs = ops.gemm_f16x3_nt(gt, 2 * M, 2 * Ms, at, 2 * M, 2 * Ms, S, O, K, 2 * Ms)
             return (ops.sum_slabs(slabs) if S > 1 else slabs[0]).mul_(inv_g * inv_a)
         a2d = ops.im2col_f32(xh, KH, KW, stride, pad, Ho, Wo)
     K = a2d.shape[1]
@@ -82,12 +82,12 @@ def _wgrad(gy2d, a2d, amax_g=None, amax_a=None, conv=None):
         M = Mp
     S = _split(M, O, K)
     Ms = M // S
-    if F16X3 and Ms % 8 == 0 and M >= 2048 and O * K >= 128 * 128:
+    if F16X3 and Ms % 16 == 0 and M >= 2048 and O * K >= 128 * 128:
         # transposition, slab cut and two-term f16 expansion of both operands in one pass each; S slabs of K = 3 Ms on
         # the f16 MFMA; the two power-of-two scales come off after the ordered slab sum
-        gt, inv_g = ops.transpose_split_f16(gy2d, Ms, 0, amax=amax_g)    # [O][S][3][Ms]
-        at, inv_a = ops.transpose_split_f16(a2d, Ms, 1, amax=amax_a)     # [K][S][3][Ms]
-        slabs = ops.gemm_f16_nt(gt, 3 * M, 3 * Ms, at, 3 * M, 3 * Ms, S, O, K, 3 * Ms, 1.0)
+        gt, inv_g = ops.transpose_split_f16(gy2d, Ms, 2, amax=amax_g)    # [O][S][Ms / 16][2][16]
+        at, inv_a = ops.transpose_split_f16(a2d, Ms, 2, amax=amax_a)     # [K][S][Ms / 16][2][16]
+        slabs = ops.gemm_f16x3_nt(gt, 2 * M, 2 * Ms, at, 2 * M, 2 * Ms, S, O, K, 2 * Ms)
         return (ops.sum_slabs(slabs) if S > 1 else slabs[0]).mul_(inv_g * inv_a)
     gyT, aT = ops.transpose_f32(gy2d), ops.transpose_f32(a2d)            # [O][M], [K][M]
     if S == 1:

@@ -45,7 +45,7 @@ class DecoderEngine:
         if F16X3 and ops.f16x3_conv_ok(x, w) and x.shape[0] * x.shape[1] * x.shape[2] * (4 if ups else 1) >= 16384:
             key = ("h", id(conv))
             if key not in self._wc:                              # the filter's two-term f16 expansion, once
-                self._wc[key] = ops.split_f16(w, w.shape[0], w.shape[1] * w.shape[2], w.shape[3], 1, True)[:2]
+                self._wc[key] = ops.split_f16(w, w.shape[0], w.shape[1] * w.shape[2], w.shape[3], 2, True)[:2]
             return ops.conv2d_f16x3_nhwc(x, w, b, residual=residual, stride=1, pad=conv.padding[0], ups=ups,
                                          presplit=self._wc[key])
         return ops.conv2d_f32_nhwc(x, w, b, residual=residual, stride=1, pad=conv.padding[0], ups=ups)

@@ -517,7 +517,7 @@ def gemm_f32_nt(A, Bm, M, N, K, alpha=1.0, bias=None, residual=None, out=None, l
 
 def split_f16(x, R, T, C, order, per_row, other=None, N=0, amax=None):
     """fp32 [R][T][C] -> f16 [R][T][3][C] two-term expansion (edadm_split_f16).  Returns (planes, inv, comb)."""
-    out = torch.empty(R, T * 3 * C, dtype=torch.float16, device=x.device)
+    out = torch.empty(R, T * (2 if order == 2 else 3) * C, dtype=torch.float16, device=x.device)
     inv = torch.empty(R if per_row else 1, dtype=torch.float32, device=x.device)
     comb = torch.empty(N, dtype=torch.float32, device=x.device) if other is not None else None
     lib.call("edadm_split_f16", _pf(x), int(R), int(T), int(C), int(order), 1 if per_row else 0, _pf(amax),
@@ -545,7 +545,7 @@ def transpose_split_f16(x2d, L, order, amax=None, conv=None):
         gptr = ctypes.cast(geom, ctypes.c_void_p)
     else:
         (R, C), gptr = x2d.shape, None
-    out = torch.empty(C, 3 * R, dtype=torch.float16, device=x2d.device)
+    out = torch.empty(C, (2 if order == 2 else 3) * R, dtype=torch.float16, device=x2d.device)
     inv = torch.empty(1, dtype=torch.float32, device=x2d.device)
     lib.call("edadm_transpose_split_f16", _pf(x2d), int(R), int(C), int(L), int(order), gptr, _pf(amax),
              ctypes.c_void_p(out.data_ptr()), _pf(inv), _pf(workspace(x2d.device)), _stream())
@@ -555,32 +555,45 @@ def transpose_split_f16(x2d, L, order, amax=None, conv=None):
 def f16x3_conv_ok(x, w, ups=False):
     """shapes the three-product f16 path takes: 16-byte f16 channel groups and 32-bit gather offsets"""
     B, H, W, C = x.shape
-    return C % 8 == 0 and B * H * W * C * 6 < (1 << 31) and w.shape[0] >= 16
+    return C % 16 == 0 and B * H * W * C * 4 < (1 << 31) and w.shape[0] >= 16
 
 
 def conv2d_f16x3_nhwc(x, w, bias=None, residual=None, stride=1, pad=1, ups=False, presplit=None, amax=None):
-    """conv2d_f32_nhwc's contract on the f16 MFMA: both operands as two-term f16 expansions, three products in one
-    implicit GEMM over K = KH KW 3C, fp32 accumulation (fp32-grade result, see csrc/elem.hip)."""
+    """conv2d_f32_nhwc's contract on the f16 MFMA: both operands as two-term f16 expansions ([hi x16 | lo x16] per 16
+    channels), three products per K-slice in one implicit GEMM, fp32 accumulation (fp32-grade result, see csrc/elem.hip
+    and operand type 3 of csrc/gemm.hip).  C % 16 == 0."""
     B, H, W, C = x.shape
     N, KH, KW, _ = w.shape
     Hl, Wl = (2 * H, 2 * W) if ups else (H, W)
     Ho, Wo = (Hl + 2 * pad - KH) // stride + 1, (Wl + 2 * pad - KW) // stride + 1
-    wb, inv_b = presplit if presplit is not None else split_f16(w, N, KH * KW, C, 1, True)[:2]   # static weights: split once
-    xa, _, comb = split_f16(x, B * H * W, 1, C, 0, False, other=inv_b, N=N, amax=amax)
+    wb, inv_b = presplit if presplit is not None else split_f16(w, N, KH * KW, C, 2, True)[:2]   # static weights: split once
+    xa, _, comb = split_f16(x, B * H * W, 1, C, 2, False, other=inv_b, N=N, amax=amax)
     out = torch.empty(B, Ho, Wo, N, dtype=torch.float32, device=x.device)
-    geom = (ctypes.c_int32 * 12)(1, B, H, W, 3 * C, Ho, Wo, KH, KW, stride, pad, 1 if ups else 0)
-    qgemm_f16(xa, wb, B * Ho * Wo, N, KH * KW * 3 * C, comb, bias, out, geom=geom, residual=residual)
+    geom = (ctypes.c_int32 * 12)(1, B, H, W, 2 * C, Ho, Wo, KH, KW, stride, pad, 1 if ups else 0)
+    K2 = KH * KW * 2 * C
+    lib.call("edadm_qgemm_f16x3", ctypes.c_void_p(xa.data_ptr()), int(K2), ctypes.c_void_p(wb.data_ptr()), int(K2),
+             int(B * Ho * Wo), int(N), int(K2), ctypes.cast(geom, ctypes.c_void_p), _pf(comb), _pf(bias), _pf(residual),
+             int(N), _pf(out), int(N), _stream())
     return out
 
 
 def matmul_f16x3_nt(a2d, w2d, bias=None, residual=None, amax=None):
-    """[M][K] . [N][K]^T (+bias) (+residual) through the same expansion (K % 8 == 0)."""
+    """[M][K] . [N][K]^T (+bias) (+residual) through the same expansion (K % 16 == 0)."""
     M, K = a2d.shape
     N = w2d.shape[0]
-    wb, inv_b, _ = split_f16(w2d, N, 1, K, 1, True)
-    xa, _, comb = split_f16(a2d, M, 1, K, 0, False, other=inv_b, N=N, amax=amax)
+    wb, inv_b, _ = split_f16(w2d, N, 1, K, 2, True)
+    xa, _, comb = split_f16(a2d, M, 1, K, 2, False, other=inv_b, N=N, amax=amax)
     out = torch.empty(M, N, dtype=torch.float32, device=a2d.device)
-    qgemm_f16(xa, wb, M, N, 3 * K, comb, bias, out, residual=residual)
+    lib.call("edadm_qgemm_f16x3", ctypes.c_void_p(xa.data_ptr()), int(2 * K), ctypes.c_void_p(wb.data_ptr()), int(2 * K),
+             int(M), int(N), int(2 * K), None, _pf(comb), _pf(bias), _pf(residual), int(N), _pf(out), int(N), _stream())
+    return out
+
+
+def gemm_f16x3_nt(A, lda, strideA, Bm, ldb, strideB, batch, M, N, K2):
+    """C[z] = A[z] . B[z]^T over order-2 expansions (edadm_gemm_f16x3_nt): the weight gradient's split-K slabs."""
+    out = torch.empty(batch, M, N, dtype=torch.float32, device=A.device)
+    lib.call("edadm_gemm_f16x3_nt", ctypes.c_void_p(A.data_ptr()), int(lda), int(strideA), ctypes.c_void_p(Bm.data_ptr()),
+             int(ldb), int(strideB), _pf(out), int(N), int(M * N), int(batch), int(M), int(N), int(K2), 1.0, _stream())
     return out
 
 

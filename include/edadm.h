@@ -237,7 +237,10 @@ int edadm_gemm_f16_nt_q(const void* A, int64_t lda, int64_t strideA, int64_t str
  * comb[n] = inv[0] * other[n] (other[0] when n_other == 1) = the per-column factor edadm_qgemm_f16 applies to
  * the accumulators.  ws = edadm_reduce_ws_floats() floats.  The contraction itself is edadm_qgemm_f16 over K = 3 T C.
  * amax_parts: NULL, or the 1024 partial maxima edadm_absmax_parts wrote for this tensor (an operand that is
- * expanded more than once -- forward and weight gradient -- is scanned once). */
+ * expanded more than once -- forward and weight gradient -- is scanned once).
+ * order 2 (C % 16 == 0): out [R][T][C / 16][2][16] = every 16 k-values as [hi x16 | lo x16] (2 T C f16 per row) -- the
+ * operand layout of edadm_qgemm_f16x3 / edadm_gemm_f16x3_nt, whose kernels form the three products from the two
+ * fragments, so that each term crosses memory, L2 and LDS once. */
 int edadm_absmax_parts(const float* x, int64_t n, float* parts, void* stream);
 int edadm_split_f16(const float* x, int64_t R, int64_t T, int64_t C, int order, int per_row, const float* amax_parts,
                     void* out, float* inv, const float* other, int64_t n_other, float* comb, int64_t N, float* ws,
@@ -248,9 +251,20 @@ int edadm_split_f16(const float* x, int64_t R, int64_t T, int64_t C, int order, 
  * edadm_gemm_f16_nt over batch = R / L slabs of K = 3 L, summed by edadm_sum_slabs.
  * geom = host {B, H, W, C, Ho, Wo, KH, KW, stride, pad} (C % 64 == 0; amax_parts required): `in` is the NHWC activation
  * and the matrix is its im2col, gathered on the fly (R = B Ho Wo, C = KH KW C) -- the convolution's weight gradient
- * without the [M][KH KW C] matrix. */
+ * without the [M][KH KW C] matrix.
+ * order 2 (L % 16 == 0): out [C][R / L][L / 16][2][16], for edadm_gemm_f16x3_nt over slabs of K2 = 2 L. */
 int edadm_transpose_split_f16(const float* in, int64_t R, int64_t C, int64_t L, int order, const int32_t* geom,
                               const float* amax_parts, void* out, float* inv, float* ws, void* stream);
+/* The contraction over order-2 expansions (operand type 3 of the K4 template: per 64 operand bytes one hi.hi, one lo.hi
+ * and one hi.lo f16 MFMA, fp32 accumulation).  edadm_qgemm_f16x3: edadm_qgemm_f16's contract (out = acc * scale[n] +
+ * bias[n] (+ residual)), K2 = 2 K f16 per row (K2 % 32 == 0), geom[4] = 2 C f16 per pixel (C % 16 == 0).
+ * edadm_gemm_f16x3_nt: C[z] = alpha * A[z] . B[z]^T over `batch` slabs (element strides), for the weight gradient. */
+int edadm_qgemm_f16x3(const void* A, int64_t lda, const void* Wt, int64_t ldw, int64_t M, int64_t N, int64_t K2,
+                      const int32_t* geom, const float* scale, const float* bias, const float* residual, int64_t ldr,
+                      float* out, int64_t ldo, void* stream);
+int edadm_gemm_f16x3_nt(const void* A, int64_t lda, int64_t strideA, const void* Bm, int64_t ldb, int64_t strideB,
+                        float* C, int64_t ldc, int64_t strideC, int64_t batch, int64_t M, int64_t N, int64_t K2,
+                        float alpha, void* stream);
 int edadm_gemm_f32_nt(const float* A, int64_t lda, int64_t strideA, const float* Bm, int64_t ldb,
                       int64_t strideB, float* C, int64_t ldc, int64_t strideC, int64_t batch, int64_t M,
                       int64_t N, int64_t K, float alpha, const float* bias, const float* residual,
