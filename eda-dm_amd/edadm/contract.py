@@ -53,6 +53,13 @@ def _matmul_nt(a2d, w2d, bias=None, amax=None):
             return ops.matmul_f16x3_nt(a2d, w2d, bias, amax=amax)
         return ops.gemm_f32_nt(a2d, w2d, M, N, K, bias=bias)
     Ks = K // S
+    if F16X3 and Ks % 16 == 0 and M >= 1024 and N >= 256:
+        # the same slabs on the f16 three-product path: the [hi x16 | lo x16] layout cuts along K at any multiple of 16
+        wb, inv_b, _ = ops.split_f16(w2d, N, 1, K, 2, True)
+        xa, _, comb = ops.split_f16(a2d, M, 1, K, 2, False, other=inv_b, N=N, amax=amax)
+        slabs = ops.gemm_f16x3_nt(xa, 2 * K, 2 * Ks, wb, 2 * K, 2 * Ks, S, M, N, 2 * Ks)
+        out = ops.sum_slabs(slabs).mul_(comb)
+        return out if bias is None else out.add_(bias)
     slabs = ops.gemm_f32_nt(a2d, w2d, M, N, Ks, lda=K, ldb=K, batch=S, strideA=Ks, strideB=Ks)
     out = ops.sum_slabs(slabs)
     return out if bias is None else out.add_(bias)
@@ -167,7 +174,8 @@ class _Conv2dFn(torch.autograd.Function):
                 out = ops.conv2d_f32_nhwc(xh, w4, bias, stride=stride, pad=pad)
         else:                                                # few tiles (8x8 / 16x16 levels): im2col + split-K GEMM
             cols = xh.reshape(M, Cp) if one else ops.im2col_f32(xh, KH, KW, stride, pad, Ho, Wo)
-            out = _matmul_nt(cols, w4.reshape(O, KH * KW * Cp), bias).reshape(B, Ho, Wo, O)
+            px = _amax(xh)                                   # max |cols| = max |x|
+            out = _matmul_nt(cols, w4.reshape(O, KH * KW * Cp), bias, amax=px).reshape(B, Ho, Wo, O)
         ctx.save_for_backward(xh, w4.reshape(O, KH * KW * Cp))
         ctx.px = px if px is not None else _amax(xh)
         ctx.meta = (B, C, Cp, H, W, O, KH, KW, stride, pad, Ho, Wo, one, bias is not None)

@@ -17,7 +17,8 @@ def _cmp(a, b, tol=3e-5):
 
 @pytest.mark.parametrize("B,C,H,O,k,stride,pad", [(4, 32, 8, 48, 3, 1, 1), (2, 64, 16, 64, 3, 2, 1), (2, 64, 9, 32, 3, 2, 0),
                                                    (3, 64, 8, 32, 1, 1, 0), (2, 3, 16, 32, 3, 1, 1), (32, 192, 16, 192, 3, 1, 1),
-                                                   (32, 64, 64, 64, 3, 1, 1)])          # last two: f16 three-product path (fwd; fwd + dgrad)
+                                                   (32, 64, 64, 64, 3, 1, 1), (32, 256, 8, 256, 3, 1, 1)])
+# the last three take the f16 three-product path: implicit forward; forward + dgrad + gathered wgrad; split-K slabs (few tiles)
 def test_conv2d_fwd_bwd(B, C, H, O, k, stride, pad):
     from edadm import contract
     g = torch.Generator().manual_seed(B * C + O)
