@@ -35,7 +35,7 @@ for (B, H, C, N) in ((32, 64, 192, 192), (32, 32, 384, 384), (32, 16, 576, 576),
     fl = 2.0 * B * H * H * 9 * C * N / 1e9
     print("conv B%d %dx%d C%d->%d: fp32 %.3f ms (%.0f TF/s) err mean %.2e max %.2e | f16x3 %.3f ms (%.0f TF/s equiv) err mean %.2e max %.2e" % (
         B, H, H, C, N, t32, fl / t32, e32.mean() / rms, e32.max() / rms, t16, fl / t16, e16.mean() / rms, e16.max() / rms))
-for (M, K, N) in ((32768, 384, 3072), (32768, 1536, 384), (131072, 192, 192), (2048, 960, 960)):
+for (M, K, N) in ((32768, 384, 3072), (32768, 1536, 384), (131072, 192, 192), (2048, 960, 960), (32768, 384, 384), (32768, 384, 768), (8192, 576, 576), (131072, 192, 384), (131072, 384, 192)):
     a = torch.randn(M, K, generator=g).to(dev); w = (torch.randn(N, K, generator=g) * 0.05).to(dev); b = torch.randn(N, generator=g).to(dev)
     y32 = ops.gemm_f32_nt(a, w, M, N, K, bias=b); y16 = ops.matmul_f16x3_nt(a, w, b)
     ref = a[:256].double().cpu() @ w.double().cpu().T + b.double().cpu()
