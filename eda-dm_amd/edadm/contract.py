@@ -1,11 +1,15 @@
 """fp32 contraction of the calibration graph (H1) on hand-written kernels: `conv2d` / `conv1d(k=1)` /
-`linear` forward and autograd backward built from edadm_gemm_f32_nt (exact-fp32 MFMA, NT form),
-edadm_im2col_f32 / edadm_col2im_f32 and a split-K transposed product for the weight gradient
-(quant_layer.py:434 and the `loss.backward()` of block_recon.py:197).
+`linear` forward and autograd backward (quant_layer.py:434 and the `loss.backward()` of block_recon.py:197).
 
-    forward   Y[m][o]  = cols[m][k] . W[o][k]          cols = im2col(X) (NHWC rows), k = (ky, kx, c)
-    dX        dcols    = dY[m][o] . W^T[k][o]  -> col2im
-    dW        dW[o][k] = sum_m dY^T[o][m] . cols^T[k][m]   split over m into S slabs, summed in order
+    forward   Y[m][o]  = X(m, k) . W[o][k]          implicit GEMM over NHWC x, k = (ky, kx, c)
+    dX        stride-1 "same" convolutions: the same implicit GEMM of dY with the flipped, transposed filter;
+              otherwise dcols = dY[m][o] . W^T[k][o] -> col2im
+    dW        dW[o][k] = sum_m dY^T[o][m] . X^T[k][m]   split over m into S slabs, summed in order
+
+Large products run on the f16 MFMA as three products of two-term f16 expansions with fp32 accumulation
+(edadm_split_f16 / edadm_transpose_split_f16 + edadm_qgemm_f16x3 / edadm_gemm_f16x3_nt: fp32-grade results at about
+twice the exact-fp32 MFMA's rate); small or narrow ones on the exact-fp32 MFMA
+(edadm_gemm_f32_nt, edadm_conv2d_f32_nhwc, edadm_im2col_f32 / edadm_col2im_f32).  EDADM_F16X3=0: exact path only.
 """
 import os
 
