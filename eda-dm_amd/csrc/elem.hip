@@ -763,8 +763,8 @@ struct GatherGeom { int on, B, H, W, C, Ho, Wo, KH, KW, stride, pad; };
 // are 128 pixel rows of 256 contiguous bytes (zero outside the image) -- the [M][KH KW C] matrix is never written.
 __global__ void __launch_bounds__(256) k_transpose_split_f16(const float* __restrict__ in, int64_t R, int64_t C, int64_t L,
                                                              int order, const float* __restrict__ part, int g,
-                                                             _Float16* __restrict__ out, float* __restrict__ inv,
-                                                             const GatherGeom gg) {
+                                                             _Float16* __restrict__ out, int64_t ldo,
+                                                             float* __restrict__ inv, const GatherGeom gg) {
     __shared__ float tile[128][65];
     __shared__ float sm[4];
     __shared__ float s_amax;
@@ -780,37 +780,112 @@ __global__ void __launch_bounds__(256) k_transpose_split_f16(const float* __rest
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) inv[0] = iv;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t ctiles = (C + 63) / 64, rtiles = (R + 127) / 128, ntiles = ctiles * rtiles;
-    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int64_t r0 = (t / ctiles) * 128, c0 = (t % ctiles) * 64;
-        __syncthreads();
-        // load: thread -> (row = it * 16 + tid / 16, 4 columns at (tid % 16) * 4)
+    // workgroups are dealt round-robin to the 8 XCDs (one L2 each): give every XCD a contiguous range of tiles, so the
+    // column tiles of one row tile -- the 9 taps x C / 64 channel chunks that re-read the same 128 pixels -- hit one L2
+    const int64_t per_xcd = (ntiles + 7) / 8;
+    const int cc4 = (threadIdx.x & 15) * 4;
+    // tile of a walk position (false past the end); the loads of a tile into registers
+    auto tile_at = [&](int64_t tp, int64_t& r0, int64_t& c0) -> bool {
+        for (; tp < per_xcd * 8; tp += gridDim.x) {
+            const int64_t t = (tp & 7) * per_xcd + (tp >> 3);
+            if (t < ntiles) {
+                const int64_t rt_ = (int64_t)((uint32_t)t / (uint32_t)ctiles);
+                r0 = rt_ * 128;
+                c0 = (t - rt_ * ctiles) * 64;
+                return true;
+            }
+        }
+        return false;
+    };
+    auto fetch = [&](int64_t r0, int64_t c0, float4 (&v)[8]) {
+        // thread -> (row = it * 16 + tid / 16, 4 columns at (tid % 16) * 4)
+        if (gg.on) {
+            // pixel of this thread's first row by 32-bit division (R < 2^31), the next seven rows 16 pixels further each
+            const int tap = (int)((uint32_t)c0 / (uint32_t)gg.C), cb = (int)c0 - tap * gg.C;
+            const int ky = tap / gg.KW, kx = tap - ky * gg.KW;
+            const uint32_t hw = (uint32_t)(gg.Ho * gg.Wo);
+            const uint32_t rfirst = (uint32_t)r0 + (threadIdx.x >> 4);
+            int b = (int)(rfirst / hw);
+            const uint32_t p = rfirst - (uint32_t)b * hw;
+            int yo = (int)(p / (uint32_t)gg.Wo), xo = (int)(p - (uint32_t)yo * gg.Wo);
+            const float* src = in + cb + cc4;
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int rr = it * 16 + (threadIdx.x >> 4), cc = (threadIdx.x & 15) * 4;
-            const int64_t r = r0 + rr, c = c0 + cc;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gg.on) {
+            for (int it = 0; it < 8; ++it) {
+                const int rr = it * 16 + (threadIdx.x >> 4);
+                v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int iy = yo * gg.stride - gg.pad + ky, ix = xo * gg.stride - gg.pad + kx;
+                if (r0 + rr < R && iy >= 0 && iy < gg.H && ix >= 0 && ix < gg.W)
+                    v[it] = *reinterpret_cast<const float4*>(src + (((int64_t)b * gg.H + iy) * gg.W + ix) * gg.C);
+                xo += 16;
+                while (xo >= gg.Wo) { xo -= gg.Wo; ++yo; }
+                while (yo >= gg.Ho) { yo -= gg.Ho; ++b; }
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int rr = it * 16 + (threadIdx.x >> 4);
+                const int64_t r = r0 + rr, c = c0 + cc4;
+                v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (r < R) {
-                    const int tap = (int)(c0 / gg.C), cb = (int)(c0 - (int64_t)tap * gg.C);
-                    const int ky = tap / gg.KW, kx = tap - ky * gg.KW;
-                    const int hw = gg.Ho * gg.Wo, b = (int)(r / hw), p = (int)(r - (int64_t)b * hw);
-                    const int yo = p / gg.Wo, xo = p - yo * gg.Wo;
-                    const int iy = yo * gg.stride - gg.pad + ky, ix = xo * gg.stride - gg.pad + kx;
-                    if (iy >= 0 && iy < gg.H && ix >= 0 && ix < gg.W)
-                        v = *reinterpret_cast<const float4*>(in + (((int64_t)b * gg.H + iy) * gg.W + ix) * gg.C + cb + cc);
-                }
-            } else if (r < R) {
-                if (c + 3 < C && (C & 3) == 0) v = *reinterpret_cast<const float4*>(in + r * C + c);
-                else {
-                    if (c < C) v.x = in[r * C + c];
-                    if (c + 1 < C) v.y = in[r * C + c + 1];
-                    if (c + 2 < C) v.z = in[r * C + c + 2];
-                    if (c + 3 < C) v.w = in[r * C + c + 3];
+                    if (c + 3 < C && (C & 3) == 0) v[it] = *reinterpret_cast<const float4*>(in + r * C + c);
+                    else {
+                        if (c < C) v[it].x = in[r * C + c];
+                        if (c + 1 < C) v[it].y = in[r * C + c + 1];
+                        if (c + 2 < C) v[it].z = in[r * C + c + 2];
+                        if (c + 3 < C) v[it].w = in[r * C + c + 3];
+                    }
                 }
             }
-            tile[rr][cc] = v.x; tile[rr][cc + 1] = v.y; tile[rr][cc + 2] = v.z; tile[rr][cc + 3] = v.w;
         }
+    };
+    float4 v[8];
+    int64_t tp = blockIdx.x, r0 = 0, c0 = 0, rn = 0, cn = 0;
+    bool have = tile_at(tp, r0, c0);
+    if (have) fetch(r0, c0, v);
+    for (; have; r0 = rn, c0 = cn) {
+        __syncthreads();                                     // the previous tile's store phase is done with `tile`
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int rr = it * 16 + (threadIdx.x >> 4);
+            tile[rr][cc4] = v[it].x; tile[rr][cc4 + 1] = v[it].y; tile[rr][cc4 + 2] = v[it].z; tile[rr][cc4 + 3] = v[it].w;
+        }
+        // the next tile's loads fly while this one is converted and stored
+        {
+            int64_t t2 = tp + gridDim.x;
+            for (; t2 < per_xcd * 8; t2 += gridDim.x)
+                if ((t2 & 7) * per_xcd + (t2 >> 3) < ntiles) break;
+            tp = t2;
+        }
+        have = tile_at(tp, rn, cn);
+        if (have) fetch(rn, cn, v);
         __syncthreads();
+        if (order == 2) {
+            // lane -> (output row j of 8, 16-row group g of 8): 16 values down one tile column become one
+            // [hi x16 | lo x16] group = 64 contiguous bytes = four 16-byte stores; a wave writes 8 rows x 512 bytes
+            const int j = lane >> 3, gq = lane & 7;
+            const int64_t r = r0 + 16 * gq;
+            if (r < R) {
+                const int64_t sl = (int64_t)((uint32_t)r / (uint32_t)L), rl = r - sl * L;
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int cc = w * 16 + p * 8 + j;
+                    if (c0 + cc >= C) continue;
+                    _Float16 h[16], l[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float a = tile[16 * gq + i][cc] * s;
+                        h[i] = (_Float16)a;
+                        l[i] = (_Float16)(a - (float)h[i]);
+                    }
+                    uint4* o = reinterpret_cast<uint4*>(out + (c0 + cc) * ldo + sl * 2 * L + (rl >> 4) * 32);
+                    o[0] = reinterpret_cast<const uint4*>(h)[0];
+                    o[1] = reinterpret_cast<const uint4*>(h)[1];
+                    o[2] = reinterpret_cast<const uint4*>(l)[0];
+                    o[3] = reinterpret_cast<const uint4*>(l)[1];
+                }
+            }
+            continue;
+        }
         const int64_t r = r0 + 2 * lane;                         // this lane's pair of reduction rows (R, L even)
         if (r < R) {
             const int64_t sl = r / L, rl = r - sl * L;
@@ -825,11 +900,11 @@ __global__ void __launch_bounds__(256) k_transpose_split_f16(const float* __rest
                 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
                 const h2 hi = {h0, h1}, lo = {l0, l1};
                 if (order == 2) {                            // [L / 16][2][16] per slab
-                    _Float16* o = out + (c0 + cc) * 2 * R + sl * 2 * L + (rl >> 4) * 32 + (rl & 15);
+                    _Float16* o = out + (c0 + cc) * ldo + sl * 2 * L + (rl >> 4) * 32 + (rl & 15);
                     *reinterpret_cast<h2*>(o) = hi;
                     *reinterpret_cast<h2*>(o + 16) = lo;
                 } else {
-                    _Float16* o = out + (c0 + cc) * 3 * R + base;
+                    _Float16* o = out + (c0 + cc) * ldo + base;
                     *reinterpret_cast<h2*>(o) = hi;
                     *reinterpret_cast<h2*>(o + L) = order ? hi : lo;
                     *reinterpret_cast<h2*>(o + 2 * L) = order ? lo : hi;
@@ -850,11 +925,12 @@ extern "C" int edadm_absmax_parts(const float* x, int64_t n, float* parts, void*
 }
 
 extern "C" int edadm_transpose_split_f16(const float* in, int64_t R, int64_t C, int64_t L, int order, const int32_t* geom,
-                                         const float* amax_parts, void* out, float* inv, float* ws, void* stream) {
+                                         const float* amax_parts, void* out, int64_t ldo, float* inv, float* ws,
+                                         void* stream) {
     if (!in || !out || !inv || !ws || R <= 0 || C <= 0 || L <= 0 || (R % L) || (L & 1) || order < 0 || order > 2 ||
-        (order == 2 && (L & 15)))
+        (order == 2 && (L & 15)) || ldo < (order == 2 ? 2 : 3) * R || (ldo & 7) || R >= (1ll << 31) || ((C + 63) / 64) * ((R + 127) / 128) >= (1ll << 31))
         return EDADM_EINVAL;
-    if (((uintptr_t)in & 15) || ((uintptr_t)out & 3)) return EDADM_EINVAL;
+    if (((uintptr_t)in & 15) || ((uintptr_t)out & (order == 2 ? 15 : 3))) return EDADM_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     GatherGeom gg{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (geom) {                              // {B, H, W, C, Ho, Wo, KH, KW, stride, pad}: `in` is the NHWC activation
@@ -873,7 +949,8 @@ extern "C" int edadm_transpose_split_f16(const float* in, int64_t R, int64_t C, 
         amax_parts = ws;
     }
     const int64_t ntiles = ((C + 63) / 64) * ((R + 127) / 128);
-    hipLaunchKernelGGL(k_transpose_split_f16, dim3((unsigned)(ntiles < 4096 ? ntiles : 4096)), dim3(256), 0, st, in, R, C, L,
-                       order, amax_parts, g, (_Float16*)out, inv, gg);
+    const int64_t padded = ((ntiles + 7) / 8) * 8;                       // grid a multiple of 8: tp & 7 is the XCD
+    hipLaunchKernelGGL(k_transpose_split_f16, dim3((unsigned)(padded < 4096 ? padded : 4096)), dim3(256), 0, st, in, R, C, L,
+                       order, amax_parts, g, (_Float16*)out, ldo, inv, gg);
     return edadm_launch_status();
 }

@@ -81,7 +81,7 @@ def _wgrad(gy2d, a2d, amax_g=None, amax_a=None, conv=None):
             Ms = M // S
             gt, inv_g = ops.transpose_split_f16(gy2d, Ms, 2, amax=amax_g)
             at, inv_a = ops.transpose_split_f16(xh, Ms, 2, amax=amax_a, conv=(KH, KW, stride, pad, Ho, Wo))
-            slabs = ops.gemm_f16x3_nt(gt, 2 * M, 2 * Ms, at, 2 * M, 2 * Ms, S, O, K, 2 * Ms)
+            slabs = ops.gemm_f16x3_nt(gt, gt.shape[1], 2 * Ms, at, at.shape[1], 2 * Ms, S, O, K, 2 * Ms)
             return (ops.sum_slabs(slabs) if S > 1 else slabs[0]).mul_(inv_g * inv_a)
         a2d = ops.im2col_f32(xh, KH, KW, stride, pad, Ho, Wo)
     K = a2d.shape[1]
@@ -98,7 +98,7 @@ def _wgrad(gy2d, a2d, amax_g=None, amax_a=None, conv=None):
         # the f16 MFMA; the two power-of-two scales come off after the ordered slab sum
         gt, inv_g = ops.transpose_split_f16(gy2d, Ms, 2, amax=amax_g)    # [O][S][Ms / 16][2][16]
         at, inv_a = ops.transpose_split_f16(a2d, Ms, 2, amax=amax_a)     # [K][S][Ms / 16][2][16]
-        slabs = ops.gemm_f16x3_nt(gt, 2 * M, 2 * Ms, at, 2 * M, 2 * Ms, S, O, K, 2 * Ms)
+        slabs = ops.gemm_f16x3_nt(gt, gt.shape[1], 2 * Ms, at, at.shape[1], 2 * Ms, S, O, K, 2 * Ms)
         return (ops.sum_slabs(slabs) if S > 1 else slabs[0]).mul_(inv_g * inv_a)
     gyT, aT = ops.transpose_f32(gy2d), ops.transpose_f32(a2d)            # [O][M], [K][M]
     if S == 1:

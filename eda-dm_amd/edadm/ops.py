@@ -535,7 +535,7 @@ def absmax_parts(x):
 
 
 def transpose_split_f16(x2d, L, order, amax=None, conv=None):
-    """[R][C] fp32 -> ([C][R/L][3][L] f16, inv) (edadm_transpose_split_f16).  conv = (KH, KW, stride, pad, Ho, Wo): x2d is
+    """[R][C] fp32 -> ([C][R/L][...] f16 with row stride out.shape[1], inv) (edadm_transpose_split_f16).  conv = (KH, KW, stride, pad, Ho, Wo): x2d is
     the NHWC activation [B][H][W][C] and the matrix its im2col, gathered on the fly."""
     if conv is not None:
         B, H, W, Cc = x2d.shape
@@ -545,10 +545,11 @@ def transpose_split_f16(x2d, L, order, amax=None, conv=None):
         gptr = ctypes.cast(geom, ctypes.c_void_p)
     else:
         (R, C), gptr = x2d.shape, None
-    out = torch.empty(C, (2 if order == 2 else 3) * R, dtype=torch.float16, device=x2d.device)
+    ld = (2 if order == 2 else 3) * R + 128          # rows a power of two apart would all sit on the same HBM channels
+    out = torch.empty(C, ld, dtype=torch.float16, device=x2d.device)
     inv = torch.empty(1, dtype=torch.float32, device=x2d.device)
     lib.call("edadm_transpose_split_f16", _pf(x2d), int(R), int(C), int(L), int(order), gptr, _pf(amax),
-             ctypes.c_void_p(out.data_ptr()), _pf(inv), _pf(workspace(x2d.device)), _stream())
+             ctypes.c_void_p(out.data_ptr()), int(ld), _pf(inv), _pf(workspace(x2d.device)), _stream())
     return out, inv
 
 

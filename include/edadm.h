@@ -252,9 +252,11 @@ int edadm_split_f16(const float* x, int64_t R, int64_t T, int64_t C, int order, 
  * geom = host {B, H, W, C, Ho, Wo, KH, KW, stride, pad} (C % 64 == 0; amax_parts required): `in` is the NHWC activation
  * and the matrix is its im2col, gathered on the fly (R = B Ho Wo, C = KH KW C) -- the convolution's weight gradient
  * without the [M][KH KW C] matrix.
- * order 2 (L % 16 == 0): out [C][R / L][L / 16][2][16], for edadm_gemm_f16x3_nt over slabs of K2 = 2 L. */
+ * order 2 (L % 16 == 0): out [C][R / L][L / 16][2][16], for edadm_gemm_f16x3_nt over slabs of K2 = 2 L.
+ * ldo = f16 elements between output rows (>= 2 R or 3 R, % 8 == 0): callers pad it off powers of two, which would put
+ * every output row on the same HBM channels. */
 int edadm_transpose_split_f16(const float* in, int64_t R, int64_t C, int64_t L, int order, const int32_t* geom,
-                              const float* amax_parts, void* out, float* inv, float* ws, void* stream);
+                              const float* amax_parts, void* out, int64_t ldo, float* inv, float* ws, void* stream);
 /* The contraction over order-2 expansions (operand type 3 of the K4 template: per 64 operand bytes one hi.hi, one lo.hi
  * and one hi.lo f16 MFMA, fp32 accumulation).  edadm_qgemm_f16x3: edadm_qgemm_f16's contract (out = acc * scale[n] +
  * bias[n] (+ residual)), K2 = 2 K f16 per row (K2 % 32 == 0), geom[4] = 2 C f16 per pixel (C % 16 == 0).
