@@ -338,7 +338,9 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "int8 (i8 MFMA, i32 accumulate; fp32 epilogues)",
             "data": "synthetic",
             "config": {"workload": "ImageNet LDM-4 256x256 W4A8: 50-image batches x 20 DDIM steps x CFG (100 UNet rows/call), "
-                                   "400.9M-param cin256-v2 UNet, random-init weights, latents+context resident in HBM; "
+                                   "400.9M-param cin256-v2 UNet, random-init weights, latents+context resident in HBM; the one-token "
+                                   "cross-attention vectors (a function of the context alone) are evaluated once per batch "
+                                   "inside the timed sample() call, bit-identical to per-step evaluation; "
                                    "first-stage VQ decode outside the hot path (SURVEY 8f-3)",
                        "images_per_step": B, "ddim_steps": 20, "cfg_scale": 3.0, "parallelism": "dp%d (independent batches, no collective)" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": I8_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -10,28 +10,46 @@ from .schedule import make_beta_schedule, make_ddim_timesteps, make_ddim_samplin
 
 
 class GraphedUNet:
-    """Static-shape HIP-graph replay of `engine(x, t, ctx)`."""
+    """Static-shape HIP-graph replay of `engine(x, t, ctx)`.  With a one-token context the cross-attention branches
+    are a function of the context alone (Engine.context_branches): they get their own graph, replayed when the
+    context changes -- once per sample batch -- and the per-step graph only adds their vectors."""
 
     def __init__(self, engine, x, t, ctx, warmup=2):
         self.engine = engine
         self.x, self.t = x.clone(), t.clone()
         self.ctx = None if ctx is None else ctx.clone()
+        self._ctx_src, self._ctx_ver = None, -1
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(warmup):
+                engine.ctx_r = engine.context_branches(self.ctx) if hasattr(engine, "context_branches") else None
                 self.out = engine(self.x, self.t, self.ctx)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        self.ctx_graph, self.ctx_r = None, None
+        if getattr(engine, "ctx_r", None) is not None:
+            self.ctx_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.ctx_graph):
+                self.ctx_r = engine.context_branches(self.ctx)
+        engine.ctx_r = self.ctx_r
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = engine(self.x, self.t, self.ctx)
+        try:
+            with torch.cuda.graph(self.graph):
+                self.out = engine(self.x, self.t, self.ctx)
+        finally:
+            engine.ctx_r = None                       # eager calls of the engine keep evaluating the branch per call
+        if self.ctx_graph is not None:
+            self.ctx_graph.replay()                   # capture does not execute: make the vectors match self.ctx now
 
     def __call__(self, x, t, ctx=None):
         self.x.copy_(x)
         self.t.copy_(t)
-        if ctx is not None:
+        if ctx is not None and (ctx is not self._ctx_src or ctx._version != self._ctx_ver):
             self.ctx.copy_(ctx)
+            self._ctx_src, self._ctx_ver = ctx, ctx._version
+            if self.ctx_graph is not None:
+                self.ctx_graph.replay()
         self.graph.replay()
         return self.out
 

@@ -61,3 +61,29 @@ def test_one_token_context_shortcut_is_bit_exact(golden):
         eng.one_token_context = False
         full = eng(x, t, ctx)
     assert torch.equal(short, full)
+
+
+def test_context_branches_hoisted_out_of_the_step_graph_bit_exact(golden):
+    """sampling.GraphedUNet computes the one-token cross-attention vectors in a graph of their own, replayed when the
+    context changes, and the per-step graph only adds them: same bits as the eager engine evaluating the branch inside
+    every call (the softmax over one key is exactly 1 whatever the query), for successive contexts and timesteps."""
+    from edadm.sampling import GraphedUNet
+    g = golden("g13_ldm_imagenet")
+    qnn, (x, t, c), _ = quantize_like_reference(build_ldm(g), g, "ldm")
+    assert c.shape[1] == 1
+    qnn.set_quant_state(True, True)
+    with torch.no_grad():
+        eng = qnn.freeze()
+        assert eng.context_branches(c) is not None and eng.ctx_r is None
+        gu = GraphedUNet(eng, x, t, c)
+        assert gu.ctx_graph is not None and eng.ctx_r is None
+        for k in range(3):
+            ck = (c * (1.0 + 0.5 * k)).contiguous()
+            for tt in (t, (t + 37) % 1000):
+                ref = eng(x, tt, ck)
+                got = gu(x, tt, ck)
+                assert torch.equal(got, ref), (k, float((got - ref).abs().max()))
+        # an in-place update of the same context tensor is noticed too
+        ck.mul_(0.5)
+        assert torch.equal(gu(x, t, ck), eng(x, t, ck))
+        assert eng.context_branches(torch.cat([c, c], 1)) is None                   # more than one token: no shortcut
