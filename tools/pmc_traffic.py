@@ -26,8 +26,8 @@ wkb = sum(v[1] for k, v in write.items() if is_i8(k))
 out = {
     "kernel": "int8 GEMM launches of edadm_qgemm_i8 / _q (k_gemm_nt8<0,*>, k_gemm_p<0,*>, k_gemm_nt<0,*>)",
     "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, in a separate pass, --pmc WRITE_SIZE) --output-format csv -- python "
-               "tools/unet_prof.py  [N_CALLS=2: 4 eager UNet calls of the frozen LDM-4 engine, 100 rows]",
-    "launches": nl, "FETCH_SIZE_sum_KB": fkb, "WRITE_SIZE_sum_KB": wkb,
+               "tools/unet_prof.py  [N_CALLS=2: 4 eager UNet calls of the frozen LDM-4 engine as a DDIM step issues them, 100 rows]",
+    "launches": nl, "unet_calls": int(sys.argv[4]) if len(sys.argv) > 4 else 4, "FETCH_SIZE_sum_KB": fkb, "WRITE_SIZE_sum_KB": wkb,
     "correction": "MI355X_MICROARCH.md HBM: FETCH_SIZE reports 1/2 of a wide (16 B/lane) streaming read on gfx950 -> x2; WRITE_SIZE exact; unit KB -> x1024",
     "fetch_bytes_per_launch_corrected": fkb * 2 * 1024 / max(nl, 1),
     "write_bytes_per_launch": wkb * 1024 / max(nl, 1),

@@ -1,4 +1,4 @@
-"""Diagnostic: 3 eager UNet calls of the frozen LDM-4 engine (for rocprofv3 --kernel-trace --stats)."""
+"""Diagnostic: eager UNet calls of the frozen LDM-4 engine as a DDIM step issues them (for rocprofv3 --kernel-trace --stats / --pmc)."""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "eda-dm_amd"))
@@ -9,6 +9,7 @@ eng = qnn.freeze()
 B = 50
 x = torch.randn(2 * B, 3, 64, 64, device=dev); t = torch.full((2 * B,), 501, dtype=torch.long, device=dev)
 c = torch.randn(2 * B, 1, 512, device=dev)
+eng.ctx_r = eng.context_branches(c)          # the per-step launch set of the sampling loops (context vectors precomputed)
 torch.cuda.synchronize()
 import ctypes
 hip = ctypes.CDLL("libamdhip64.so")
