@@ -113,6 +113,7 @@ class Engine:
         self._attn_cache = {}
         self.one_token_context = os.environ.get("EDADM_ONE_TOKEN_CONTEXT", "1") != "0"
         self.ctx_r = None            # {id(transformer block): [B][C]} from context_branches(), set by a sampling loop
+        self.emb_r = None            # {id(emb projection): [B][N]} time-embedding rows of the current step (emb_tables())
         self.gn_from_producer = os.environ.get("EDADM_GN_FROM_PRODUCER", "0") == "1"   # measured slower (58.4 vs 61.7 img/s): off
         self.graph = None
         self.prof = None
@@ -351,9 +352,49 @@ class Engine:
 
     def emb_proj(self, qm, emb):
         """silu(emb) -> quantise -> linear: the per-block time-embedding projection [B][N]."""
+        if self.emb_r is not None and id(qm) in self.emb_r:
+            return self.emb_r[id(qm)]
         L = self.L(qm)
         assert L.mode == "i8"
         return self._gemm(L, ops.silu_quant_i8(emb, L.qp), emb.shape[0])
+
+    def emb_tables(self, ts_all, steps):
+        """The time-embedding path of every step of a fixed schedule in one pass: ts_all = the `steps` timestep vectors
+        of a sampling run back to back ([steps * B]).  Returns (table [steps][F], {id(projection): (offset, N)}): row s
+        holds, for every ResBlock, its [B][N] projection of step s -- the same kernels on steps * B rows instead of
+        B rows per step (rows are independent, integer accumulation: the same bits), 2 + 2 x 22 launches per run
+        instead of per step.  None for networks without this structure."""
+        if isinstance(self.net, ddpm_unet.Model):
+            return None
+        with torch.no_grad():
+            net = self.net
+            M = ts_all.numel()
+            B = M // steps
+            temb = self._sinusoid(ts_all, net.model_channels, ddpm=False)
+            h0 = self.lin(net.time_embed[0], temb)
+            L2 = self.L(net.time_embed[2])
+            emb = self._gemm(L2, ops.silu_quant_i8(h0, L2.qp), M)
+            outs, layout, off = [], {}, 0
+            for m in net.modules():
+                layers = getattr(m, "emb_layers", None)
+                if layers is None or id(layers[1]) in layout:
+                    continue
+                e = self.emb_proj(layers[1], emb)                                   # [steps * B][N]
+                N = e.shape[1]
+                outs.append(e.reshape(steps, B * N))
+                layout[id(layers[1])] = (off, N)
+                off += B * N
+            return torch.cat(outs, 1).contiguous(), layout
+
+    def emb_rows(self, timesteps):
+        """{id(projection): [B][N]} for ONE timestep vector: what a loop's step reads from its table row (diagnostics:
+        lets an eager call issue exactly a step's launches)."""
+        r = self.emb_tables(timesteps, 1)
+        if r is None:
+            return None
+        tab, layout = r
+        B = timesteps.numel()
+        return {k: tab[0, off:off + B * n].view(B, n) for k, (off, n) in layout.items()}
 
     # ------------------------------------------------------------------ attention core (K6)
     def _aq(self, q):
@@ -675,10 +716,13 @@ class Engine:
     def forward_ldm(self, x, timesteps, context=None):
         net = self.net
         B = x.shape[0]
-        temb = self._sinusoid(timesteps, net.model_channels, ddpm=False)
-        h0 = self.lin(net.time_embed[0], temb)
-        L2 = self.L(net.time_embed[2])
-        emb = self._gemm(L2, ops.silu_quant_i8(h0, L2.qp), B)
+        if self.emb_r is not None:
+            emb = None                       # every projection of this step comes from the run's table (emb_tables)
+        else:
+            temb = self._sinusoid(timesteps, net.model_channels, ddpm=False)
+            h0 = self.lin(net.time_embed[0], temb)
+            L2 = self.L(net.time_embed[2])
+            emb = self._gemm(L2, ops.silu_quant_i8(h0, L2.qp), B)
         ctx = None if context is None else context.contiguous().float()
         h = ops.nchw_to_nhwc(x.contiguous().float())
         hs = []

@@ -14,16 +14,26 @@ class GraphedUNet:
     are a function of the context alone (Engine.context_branches): they get their own graph, replayed when the
     context changes -- once per sample batch -- and the per-step graph only adds their vectors."""
 
-    def __init__(self, engine, x, t, ctx, warmup=2):
+    def __init__(self, engine, x, t, ctx, warmup=2, timesteps=None):
+        """timesteps: the schedule of the run (one int per step, in call order).  With it the time-embedding path of all
+        steps is one graph replayed by begin() at the start of a run (Engine.emb_tables), and a step -- called with
+        its index -- copies its row of that table instead of recomputing 2 + 2 x 22 tiny launches."""
         self.engine = engine
         self.x, self.t = x.clone(), t.clone()
         self.ctx = None if ctx is None else ctx.clone()
         self._ctx_src, self._ctx_ver = None, -1
+        rows = x.shape[0]
+        self.emb_graph = self.emb_tab = self.emb_stage = None
+        ts_all = None
+        if timesteps is not None and hasattr(engine, "emb_tables"):
+            ts_all = torch.tensor(np.repeat(np.asarray(timesteps, dtype=np.int64), rows), device=x.device)
+        self.ts_all = ts_all                          # an input of the table graph: must outlive this constructor
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(warmup):
                 engine.ctx_r = engine.context_branches(self.ctx) if hasattr(engine, "context_branches") else None
+                tabs = engine.emb_tables(ts_all, len(timesteps)) if ts_all is not None else None
                 self.out = engine(self.x, self.t, self.ctx)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
@@ -33,18 +43,37 @@ class GraphedUNet:
             with torch.cuda.graph(self.ctx_graph):
                 self.ctx_r = engine.context_branches(self.ctx)
         engine.ctx_r = self.ctx_r
+        emb_r = None
+        if ts_all is not None and tabs is not None:
+            self.emb_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.emb_graph):
+                self.emb_tab, layout = engine.emb_tables(ts_all, len(timesteps))
+            self.emb_stage = torch.empty_like(self.emb_tab[0])
+            emb_r = {k: self.emb_stage[off:off + rows * n].view(rows, n) for k, (off, n) in layout.items()}
+        engine.emb_r = emb_r
         self.graph = torch.cuda.CUDAGraph()
         try:
             with torch.cuda.graph(self.graph):
                 self.out = engine(self.x, self.t, self.ctx)
         finally:
-            engine.ctx_r = None                       # eager calls of the engine keep evaluating the branch per call
+            engine.ctx_r = None                       # eager calls of the engine keep evaluating both per call
+            engine.emb_r = None
         if self.ctx_graph is not None:
             self.ctx_graph.replay()                   # capture does not execute: make the vectors match self.ctx now
+        self.begin()
 
-    def __call__(self, x, t, ctx=None):
+    def begin(self):
+        """Start of a sampling run: the time-embedding table of the schedule (a no-op without a schedule)."""
+        if self.emb_graph is not None:
+            self.emb_graph.replay()
+
+    def __call__(self, x, t, ctx=None, step=None):
         self.x.copy_(x)
         self.t.copy_(t)
+        if self.emb_graph is not None:
+            if step is None:
+                raise ValueError("this graph was built for a fixed schedule: pass the step index")
+            self.emb_stage.copy_(self.emb_tab[step])
         if ctx is not None and (ctx is not self._ctx_src or ctx._version != self._ctx_ver):
             self.ctx.copy_(ctx)
             self._ctx_src, self._ctx_ver = ctx, ctx._version
@@ -72,7 +101,11 @@ class DDIMLoop:
             x0 = torch.zeros((rows,) + self.shape, device=device)
             t0 = torch.zeros(rows, dtype=torch.long, device=device)
             c0 = None if context_shape is None else torch.zeros((rows,) + tuple(context_shape), device=device)
-            self.unet = GraphedUNet(engine, x0, t0, c0)
+            self.unet = GraphedUNet(engine, x0, t0, c0, timesteps=self._schedule())
+
+    def _schedule(self):
+        """timesteps in call order, or None when the loop does not walk a fixed list (PLMS: extra evaluations)"""
+        return [int(v) for v in np.flip(self.ddim_timesteps)]
 
     @torch.no_grad()
     def sample(self, x_T, cond=None, uncond=None):
@@ -83,11 +116,14 @@ class DDIMLoop:
         if cond is not None:
             ctx = torch.cat([uncond, cond]) if self.cfg else cond
         total = self.ddim_timesteps.shape[0]
+        graphed = isinstance(self.unet, GraphedUNet)
+        if graphed:
+            self.unet.begin()
         for i, step in enumerate(np.flip(self.ddim_timesteps)):
             index = total - i - 1
             ts = torch.full((B * (2 if self.cfg else 1),), int(step), device=img.device, dtype=torch.long)
             x_in = torch.cat([img, img]) if self.cfg else img
-            e = self.unet(x_in, ts, ctx)
+            e = self.unet(x_in, ts, ctx, step=i) if graphed else self.unet(x_in, ts, ctx)
             coef = self.coef[index:index + 1].expand(B, 5).contiguous()
             if self.cfg:
                 img = ops.ddim_step(img.contiguous(), e[B:], e[:B], self.scale, coef)
@@ -104,6 +140,9 @@ class PLMSLoop(DDIMLoop):
     def __init__(self, engine, shape, batch, steps=50, scale=7.5, linear_start=0.00085, linear_end=0.012, **kw):
         super().__init__(engine, shape, batch, steps=steps, eta=0.0, scale=scale, linear_start=linear_start,
                          linear_end=linear_end, **kw)
+
+    def _schedule(self):
+        return None                      # the second evaluation of the first step visits a timestep out of order
 
     def _eps(self, img, step, ctx):
         B = img.shape[0]

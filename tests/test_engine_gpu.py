@@ -87,3 +87,25 @@ def test_context_branches_hoisted_out_of_the_step_graph_bit_exact(golden):
         ck.mul_(0.5)
         assert torch.equal(gu(x, t, ck), eng(x, t, ck))
         assert eng.context_branches(torch.cat([c, c], 1)) is None                   # more than one token: no shortcut
+
+
+def test_time_embedding_table_of_a_schedule_bit_exact(golden):
+    """sampling.GraphedUNet with a schedule: the time-embedding path of all steps runs once per sampling run
+    (Engine.emb_tables, steps * B rows through the same kernels) and each step copies its row: the same bits as the
+    eager engine computing the projections inside the call, for every step of the schedule."""
+    from edadm.sampling import GraphedUNet
+    g = golden("g13_ldm_imagenet")
+    qnn, (x, t, c), _ = quantize_like_reference(build_ldm(g), g, "ldm")
+    qnn.set_quant_state(True, True)
+    sched = [901, 651, 401, 151, 1]
+    with torch.no_grad():
+        eng = qnn.freeze()
+        gu = GraphedUNet(eng, x, t, c, timesteps=sched)
+        assert gu.emb_graph is not None and eng.emb_r is None and eng.ctx_r is None
+        for rep in range(2):
+            gu.begin()
+            for i, ts in enumerate(sched):
+                tt = torch.full_like(t, ts)
+                assert torch.equal(gu(x, tt, c, step=i), eng(x, tt, c)), (rep, i)
+        with pytest.raises(ValueError):
+            gu(x, t, c)
