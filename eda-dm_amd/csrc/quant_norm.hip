@@ -270,7 +270,8 @@ __global__ void __launch_bounds__(256) k_gn_apply(const float* __restrict__ x, c
                                                   int64_t G, int silu, float* __restrict__ out_f32,
                                                   int8_t* __restrict__ q0, int8_t* __restrict__ q1,
                                                   int8_t* __restrict__ q2, const QP* __restrict__ qp, int nq,
-                                                  int rows_per_block) {
+                                                  int rows_per_block, int8_t* __restrict__ qraw,
+                                                  const QP* __restrict__ qpr, int64_t raw_split) {
     const int64_t b = blockIdx.y;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < HW ? r0 + rows_per_block : HW;
@@ -296,6 +297,10 @@ __global__ void __launch_bounds__(256) k_gn_apply(const float* __restrict__ x, c
         }
         const int Q1 = (int)(C1 >> 2), Q2 = Q - Q1;
         const bool first = q < Q1;
+        // the un-normalised input quantised for a second consumer of the same tensor (the ResBlock's skip convolution,
+        // two quantisers over channel ranges when raw_split > 0): what edadm_quant_i8_cat computes, without its read
+        QP qr = qa;
+        if (qraw) qr = qp_load(qpr, (raw_split > 0 && q * 4 >= raw_split) ? 1 : 0);
         for (int64_t r = r0 + rs; r < r1; r += RS) {
             const int64_t idx = (b * HW + r) * Q + q;
             float4 v = first ? reinterpret_cast<const float4*>(x)[(b * HW + r) * Q1 + q]
@@ -314,25 +319,36 @@ __global__ void __launch_bounds__(256) k_gn_apply(const float* __restrict__ x, c
             if (q0) reinterpret_cast<uint32_t*>(q0)[idx] = quant4(o, qa);
             if (q1) reinterpret_cast<uint32_t*>(q1)[idx] = quant4(o, qb);
             if (q2) reinterpret_cast<uint32_t*>(q2)[idx] = quant4(o, qc);
+            if (qraw) reinterpret_cast<uint32_t*>(qraw)[idx] = quant4(v, qr);
         }
         if (Q <= 256) break;
     }
 }
-extern "C" int edadm_groupnorm_apply_cat(const float* x1, int64_t C1, const float* x2, int64_t C2, const float* stats,
-                                         const float* gamma, const float* beta, const float* scale_shift, int64_t B,
-                                         int64_t HW, int64_t G, int silu, float* out_f32, int8_t* q0, int8_t* q1,
-                                         int8_t* q2, const float* qp, int nq, void* stream) {
+extern "C" int edadm_groupnorm_apply_cat_raw(const float* x1, int64_t C1, const float* x2, int64_t C2, const float* stats,
+                                             const float* gamma, const float* beta, const float* scale_shift, int64_t B,
+                                             int64_t HW, int64_t G, int silu, float* out_f32, int8_t* q0, int8_t* q1,
+                                             int8_t* q2, const float* qp, int nq, int8_t* qraw, const float* qp_raw,
+                                             int64_t raw_split, void* stream) {
     const int64_t C = C1 + (x2 ? C2 : 0);
     if (!x1 || !stats || !gamma || !beta || B <= 0 || HW <= 0 || C1 <= 0 || (x2 && C2 <= 0) || (C & 3) || (C1 & 3) || (C % G))
         return EDADM_EINVAL;
     if ((q0 || q1 || q2) && !qp) return EDADM_EINVAL;
+    if (qraw && (!qp_raw || raw_split < 0 || raw_split >= C || (raw_split & 3))) return EDADM_EINVAL;
     // rows per block: a multiple of what keeps (quad) fixed per thread when Q | 256, ~16 KB of input per block
     int rpb = (int)(16384 / C);   // ~64 KB of fp32 input per block
     if (rpb < 1) rpb = 1;
     const unsigned gx = (unsigned)((HW + rpb - 1) / rpb);
     hipLaunchKernelGGL(k_gn_apply, dim3(gx, (unsigned)B), dim3(256), 0, (hipStream_t)stream, x1, x2, C1, stats, gamma, beta,
-                       scale_shift, HW, C, G, silu, out_f32, q0, q1, q2, (const QP*)qp, nq, rpb);
+                       scale_shift, HW, C, G, silu, out_f32, q0, q1, q2, (const QP*)qp, nq, rpb, qraw, (const QP*)qp_raw,
+                       raw_split);
     return edadm_launch_status();
+}
+extern "C" int edadm_groupnorm_apply_cat(const float* x1, int64_t C1, const float* x2, int64_t C2, const float* stats,
+                                         const float* gamma, const float* beta, const float* scale_shift, int64_t B,
+                                         int64_t HW, int64_t G, int silu, float* out_f32, int8_t* q0, int8_t* q1,
+                                         int8_t* q2, const float* qp, int nq, void* stream) {
+    return edadm_groupnorm_apply_cat_raw(x1, C1, x2, C2, stats, gamma, beta, scale_shift, B, HW, G, silu, out_f32, q0, q1, q2,
+                                         qp, nq, nullptr, nullptr, 0, stream);
 }
 extern "C" int edadm_groupnorm_apply(const float* x, const float* stats, const float* gamma, const float* beta,
                                      const float* scale_shift, int64_t B, int64_t HW, int64_t C, int64_t G,

@@ -112,6 +112,7 @@ class Engine:
                 self.layers[id(m)] = FrozenLayer(m, name)
         self._attn_cache = {}
         self.one_token_context = os.environ.get("EDADM_ONE_TOKEN_CONTEXT", "1") != "0"
+        self.fuse_skip_quant = os.environ.get("EDADM_FUSE_SKIP_QUANT", "1") != "0"
         self.ctx_r = None            # {id(transformer block): [B][C]} from context_branches(), set by a sampling loop
         self.emb_r = None            # {id(emb projection): [B][N]} time-embedding rows of the current step (emb_tables())
         self.gn_from_producer = os.environ.get("EDADM_GN_FROM_PRODUCER", "0") == "1"   # measured slower (58.4 vs 61.7 img/s): off
@@ -327,14 +328,16 @@ class Engine:
             return ops.groupnorm_final(gs[0][0], parts[0].shape[-1], ws2, parts[-1].shape[-1], B, HW, norm.num_groups, norm.eps)
         return ops.groupnorm_stats(x, norm.num_groups, norm.eps)
 
-    def gn(self, norm, x, silu, qms=(), want_f32=False, scale_shift=None):
-        """GroupNorm(+SiLU) of NHWC x -> (fp32 or None, [int8 operand per layer in qms])."""
+    def gn(self, norm, x, silu, qms=(), want_f32=False, scale_shift=None, raw=None):
+        """GroupNorm(+SiLU) of NHWC x -> (fp32 or None, [int8 operand per layer in qms]); raw = a FrozenLayer that
+        consumes x itself: its int8 operand comes out of the same pass as a third element."""
         st = self._gn_stats(norm, x)
         Ls = [self.L(q) for q in qms]
         assert all(l.mode == "i8" and not l.split for l in Ls)
         qp = self._qp_cat(Ls) if Ls else None
+        kw = dict(raw_qp=raw.qp, raw_split=raw.split) if raw is not None else {}
         return ops.groupnorm_apply(x, st, norm.weight, norm.bias, norm.num_groups, silu, qp=qp, nq=len(Ls),
-                                   want_f32=want_f32, scale_shift=scale_shift)
+                                   want_f32=want_f32, scale_shift=scale_shift, **kw)
 
     def _qp_cat(self, Ls):
         """the quantiser tables of the consumers of one normalised tensor, concatenated once (not per call: a tiny
@@ -549,6 +552,7 @@ class Engine:
     # ------------------------------------------------------------------ LDM graph
     def ldm_res(self, blk, x, emb, split=0):
         B, H, W, C = x.shape
+        xs_q = None
         e = self.emb_proj(blk.emb_layers[1], emb)                        # [B][Cout or 2 Cout]
         n_in, conv_in = blk.in_layers[0], blk.in_layers[2]
         if blk.updown and isinstance(x, ops.Cat):
@@ -568,7 +572,13 @@ class Engine:
                 h = self.conv(conv_in, a, B, H // 2, W // 2, rowadd=None if blk.use_scale_shift_norm else e)
             B, H, W, C = x.shape
         else:
-            _, (a,) = self.gn(n_in, x, True, (conv_in,))
+            # a skip convolution quantises the block input itself: its operand comes out of the GroupNorm pass that reads
+            # the same tensor (same quantiser arithmetic as edadm_quant_i8_cat, one read of x less)
+            Ls = None if isinstance(blk.skip_connection, nn.Identity) else self.L(blk.skip_connection)
+            if Ls is not None and Ls.mode == "i8" and self.fuse_skip_quant and (Ls.split or 0) % 4 == 0:
+                _, (a,), xs_q = self.gn(n_in, x, True, (conv_in,), raw=Ls)
+            else:
+                _, (a,) = self.gn(n_in, x, True, (conv_in,))
             h = self.conv(conv_in, a, B, H, W, rowadd=None if blk.use_scale_shift_norm else e)
         n_out, conv_out = blk.out_layers[0], blk.out_layers[3]
         _, (a2,) = self.gn(n_out, h, True, (conv_out,), scale_shift=e if blk.use_scale_shift_norm else None)
@@ -577,9 +587,11 @@ class Engine:
         else:
             L = self.L(blk.skip_connection)
             if L.kind == "dense":
-                xs = self.lin(blk.skip_connection, self._rows(x, C)).reshape(B, H, W, -1)
+                xs = self.lin(blk.skip_connection, None if xs_q is not None else self._rows(x, C),
+                              pre=None if xs_q is None else xs_q.reshape(-1, C)).reshape(B, H, W, -1)
             else:
-                xs = self.conv(blk.skip_connection, self._quant(L, self._rows(x, C)).reshape(B, H, W, C), B, H, W)
+                aq = xs_q if xs_q is not None else self._quant(L, self._rows(x, C))
+                xs = self.conv(blk.skip_connection, aq.reshape(B, H, W, C), B, H, W)
         return self.conv(conv_out, a2, B, H, W, residual=xs)
 
     def ldm_cross_attn(self, attn, x2d_q, ctx_ops, B, Nq, Nk, residual):

@@ -271,24 +271,29 @@ def groupnorm_stats(x_nhwc, G, eps):
     return stats
 
 
-def groupnorm_apply(x_nhwc, stats, gamma, beta, G, silu, qp=None, nq=0, want_f32=False, scale_shift=None):
-    if isinstance(x_nhwc, Cat):
-        a, b = x_nhwc.a, x_nhwc.b
-        B, C = a.shape[0], x_nhwc.shape[-1]
-        HW = a.numel() // (B * a.shape[-1])
-        out = torch.empty(x_nhwc.shape, dtype=torch.float32, device=a.device) if want_f32 else None
-        qs = [torch.empty(x_nhwc.shape, dtype=torch.int8, device=a.device) for _ in range(nq)]
-        qq = qs + [None] * (3 - nq)
+def groupnorm_apply(x_nhwc, stats, gamma, beta, G, silu, qp=None, nq=0, want_f32=False, scale_shift=None, raw_qp=None,
+                    raw_split=0):
+    """-> (fp32 or None, [int8 operands of the normalised value]) -- and, with raw_qp, a third element: the int8 operand of
+    the un-normalised input under raw_qp (split quantisers at column raw_split), for the tensor's second consumer."""
+    cat = isinstance(x_nhwc, Cat)
+    a, b = (x_nhwc.a, x_nhwc.b) if cat else (x_nhwc, None)
+    B, C = a.shape[0], x_nhwc.shape[-1]
+    HW = a.numel() // (B * a.shape[-1])
+    dev = a.device
+    out = torch.empty(tuple(x_nhwc.shape), dtype=torch.float32, device=dev) if want_f32 else None
+    qs = [torch.empty(tuple(x_nhwc.shape), dtype=torch.int8, device=dev) for _ in range(nq)]
+    qq = qs + [None] * (3 - nq)
+    if raw_qp is not None:
+        qraw = torch.empty(tuple(x_nhwc.shape), dtype=torch.int8, device=dev)
+        lib.call("edadm_groupnorm_apply_cat_raw", _pf(a), a.shape[-1], _pf(b), b.shape[-1] if cat else 0, _pf(stats),
+                 _pf(gamma), _pf(beta), _pf(scale_shift), B, HW, G, 1 if silu else 0, _pf(out), _p(qq[0]), _p(qq[1]),
+                 _p(qq[2]), _pf(qp), nq, _p(qraw, torch.int8), _pf(raw_qp), int(raw_split), _stream())
+        return out, qs, qraw
+    if cat:
         lib.call("edadm_groupnorm_apply_cat", _pf(a), a.shape[-1], _pf(b), b.shape[-1], _pf(stats), _pf(gamma), _pf(beta),
                  _pf(scale_shift), B, HW, G, 1 if silu else 0, _pf(out), _p(qq[0]), _p(qq[1]), _p(qq[2]), _pf(qp), nq,
                  _stream())
         return out, qs
-    B, C = x_nhwc.shape[0], x_nhwc.shape[-1]
-    HW = x_nhwc.numel() // (B * C)
-    dev = x_nhwc.device
-    out = torch.empty_like(x_nhwc) if want_f32 else None
-    qs = [torch.empty(x_nhwc.shape, dtype=torch.int8, device=dev) for _ in range(nq)]
-    qq = qs + [None] * (3 - nq)
     lib.call("edadm_groupnorm_apply", _pf(x_nhwc), _pf(stats), _pf(gamma), _pf(beta), _pf(scale_shift), B, HW, C, G,
              1 if silu else 0, _pf(out), _p(qq[0]), _p(qq[1]), _p(qq[2]), _pf(qp), nq, _stream())
     return out, qs

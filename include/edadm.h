@@ -151,6 +151,14 @@ int edadm_groupnorm_apply_cat(const float* x1, int64_t C1, const float* x2, int6
                               const float* gamma, const float* beta, const float* scale_shift, int64_t B, int64_t HW,
                               int64_t G, int silu, float* out_f32, int8_t* q0, int8_t* q1, int8_t* q2,
                               const float* qp, int nq, void* stream);
+/* the same with one more output: qraw = the UN-normalised input quantised with qp_raw (two quantisers over the channel
+ * ranges [0, raw_split) / [raw_split, C) when raw_split > 0) = what edadm_quant_i8_cat writes for the second consumer of
+ * the tensor -- the ResBlock's skip convolution (openaimodel.py:265-277) -- without reading it again */
+int edadm_groupnorm_apply_cat_raw(const float* x1, int64_t C1, const float* x2, int64_t C2, const float* stats,
+                                  const float* gamma, const float* beta, const float* scale_shift, int64_t B, int64_t HW,
+                                  int64_t G, int silu, float* out_f32, int8_t* q0, int8_t* q1, int8_t* q2,
+                                  const float* qp, int nq, int8_t* qraw, const float* qp_raw, int64_t raw_split,
+                                  void* stream);
 /* pass 2 alone: per-channel partials [B][nchunk][C][2] (sum, sum of squares) written by a producer's epilogue
  * (edadm_qgemm_i8_gn) -> stats; ws2 (may be NULL) holds the second half of a channel concatenation */
 int edadm_groupnorm_final_cat(const float* ws1, int64_t C1, const float* ws2, int64_t C2, float* stats, int64_t B,

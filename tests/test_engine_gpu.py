@@ -109,3 +109,20 @@ def test_time_embedding_table_of_a_schedule_bit_exact(golden):
                 assert torch.equal(gu(x, tt, c, step=i), eng(x, tt, c)), (rep, i)
         with pytest.raises(ValueError):
             gu(x, t, c)
+
+
+def test_skip_conv_operand_from_the_groupnorm_pass_bit_exact(golden):
+    """A ResBlock's skip convolution quantises the block input, which the first GroupNorm reads anyway: the GroupNorm apply
+    pass writes that operand too (edadm_groupnorm_apply_cat_raw, split quantisers over the skip concatenation included)
+    -- the same bits as the separate edadm_quant_i8_cat pass."""
+    for name, kind in (("g13_ldm_imagenet", "ldm"),):
+        g = golden(name)
+        qnn, (x, t, c), _ = quantize_like_reference(build_ldm(g), g, kind)
+        qnn.set_quant_state(True, True)
+        with torch.no_grad():
+            eng = qnn.freeze()
+            assert eng.fuse_skip_quant
+            fused = eng(x, t, c)
+            eng.fuse_skip_quant = False
+            plain = eng(x, t, c)
+        assert torch.equal(fused, plain)
