@@ -299,11 +299,13 @@ def main():
     c_in = torch.cat([uncond, cond])
     eng.ctx_r = eng.context_branches(c_in)
     eng.emb_r = eng.emb_rows(t_in)           # ... and the step's time-embedding rows from the run's table
+    eng.cfg_pair = True                      # x_in is a guidance pair [x, x]: context-independent prefix once per pair
     eng.prof = []
     eng(x_in, t_in, c_in)
     torch.cuda.synchronize()
     prof, eng.prof = eng.prof, None
     eng.ctx_r = eng.emb_r = None
+    eng.cfg_pair = False
 
     def kernel_ms(run, reps=5):
         """average device time of one recorded GEMM launch: `reps` back-to-back launches between two HIP
@@ -349,8 +351,9 @@ def main():
             "config": {"workload": "ImageNet LDM-4 256x256 W4A8: 50-image batches x 20 DDIM steps x CFG (100 UNet rows/call), "
                                    "400.9M-param cin256-v2 UNet, random-init weights, latents+context resident in HBM; the one-token "
                                    "cross-attention vectors (a function of the context alone) and the time-embedding rows of "
-                                   "the 20 timesteps are evaluated once per batch inside the timed sample() call, "
-                                   "bit-identical to per-step evaluation; "
+                                   "the 20 timesteps are evaluated once per batch inside the timed sample() call, and the "
+                                   "attention-free leading blocks (identical for the two halves of a guidance pair) once "
+                                   "per pair: all bit-identical to the plain evaluation; "
                                    "first-stage VQ decode outside the hot path (SURVEY 8f-3)",
                        "images_per_step": B, "ddim_steps": 20, "cfg_scale": 3.0, "parallelism": "dp%d (independent batches, no collective)" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": I8_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -39,7 +39,9 @@ __device__ __forceinline__ uint32_t quant4(const float4& v, const QP& q) {
 // the UNet skip concatenation is never materialised in fp32, its consumers read the two halves in place.
 __global__ void __launch_bounds__(256) k_quant_i8(const float* __restrict__ x, const float* __restrict__ x2, int64_t C1,
                                                   int8_t* __restrict__ out, int64_t rows, int64_t C,
-                                                  const QP* __restrict__ qp, int64_t split) {
+                                                  const QP* __restrict__ qp, int64_t split, int64_t rows2) {
+    // rows2 > 0: x2 holds rows2 < rows rows and is read periodically (r % rows2): the half-batch skip tensors of a
+    // classifier-free-guidance pair, whose two halves are identical up to the first context-dependent layer
     const int64_t n = rows * C, stride = (int64_t)gridDim.x * blockDim.x;
     const QP q0 = qp_load(qp, 0);
     const QP q1 = split > 0 ? qp_load(qp, 1) : q0;
@@ -48,27 +50,32 @@ __global__ void __launch_bounds__(256) k_quant_i8(const float* __restrict__ x, c
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
             const int64_t r = i / C4, c = i - r * C4;
             const float4 v = c < A4 ? reinterpret_cast<const float4*>(x)[r * A4 + c]
-                                    : reinterpret_cast<const float4*>(x2)[r * B4 + (c - A4)];
+                                    : reinterpret_cast<const float4*>(x2)[(rows2 > 0 ? r % rows2 : r) * B4 + (c - A4)];
             const bool second = split > 0 && c >= s4;
             reinterpret_cast<uint32_t*>(out)[i] = quant4(v, second ? q1 : q0);
         }
     } else {
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
             const int64_t r = i / C, c = i - r * C;
-            const float v = c < C1 ? x[r * C1 + c] : x2[r * (C - C1) + (c - C1)];
+            const float v = c < C1 ? x[r * C1 + c] : x2[(rows2 > 0 ? r % rows2 : r) * (C - C1) + (c - C1)];
             const bool second = split > 0 && c >= split;
             out[i] = (int8_t)q_code_i8(v, second ? q1 : q0);
         }
     }
 }
-extern "C" int edadm_quant_i8_cat(const float* x1, int64_t C1, const float* x2, int64_t C2, int8_t* out, int64_t rows,
-                                  const float* qp, int64_t split, void* stream) {
+extern "C" int edadm_quant_i8_cat_rep(const float* x1, int64_t C1, const float* x2, int64_t C2, int8_t* out, int64_t rows,
+                                      const float* qp, int64_t split, int64_t rows2, void* stream) {
     const int64_t C = C1 + (x2 ? C2 : 0);
-    if (!x1 || !out || !qp || rows <= 0 || C1 <= 0 || (x2 && C2 <= 0) || split < 0 || split >= C + (split == 0))
+    if (!x1 || !out || !qp || rows <= 0 || C1 <= 0 || (x2 && C2 <= 0) || split < 0 || split >= C + (split == 0) ||
+        rows2 < 0 || (rows2 > 0 && (!x2 || rows % rows2)))
         return EDADM_EINVAL;
     hipLaunchKernelGGL(k_quant_i8, dim3(edadm_grid(rows * C / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, x1, x2,
-                       C1, out, rows, C, (const QP*)qp, split);
+                       C1, out, rows, C, (const QP*)qp, split, rows2);
     return edadm_launch_status();
+}
+extern "C" int edadm_quant_i8_cat(const float* x1, int64_t C1, const float* x2, int64_t C2, int8_t* out, int64_t rows,
+                                  const float* qp, int64_t split, void* stream) {
+    return edadm_quant_i8_cat_rep(x1, C1, x2, C2, out, rows, qp, split, 0, stream);
 }
 extern "C" int edadm_quant_i8(const float* x, int8_t* out, int64_t rows, int64_t C, const float* qp, int64_t split,
                               void* stream) {
@@ -161,9 +168,10 @@ extern "C" int edadm_im2col_quant_i8(const float* x, int8_t* out, int64_t B, int
 #define GN_CHUNKS(HW) ((int)((HW) >= 1024 ? 32 : ((HW) >= 64 ? 8 : 1)))
 
 __global__ void __launch_bounds__(256) k_gn_partial(const float* __restrict__ x, const float* __restrict__ x2, int64_t C1,
-                                                    float* __restrict__ ws, int64_t HW, int64_t C, int nchunk) {
+                                                    float* __restrict__ ws, int64_t HW, int64_t C, int nchunk, int64_t B2) {
     extern __shared__ float sm[];  // [RS][C][2] when RS > 1
     const int64_t b = blockIdx.y;
+    const int64_t b2 = B2 > 0 ? b % B2 : b;                          // x2 of B2 images read periodically (CFG pair)
     const int chunk = blockIdx.x;
     const int64_t r0 = HW * chunk / nchunk, r1 = HW * (chunk + 1) / nchunk;
     const int Q = (int)(C >> 2);
@@ -171,7 +179,7 @@ __global__ void __launch_bounds__(256) k_gn_partial(const float* __restrict__ x,
     const int tid = threadIdx.x;
     const int Q1 = (int)(C1 >> 2), Q2 = Q - Q1;                      // [x | x2] halves (x2 == nullptr: Q1 == Q)
     const float4* xa = reinterpret_cast<const float4*>(x) + b * HW * Q1;
-    const float4* xc = reinterpret_cast<const float4*>(x2) + b * HW * Q2;
+    const float4* xc = reinterpret_cast<const float4*>(x2) + b2 * HW * Q2;
     float* wb = ws + ((b * nchunk + chunk) * C) * 2;
     if (Q <= 256) {
         const int q = tid % Q, rs = tid / Q;
@@ -235,20 +243,25 @@ __global__ void __launch_bounds__(64) k_gn_final(const float* __restrict__ ws, c
     }
 }
 extern "C" int64_t edadm_gn_ws_floats(int64_t B, int64_t HW, int64_t C) { return B * GN_CHUNKS(HW) * C * 2; }
-extern "C" int edadm_groupnorm_stats_cat(const float* x1, int64_t C1, const float* x2, int64_t C2, float* stats, float* ws,
-                                         int64_t B, int64_t HW, int64_t G, float eps, void* stream) {
+extern "C" int edadm_groupnorm_stats_cat_rep(const float* x1, int64_t C1, const float* x2, int64_t C2, float* stats, float* ws,
+                                             int64_t B, int64_t HW, int64_t G, float eps, int64_t B2, void* stream) {
     const int64_t C = C1 + (x2 ? C2 : 0);
-    if (!x1 || !stats || !ws || B <= 0 || HW <= 0 || C1 <= 0 || (x2 && C2 <= 0) || G <= 0 || (C % G) || (C & 3) || (C1 & 3))
+    if (!x1 || !stats || !ws || B <= 0 || HW <= 0 || C1 <= 0 || (x2 && C2 <= 0) || G <= 0 || (C % G) || (C & 3) || (C1 & 3) ||
+        B2 < 0 || (B2 > 0 && (!x2 || B % B2)))
         return EDADM_EINVAL;
     const int nchunk = GN_CHUNKS(HW);
     const int Q = (int)(C >> 2);
     const int RS = Q <= 256 ? 256 / Q : 1;
     const size_t smem = Q <= 256 ? (size_t)RS * C * 2 * sizeof(float) : 0;
     hipLaunchKernelGGL(k_gn_partial, dim3(nchunk, (unsigned)B), dim3(256), smem, (hipStream_t)stream, x1, x2, C1, ws, HW,
-                       C, nchunk);
+                       C, nchunk, B2);
     hipLaunchKernelGGL(k_gn_final, dim3((unsigned)G, (unsigned)B), dim3(64), 0, (hipStream_t)stream, ws, (const float*)nullptr,
                        C, stats, HW, C, G, nchunk, eps);
     return edadm_launch_status();
+}
+extern "C" int edadm_groupnorm_stats_cat(const float* x1, int64_t C1, const float* x2, int64_t C2, float* stats, float* ws,
+                                         int64_t B, int64_t HW, int64_t G, float eps, void* stream) {
+    return edadm_groupnorm_stats_cat_rep(x1, C1, x2, C2, stats, ws, B, HW, G, eps, 0, stream);
 }
 // pass 2 alone, over per-channel partials [B][nchunk][C][2] that a producer already wrote (edadm_qgemm_i8_gn)
 extern "C" int edadm_groupnorm_final_cat(const float* ws1, int64_t C1, const float* ws2, int64_t C2, float* stats, int64_t B,
@@ -271,8 +284,9 @@ __global__ void __launch_bounds__(256) k_gn_apply(const float* __restrict__ x, c
                                                   int8_t* __restrict__ q0, int8_t* __restrict__ q1,
                                                   int8_t* __restrict__ q2, const QP* __restrict__ qp, int nq,
                                                   int rows_per_block, int8_t* __restrict__ qraw,
-                                                  const QP* __restrict__ qpr, int64_t raw_split) {
+                                                  const QP* __restrict__ qpr, int64_t raw_split, int64_t B2) {
     const int64_t b = blockIdx.y;
+    const int64_t b2 = B2 > 0 ? b % B2 : b;                          // x2 of B2 images read periodically (CFG pair)
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < HW ? r0 + rows_per_block : HW;
     const int Q = (int)(C >> 2);
@@ -304,7 +318,7 @@ __global__ void __launch_bounds__(256) k_gn_apply(const float* __restrict__ x, c
         for (int64_t r = r0 + rs; r < r1; r += RS) {
             const int64_t idx = (b * HW + r) * Q + q;
             float4 v = first ? reinterpret_cast<const float4*>(x)[(b * HW + r) * Q1 + q]
-                             : reinterpret_cast<const float4*>(x2)[(b * HW + r) * Q2 + (q - Q1)];
+                             : reinterpret_cast<const float4*>(x2)[(b2 * HW + r) * Q2 + (q - Q1)];
             float y[4] = {v.x * a[0] + bb[0], v.y * a[1] + bb[1], v.z * a[2] + bb[2], v.w * a[3] + bb[3]};
             if (scale_shift) {
 #pragma unroll
@@ -328,19 +342,20 @@ extern "C" int edadm_groupnorm_apply_cat_raw(const float* x1, int64_t C1, const 
                                              const float* gamma, const float* beta, const float* scale_shift, int64_t B,
                                              int64_t HW, int64_t G, int silu, float* out_f32, int8_t* q0, int8_t* q1,
                                              int8_t* q2, const float* qp, int nq, int8_t* qraw, const float* qp_raw,
-                                             int64_t raw_split, void* stream) {
+                                             int64_t raw_split, int64_t B2, void* stream) {
     const int64_t C = C1 + (x2 ? C2 : 0);
     if (!x1 || !stats || !gamma || !beta || B <= 0 || HW <= 0 || C1 <= 0 || (x2 && C2 <= 0) || (C & 3) || (C1 & 3) || (C % G))
         return EDADM_EINVAL;
     if ((q0 || q1 || q2) && !qp) return EDADM_EINVAL;
     if (qraw && (!qp_raw || raw_split < 0 || raw_split >= C || (raw_split & 3))) return EDADM_EINVAL;
+    if (B2 < 0 || (B2 > 0 && (!x2 || B % B2))) return EDADM_EINVAL;
     // rows per block: a multiple of what keeps (quad) fixed per thread when Q | 256, ~16 KB of input per block
     int rpb = (int)(16384 / C);   // ~64 KB of fp32 input per block
     if (rpb < 1) rpb = 1;
     const unsigned gx = (unsigned)((HW + rpb - 1) / rpb);
     hipLaunchKernelGGL(k_gn_apply, dim3(gx, (unsigned)B), dim3(256), 0, (hipStream_t)stream, x1, x2, C1, stats, gamma, beta,
                        scale_shift, HW, C, G, silu, out_f32, q0, q1, q2, (const QP*)qp, nq, rpb, qraw, (const QP*)qp_raw,
-                       raw_split);
+                       raw_split, B2);
     return edadm_launch_status();
 }
 extern "C" int edadm_groupnorm_apply_cat(const float* x1, int64_t C1, const float* x2, int64_t C2, const float* stats,
@@ -348,7 +363,7 @@ extern "C" int edadm_groupnorm_apply_cat(const float* x1, int64_t C1, const floa
                                          int64_t HW, int64_t G, int silu, float* out_f32, int8_t* q0, int8_t* q1,
                                          int8_t* q2, const float* qp, int nq, void* stream) {
     return edadm_groupnorm_apply_cat_raw(x1, C1, x2, C2, stats, gamma, beta, scale_shift, B, HW, G, silu, out_f32, q0, q1, q2,
-                                         qp, nq, nullptr, nullptr, 0, stream);
+                                         qp, nq, nullptr, nullptr, 0, 0, stream);
 }
 extern "C" int edadm_groupnorm_apply(const float* x, const float* stats, const float* gamma, const float* beta,
                                      const float* scale_shift, int64_t B, int64_t HW, int64_t C, int64_t G,

@@ -113,6 +113,11 @@ class Engine:
         self._attn_cache = {}
         self.one_token_context = os.environ.get("EDADM_ONE_TOKEN_CONTEXT", "1") != "0"
         self.fuse_skip_quant = os.environ.get("EDADM_FUSE_SKIP_QUANT", "1") != "0"
+        # classifier-free guidance evaluates [x, x] with contexts [uncond, cond]: the two halves are identical until the first
+        # context-dependent layer.  A sampling loop that builds the pair itself sets cfg_pair: that prefix then runs on
+        # one half and its skip tensors stay at half the batch (read periodically by their consumers)
+        self.cfg_pair = False
+        self._emb_n = None           # rows of the emb tables to use while the shared prefix runs
         self.ctx_r = None            # {id(transformer block): [B][C]} from context_branches(), set by a sampling loop
         self.emb_r = None            # {id(emb projection): [B][N]} time-embedding rows of the current step (emb_tables())
         self.gn_from_producer = os.environ.get("EDADM_GN_FROM_PRODUCER", "0") == "1"   # measured slower (58.4 vs 61.7 img/s): off
@@ -232,7 +237,7 @@ class Engine:
 
     def _quant(self, L, x2d):
         if isinstance(x2d, ops.Cat) and L.mode != "i8":
-            x2d = torch.cat([x2d.a, x2d.b], dim=-1)
+            x2d = torch.cat([x2d.a, x2d.full_b()], dim=-1)
         if L.mode == "i8":
             return ops.quant_i8(x2d, L.qp, split=L.split)
         if L.mode == "f16":
@@ -320,7 +325,7 @@ class Engine:
     def _gn_stats(self, norm, x):
         """statistics pass: from the producers' partials when every half of x has them, else the two-pass kernels"""
         parts = (x.a, x.b) if isinstance(x, ops.Cat) else (x,)
-        gs = [getattr(p, "_gn", None) for p in parts]
+        gs = [getattr(p, "_gn", None) for p in parts] if not (isinstance(x, ops.Cat) and x.rep > 1) else [None]
         B = parts[0].shape[0]
         HW = parts[0].numel() // (B * parts[0].shape[-1])
         if all(g is not None and g[1] == HW for g in gs):
@@ -356,7 +361,8 @@ class Engine:
     def emb_proj(self, qm, emb):
         """silu(emb) -> quantise -> linear: the per-block time-embedding projection [B][N]."""
         if self.emb_r is not None and id(qm) in self.emb_r:
-            return self.emb_r[id(qm)]
+            r = self.emb_r[id(qm)]
+            return r if self._emb_n is None else r[:self._emb_n]
         L = self.L(qm)
         assert L.mode == "i8"
         return self._gemm(L, ops.silu_quant_i8(emb, L.qp), emb.shape[0])
@@ -556,7 +562,7 @@ class Engine:
         e = self.emb_proj(blk.emb_layers[1], emb)                        # [B][Cout or 2 Cout]
         n_in, conv_in = blk.in_layers[0], blk.in_layers[2]
         if blk.updown and isinstance(x, ops.Cat):
-            x = ops.concat_c(x.a, x.b)
+            x = ops.concat_c(x.a, x.full_b())
         if blk.updown:
             up = isinstance(blk.h_upd, ldm_unet.Upsample)
             y, _ = self.gn(n_in, x, True, (), want_f32=True)
@@ -738,7 +744,25 @@ class Engine:
         ctx = None if context is None else context.contiguous().float()
         h = ops.nchw_to_nhwc(x.contiguous().float())
         hs = []
-        for mods in net.input_blocks:
+        blocks = list(net.input_blocks)
+        n_pre = 0
+        if self.cfg_pair and B % 2 == 0 and os.environ.get("EDADM_CFG_SHARED_PREFIX", "1") != "0":
+            # leading blocks without attention do not see the context: one evaluation for both halves of the pair
+            while n_pre < len(blocks) and not any(hasattr(m, "transformer_blocks") or type(m).__name__.endswith("AttentionBlock")
+                                                  for m in blocks[n_pre]):
+                n_pre += 1
+        if n_pre:
+            half = B // 2
+            hp, self._emb_n = h[:half], half
+            try:
+                ep = None if emb is None else emb[:half]
+                for mods in blocks[:n_pre]:
+                    hp = self.ldm_seq(mods, hp, ep, None)
+                    hs.append(hp)
+            finally:
+                self._emb_n = None
+            h = torch.cat([hp, hp])
+        for mods in blocks[n_pre:]:
             h = self.ldm_seq(mods, h, emb, ctx)
             hs.append(h)
         h = self.ldm_seq(net.middle_block, h, emb, ctx)

@@ -196,13 +196,20 @@ class Cat:
     quantiser read the two halves in place (edadm_*_cat)."""
 
     def __init__(self, a, b):
-        assert a.shape[:-1] == b.shape[:-1]
+        # b may hold a whole fraction of a's leading dimension: it is then read periodically (image i of the
+        # concatenation takes b's image i % len(b)) -- the skip tensors shared by a classifier-free-guidance pair
+        assert a.shape[1:-1] == b.shape[1:-1] and a.shape[0] % b.shape[0] == 0
         self.a, self.b = a, b
+        self.rep = a.shape[0] // b.shape[0]
         self.shape = tuple(a.shape[:-1]) + (a.shape[-1] + b.shape[-1],)
         self.device = a.device
 
     def rows2d(self):
         return Cat(self.a.reshape(-1, self.a.shape[-1]), self.b.reshape(-1, self.b.shape[-1]))
+
+    def full_b(self):
+        """b at a's batch (materialised only by the rare consumers that cannot read it periodically)"""
+        return self.b if self.rep == 1 else torch.cat([self.b] * self.rep)
 
 
 def quant_i8(x2d, qp, split=0, out=None):
@@ -211,8 +218,8 @@ def quant_i8(x2d, qp, split=0, out=None):
         rows, C = a.shape[0], a.shape[1] + b.shape[1]
         if out is None:
             out = torch.empty(rows, C, dtype=torch.int8, device=a.device)
-        lib.call("edadm_quant_i8_cat", _pf(a), a.shape[1], _pf(b), b.shape[1], _p(out, torch.int8), rows, _pf(qp), int(split),
-                 _stream())
+        lib.call("edadm_quant_i8_cat_rep", _pf(a), a.shape[1], _pf(b), b.shape[1], _p(out, torch.int8), rows, _pf(qp),
+                 int(split), b.shape[0] if b.shape[0] != rows else 0, _stream())
         return out
     rows, C = x2d.shape
     if out is None:
@@ -260,8 +267,8 @@ def groupnorm_stats(x_nhwc, G, eps):
         HW = a.numel() // (B * a.shape[-1])
         stats = torch.empty(B, G, 2, dtype=torch.float32, device=a.device)
         ws = workspace(a.device, lib.load().edadm_gn_ws_floats(B, HW, C))
-        lib.call("edadm_groupnorm_stats_cat", _pf(a), a.shape[-1], _pf(b), b.shape[-1], _pf(stats), _pf(ws), B, HW, G,
-                 float(eps), _stream())
+        lib.call("edadm_groupnorm_stats_cat_rep", _pf(a), a.shape[-1], _pf(b), b.shape[-1], _pf(stats), _pf(ws), B, HW, G,
+                 float(eps), b.shape[0] if x_nhwc.rep > 1 else 0, _stream())
         return stats
     B, C = x_nhwc.shape[0], x_nhwc.shape[-1]
     HW = x_nhwc.numel() // (B * C)
@@ -283,12 +290,13 @@ def groupnorm_apply(x_nhwc, stats, gamma, beta, G, silu, qp=None, nq=0, want_f32
     out = torch.empty(tuple(x_nhwc.shape), dtype=torch.float32, device=dev) if want_f32 else None
     qs = [torch.empty(tuple(x_nhwc.shape), dtype=torch.int8, device=dev) for _ in range(nq)]
     qq = qs + [None] * (3 - nq)
-    if raw_qp is not None:
-        qraw = torch.empty(tuple(x_nhwc.shape), dtype=torch.int8, device=dev)
+    if raw_qp is not None or (cat and x_nhwc.rep > 1):
+        qraw = torch.empty(tuple(x_nhwc.shape), dtype=torch.int8, device=dev) if raw_qp is not None else None
         lib.call("edadm_groupnorm_apply_cat_raw", _pf(a), a.shape[-1], _pf(b), b.shape[-1] if cat else 0, _pf(stats),
                  _pf(gamma), _pf(beta), _pf(scale_shift), B, HW, G, 1 if silu else 0, _pf(out), _p(qq[0]), _p(qq[1]),
-                 _p(qq[2]), _pf(qp), nq, _p(qraw, torch.int8), _pf(raw_qp), int(raw_split), _stream())
-        return out, qs, qraw
+                 _p(qq[2]), _pf(qp), nq, _p(qraw, torch.int8) if qraw is not None else None, _pf(raw_qp), int(raw_split),
+                 b.shape[0] if (cat and x_nhwc.rep > 1) else 0, _stream())
+        return (out, qs, qraw) if raw_qp is not None else (out, qs)
     if cat:
         lib.call("edadm_groupnorm_apply_cat", _pf(a), a.shape[-1], _pf(b), b.shape[-1], _pf(stats), _pf(gamma), _pf(beta),
                  _pf(scale_shift), B, HW, G, 1 if silu else 0, _pf(out), _p(qq[0]), _p(qq[1]), _p(qq[2]), _pf(qp), nq,

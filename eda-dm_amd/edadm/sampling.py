@@ -14,15 +14,20 @@ class GraphedUNet:
     are a function of the context alone (Engine.context_branches): they get their own graph, replayed when the
     context changes -- once per sample batch -- and the per-step graph only adds their vectors."""
 
-    def __init__(self, engine, x, t, ctx, warmup=2, timesteps=None):
+    def __init__(self, engine, x, t, ctx, warmup=2, timesteps=None, cfg_pair=False):
         """timesteps: the schedule of the run (one int per step, in call order).  With it the time-embedding path of all
         steps is one graph replayed by begin() at the start of a run (Engine.emb_tables), and a step -- called with
         its index -- copies its row of that table instead of recomputing 2 + 2 x 22 tiny launches."""
+        # cfg_pair: the caller always passes x = [img, img] (a classifier-free-guidance pair): the context-independent
+        # prefix of the network runs once for both halves (Engine.cfg_pair)
         self.engine = engine
         self.x, self.t = x.clone(), t.clone()
         self.ctx = None if ctx is None else ctx.clone()
         self._ctx_src, self._ctx_ver = None, -1
         rows = x.shape[0]
+        pair = bool(cfg_pair) and hasattr(engine, "cfg_pair")
+        if pair:
+            engine.cfg_pair = True
         self.emb_graph = self.emb_tab = self.emb_stage = None
         ts_all = None
         if timesteps is not None and hasattr(engine, "emb_tables"):
@@ -58,6 +63,8 @@ class GraphedUNet:
         finally:
             engine.ctx_r = None                       # eager calls of the engine keep evaluating both per call
             engine.emb_r = None
+            if pair:
+                engine.cfg_pair = False
         if self.ctx_graph is not None:
             self.ctx_graph.replay()                   # capture does not execute: make the vectors match self.ctx now
         self.begin()
@@ -101,7 +108,7 @@ class DDIMLoop:
             x0 = torch.zeros((rows,) + self.shape, device=device)
             t0 = torch.zeros(rows, dtype=torch.long, device=device)
             c0 = None if context_shape is None else torch.zeros((rows,) + tuple(context_shape), device=device)
-            self.unet = GraphedUNet(engine, x0, t0, c0, timesteps=self._schedule())
+            self.unet = GraphedUNet(engine, x0, t0, c0, timesteps=self._schedule(), cfg_pair=self.cfg)
 
     def _schedule(self):
         """timesteps in call order, or None when the loop does not walk a fixed list (PLMS: extra evaluations)"""

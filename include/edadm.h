@@ -158,7 +158,15 @@ int edadm_groupnorm_apply_cat_raw(const float* x1, int64_t C1, const float* x2, 
                                   const float* gamma, const float* beta, const float* scale_shift, int64_t B, int64_t HW,
                                   int64_t G, int silu, float* out_f32, int8_t* q0, int8_t* q1, int8_t* q2,
                                   const float* qp, int nq, int8_t* qraw, const float* qp_raw, int64_t raw_split,
-                                  void* stream);
+                                  int64_t B2, void* stream);
+/* B2 / rows2 > 0 (the *_rep forms and edadm_groupnorm_apply_cat_raw): x2 holds B2 < B images (rows2 < rows rows) and is read
+ * periodically -- image b of the concatenation takes x2's image b % B2.  Serves the skip tensors a classifier-free-guidance
+ * pair shares: both halves of the doubled batch are identical up to the first context-dependent layer, so the sampling
+ * loop evaluates that prefix once per pair and its skip tensors stay at half the batch. */
+int edadm_groupnorm_stats_cat_rep(const float* x1, int64_t C1, const float* x2, int64_t C2, float* stats, float* ws,
+                                  int64_t B, int64_t HW, int64_t G, float eps, int64_t B2, void* stream);
+int edadm_quant_i8_cat_rep(const float* x1, int64_t C1, const float* x2, int64_t C2, int8_t* out, int64_t rows,
+                           const float* qp, int64_t split, int64_t rows2, void* stream);
 /* pass 2 alone: per-channel partials [B][nchunk][C][2] (sum, sum of squares) written by a producer's epilogue
  * (edadm_qgemm_i8_gn) -> stats; ws2 (may be NULL) holds the second half of a channel concatenation */
 int edadm_groupnorm_final_cat(const float* ws1, int64_t C1, const float* ws2, int64_t C2, float* stats, int64_t B,

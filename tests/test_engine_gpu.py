@@ -126,3 +126,33 @@ def test_skip_conv_operand_from_the_groupnorm_pass_bit_exact(golden):
             eng.fuse_skip_quant = False
             plain = eng(x, t, c)
         assert torch.equal(fused, plain)
+
+
+def test_cfg_pair_shares_the_context_independent_prefix_bit_exact(golden):
+    """Classifier-free guidance evaluates [x, x] with contexts [uncond, cond]; the leading blocks without attention do
+    not see the context, so sampling.GraphedUNet(cfg_pair=True) runs them once for both halves and keeps their skip
+    tensors at half the batch (read periodically by GroupNorm / quantise over the skip concatenation): the same bits
+    as the eager engine on the doubled batch."""
+    from edadm.sampling import GraphedUNet
+    g = golden("g13_ldm_imagenet")
+    qnn, (x, t, c), _ = quantize_like_reference(build_ldm(g), g, "ldm")
+    qnn.set_quant_state(True, True)
+    half = x.shape[0] // 2
+    with torch.no_grad():
+        eng = qnn.freeze()
+        x2 = torch.cat([x[:half], x[:half]]).contiguous()
+        t2 = torch.cat([t[:half], t[:half]]).contiguous()
+        gu = GraphedUNet(eng, x2, t2, c, cfg_pair=True)
+        assert eng.cfg_pair is False
+        for k in range(2):
+            xk = torch.cat([x[k:k + half], x[k:k + half]]).contiguous() if k + half <= x.shape[0] else x2
+            ck = (c * (1.0 + 0.3 * k)).contiguous()
+            assert torch.equal(gu(xk, t2, ck), eng(xk, t2, ck)), k
+        for flag in (True, False):                       # with and without the fused skip-convolution operand
+            eng.fuse_skip_quant = flag
+            eng.cfg_pair = True
+            try:
+                shared = eng(x2, t2, c)
+            finally:
+                eng.cfg_pair = False
+            assert torch.equal(shared, eng(x2, t2, c)), flag

@@ -10,7 +10,9 @@ B = 50
 x = torch.randn(2 * B, 3, 64, 64, device=dev); t = torch.full((2 * B,), 501, dtype=torch.long, device=dev)
 c = torch.randn(2 * B, 1, 512, device=dev)
 eng.ctx_r = eng.context_branches(c)          # the per-step launch set of the sampling loops (context vectors and
-eng.emb_r = eng.emb_rows(t)                  # time-embedding rows precomputed)
+eng.emb_r = eng.emb_rows(t)                  # time-embedding rows precomputed; the batch is a guidance pair [x, x])
+x = torch.cat([x[:B], x[:B]]).contiguous()
+eng.cfg_pair = True
 torch.cuda.synchronize()
 import ctypes
 hip = ctypes.CDLL("libamdhip64.so")
