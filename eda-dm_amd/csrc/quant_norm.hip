@@ -545,21 +545,27 @@ extern "C" int edadm_add(const float* a, const float* b, float* out, int64_t n, 
 // over a one-token context is the same vector for every query: softmax over one key is 1)
 __global__ void __launch_bounds__(256) k_add_rowbcast(const float* __restrict__ x, const float* __restrict__ r,
                                                       float* __restrict__ out, int64_t rows, int64_t C4,
-                                                      int64_t rows_per_batch) {
+                                                      int64_t rows_per_batch, int64_t xrows) {
+    // xrows > 0: x holds xrows < rows rows and is read periodically (the half of a guidance pair that both halves share)
     const int64_t n = rows * C4, stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const int64_t m = i / C4, c = i - m * C4;
-        const float4 a = reinterpret_cast<const float4*>(x)[i];
+        const float4 a = reinterpret_cast<const float4*>(x)[xrows > 0 ? (m % xrows) * C4 + c : i];
         const float4 b = reinterpret_cast<const float4*>(r)[(m / rows_per_batch) * C4 + c];
         reinterpret_cast<float4*>(out)[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
     }
 }
+extern "C" int edadm_add_rowbcast_rep(const float* x, const float* r, float* out, int64_t rows, int64_t C,
+                                      int64_t rows_per_batch, int64_t xrows, void* stream) {
+    if (!x || !r || !out || rows <= 0 || C <= 0 || (C & 3) || rows_per_batch <= 0 || xrows < 0 || (xrows > 0 && rows % xrows))
+        return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_add_rowbcast, dim3(edadm_grid(rows * C / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, r, out,
+                       rows, C / 4, rows_per_batch, xrows);
+    return edadm_launch_status();
+}
 extern "C" int edadm_add_rowbcast(const float* x, const float* r, float* out, int64_t rows, int64_t C,
                                   int64_t rows_per_batch, void* stream) {
-    if (!x || !r || !out || rows <= 0 || C <= 0 || (C & 3) || rows_per_batch <= 0) return EDADM_EINVAL;
-    hipLaunchKernelGGL(k_add_rowbcast, dim3(edadm_grid(rows * C / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, r, out,
-                       rows, C / 4, rows_per_batch);
-    return edadm_launch_status();
+    return edadm_add_rowbcast_rep(x, r, out, rows, C, rows_per_batch, 0, stream);
 }
 // channel concat of two NHWC tensors (the UNet skip connection, openaimodel.py:778)
 __global__ void __launch_bounds__(256) k_concat(const float* __restrict__ a, int64_t Ca, const float* __restrict__ b,

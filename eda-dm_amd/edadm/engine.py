@@ -118,6 +118,7 @@ class Engine:
         # one half and its skip tensors stay at half the batch (read periodically by their consumers)
         self.cfg_pair = False
         self._emb_n = None           # rows of the emb tables to use while the shared prefix runs
+        self.pair_stats = {"prefix_blocks": 0, "half_attention_blocks": 0}   # what the last cfg_pair call shared
         self.ctx_r = None            # {id(transformer block): [B][C]} from context_branches(), set by a sampling loop
         self.emb_r = None            # {id(emb projection): [B][N]} time-embedding rows of the current step (emb_tables())
         self.gn_from_producer = os.environ.get("EDADM_GN_FROM_PRODUCER", "0") == "1"   # measured slower (58.4 vs 61.7 img/s): off
@@ -645,7 +646,14 @@ class Engine:
                     out[id(blk)] = self._one_token_branch(blk, torch.zeros(B, C, device=ctx.device), ctx, B)
         return out
 
-    def ldm_transformer(self, st, x, context):
+    def ldm_transformer(self, st, x, context, pair_half=False):
+        """pair_half: x is the shared half of a guidance pair.  Everything up to and including the first block's
+        self-attention is context-independent; the halves part where the (precomputed) cross-attention vectors are added,
+        which is where the batch fans out -- the result is the full pair."""
+        blocks0 = st.transformer_blocks[0]
+        half_mode = pair_half and self.ctx_r is not None and context is not None and id(blocks0) in self.ctx_r
+        if pair_half and not half_mode:
+            x = torch.cat([x, x])
         B, H, W, C = x.shape
         N = H * W
         _, (a,) = self.gn(st.norm, x, False, (st.proj_in,))
@@ -655,7 +663,12 @@ class Engine:
             oq, ok, ov = self.ln(blk.norm1, t, (a1.to_q, a1.to_k, a1.to_v))
             t = self.ldm_cross_attn(a1, oq, (ok, ov), B, N, N, residual=t)
             a2 = blk.attn2
-            if context is not None and context.shape[1] == 1 and self.one_token_context:
+            if half_mode and blk is blocks0:
+                # the pair fans out here: t (one half) + the per-image cross-attention vectors of both halves
+                t = ops.add_rowbcast(t, self.ctx_r[id(blk)], N, rows=2 * B * N)
+                x = torch.cat([x, x])
+                B *= 2
+            elif context is not None and context.shape[1] == 1 and self.one_token_context:
                 # One-token context (class-conditional LDM): softmax over a single key is exactly 1 for every query,
                 # so the branch's output is ONE vector per image.  It is computed for one query row per image through
                 # the same kernels (q/k/v projections, products, quantisers, to_out -- the same codes) and broadcast:
@@ -751,6 +764,7 @@ class Engine:
             while n_pre < len(blocks) and not any(hasattr(m, "transformer_blocks") or type(m).__name__.endswith("AttentionBlock")
                                                   for m in blocks[n_pre]):
                 n_pre += 1
+        self.pair_stats = {"prefix_blocks": n_pre, "half_attention_blocks": 0}
         if n_pre:
             half = B // 2
             hp, self._emb_n = h[:half], half
@@ -761,7 +775,21 @@ class Engine:
                     hs.append(hp)
             finally:
                 self._emb_n = None
-            h = torch.cat([hp, hp])
+            nxt = list(blocks[n_pre]) if n_pre < len(blocks) else []
+            if len(nxt) == 2 and isinstance(nxt[0], QuantResBlock) and isinstance(nxt[1], ldm_unet.SpatialTransformer) and \
+                    self.ctx_r is not None and ctx is not None:
+                # the first attention block: its ResBlock, proj_in and self-attention are still context-independent
+                self._emb_n = half
+                try:
+                    hp = self.ldm_res(nxt[0], hp, ep)
+                finally:
+                    self._emb_n = None
+                h = self.ldm_transformer(nxt[1], hp, ctx, pair_half=True)
+                hs.append(h)
+                n_pre += 1
+                self.pair_stats["half_attention_blocks"] = 1
+            else:
+                h = torch.cat([hp, hp])
         for mods in blocks[n_pre:]:
             h = self.ldm_seq(mods, h, emb, ctx)
             hs.append(h)

@@ -342,11 +342,14 @@ def add(a, b):
     return out
 
 
-def add_rowbcast(x2d, r, rows_per_batch, out=None):
-    """x2d[m] + r[m // rows_per_batch] (a per-image vector added to every row of the image)."""
-    rows, C = x2d.shape
-    out = torch.empty_like(x2d) if out is None else out
-    lib.call("edadm_add_rowbcast", _pf(x2d), _pf(r), _pf(out), rows, C, int(rows_per_batch), _stream())
+def add_rowbcast(x2d, r, rows_per_batch, out=None, rows=None):
+    """x2d[m] + r[m // rows_per_batch] (a per-image vector added to every row of the image).  rows > len(x2d): x2d is
+    read periodically and the result has `rows` rows (the shared half of a guidance pair fanning out)."""
+    xr, C = x2d.shape
+    rows = xr if rows is None else int(rows)
+    out = torch.empty(rows, C, dtype=torch.float32, device=x2d.device) if out is None else out
+    lib.call("edadm_add_rowbcast_rep", _pf(x2d), _pf(r), _pf(out), rows, C, int(rows_per_batch), xr if rows != xr else 0,
+             _stream())
     return out
 
 

@@ -186,6 +186,9 @@ int edadm_add(const float* a, const float* b, float* out, int64_t n, void* strea
  * a single key is exactly 1 for every query -- so it is computed for one query row per image and broadcast */
 int edadm_add_rowbcast(const float* x, const float* r, float* out, int64_t rows, int64_t C, int64_t rows_per_batch,
                        void* stream);
+/* the same with x of xrows < rows rows read periodically (out has `rows` rows): the shared half of a guidance pair */
+int edadm_add_rowbcast_rep(const float* x, const float* r, float* out, int64_t rows, int64_t C, int64_t rows_per_batch,
+                           int64_t xrows, void* stream);
 int edadm_concat_c(const float* a, int64_t Ca, const float* b, int64_t Cb, float* out, int64_t rows,
                    void* stream);
 int edadm_avgpool2_nhwc(const float* x, float* out, int64_t B, int64_t H, int64_t W, int64_t C, void* stream);

@@ -144,6 +144,8 @@ def test_cfg_pair_shares_the_context_independent_prefix_bit_exact(golden):
         t2 = torch.cat([t[:half], t[:half]]).contiguous()
         gu = GraphedUNet(eng, x2, t2, c, cfg_pair=True)
         assert eng.cfg_pair is False
+        # the graph shares the attention-free prefix AND the first attention block up to its self-attention
+        assert eng.pair_stats["prefix_blocks"] >= 1 and eng.pair_stats["half_attention_blocks"] == 1
         for k in range(2):
             xk = torch.cat([x[k:k + half], x[k:k + half]]).contiguous() if k + half <= x.shape[0] else x2
             ck = (c * (1.0 + 0.3 * k)).contiguous()
