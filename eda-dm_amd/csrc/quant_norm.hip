@@ -383,21 +383,41 @@ __global__ void __launch_bounds__(256) k_ln_quant_v4(const float* __restrict__ x
                                                      const float* __restrict__ beta, int64_t rows, int64_t C,
                                                      float eps, float* __restrict__ out_f32, int8_t* __restrict__ q0,
                                                      int8_t* __restrict__ q1, int8_t* __restrict__ q2,
-                                                     const QP* __restrict__ qp, int nq) {
+                                                     const QP* __restrict__ qp, int nq,
+                                                     const float* __restrict__ radd, int64_t rows_per_batch,
+                                                     int64_t xrows, float* __restrict__ sum_out) {
+    // radd: the input of the norm is x[row] + radd[row / rows_per_batch] (edadm_add_rowbcast folded in: the sum is
+    // written to sum_out, the updated residual stream); xrows > 0: x has xrows < rows rows, read periodically
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     QP qa = qp ? qp_load(qp, 0) : QP{1, 0, 255, 1}, qb = (qp && nq > 1) ? qp_load(qp, 1) : qa, qc = (qp && nq > 2) ? qp_load(qp, 2) : qa;
     const int Q = (int)(C >> 2);
-    const float4* xr = reinterpret_cast<const float4*>(x + row * C);
+    const float4* xr = reinterpret_cast<const float4*>(x + (xrows > 0 ? row % xrows : row) * C);
     float4 v[LN_MAXV4];
     float s = 0.f;
+    if (radd) {
+        const float4* rr = reinterpret_cast<const float4*>(radd + (row / rows_per_batch) * C);
 #pragma unroll
-    for (int j = 0; j < LN_MAXV4; ++j) {
-        const int c = j * 64 + lane;
-        v[j] = c < Q ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-        s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+        for (int j = 0; j < LN_MAXV4; ++j) {
+            const int c = j * 64 + lane;
+            if (c < Q) {
+                const float4 a = xr[c], b = rr[c];
+                v[j] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+                reinterpret_cast<float4*>(sum_out)[row * Q + c] = v[j];
+            } else {
+                v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < LN_MAXV4; ++j) {
+            const int c = j * 64 + lane;
+            v[j] = c < Q ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
+#pragma unroll
+    for (int j = 0; j < LN_MAXV4; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
     const float mean = wave_sum(s) / (float)C;
     float ss = 0.f;
 #pragma unroll
@@ -482,10 +502,30 @@ extern "C" int edadm_layernorm_quant(const float* x, const float* gamma, const f
                     !(((uintptr_t)q0 | (uintptr_t)q1 | (uintptr_t)q2) & 3);
     if ((C & 3) == 0 && C <= 256 * LN_MAXV4 && al)
         hipLaunchKernelGGL(k_ln_quant_v4, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma,
-                           beta, rows, C, eps, out_f32, q0, q1, q2, (const QP*)qp, nq);
+                           beta, rows, C, eps, out_f32, q0, q1, q2, (const QP*)qp, nq, (const float*)nullptr, (int64_t)1,
+                           (int64_t)0, (float*)nullptr);
     else
         hipLaunchKernelGGL(k_ln_quant, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma,
                            beta, rows, C, eps, out_f32, q0, q1, q2, (const QP*)qp, nq);
+    return edadm_launch_status();
+}
+
+// LayerNorm of x[row] + radd[row / rows_per_batch] with the sum written out as the updated residual stream: the
+// broadcast add of a per-image vector (edadm_add_rowbcast) folded into the norm that reads its result next
+extern "C" int edadm_layernorm_quant_radd(const float* x, int64_t xrows, const float* radd, int64_t rows_per_batch,
+                                          float* sum_out, const float* gamma, const float* beta, int64_t rows, int64_t C,
+                                          float eps, int8_t* q0, int8_t* q1, int8_t* q2, const float* qp, int nq,
+                                          void* stream) {
+    if (!x || !radd || !sum_out || !gamma || !beta || rows <= 0 || C <= 0 || (C & 3) || C > 256 * LN_MAXV4 ||
+        rows_per_batch <= 0 || xrows < 0 || (xrows > 0 && rows % xrows))
+        return EDADM_EINVAL;
+    if ((q0 || q1 || q2) && !qp) return EDADM_EINVAL;
+    if ((((uintptr_t)x | (uintptr_t)radd | (uintptr_t)sum_out | (uintptr_t)gamma | (uintptr_t)beta) & 15) ||
+        (((uintptr_t)q0 | (uintptr_t)q1 | (uintptr_t)q2) & 3))
+        return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_ln_quant_v4, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
+                       rows, C, eps, (float*)nullptr, q0, q1, q2, (const QP*)qp, nq, radd, rows_per_batch,
+                       xrows == rows ? (int64_t)0 : xrows, sum_out);
     return edadm_launch_status();
 }
 

@@ -113,6 +113,7 @@ class Engine:
         self._attn_cache = {}
         self.one_token_context = os.environ.get("EDADM_ONE_TOKEN_CONTEXT", "1") != "0"
         self.fuse_skip_quant = os.environ.get("EDADM_FUSE_SKIP_QUANT", "1") != "0"
+        self.fuse_rowadd_ln = os.environ.get("EDADM_FUSE_ROWADD_LN", "1") != "0"
         # classifier-free guidance evaluates [x, x] with contexts [uncond, cond]: the two halves are identical until the first
         # context-dependent layer.  A sampling loop that builds the pair itself sets cfg_pair: that prefix then runs on
         # one half and its skip tensors stay at half the batch (read periodically by their consumers)
@@ -352,6 +353,13 @@ class Engine:
         if key not in self._attn_cache:
             self._attn_cache[key] = Ls[0].qp if len(Ls) == 1 else torch.cat([l.qp for l in Ls]).contiguous()
         return self._attn_cache[key]
+
+    def ln_radd(self, norm, x2d, radd, rows_per_batch, qms, rows):
+        """LayerNorm(x2d + radd per image) -> (the sum = updated residual stream, operands)."""
+        Ls = [self.L(q) for q in qms]
+        assert all(l.mode == "i8" and not l.split for l in Ls)
+        return ops.layernorm_quant_radd(x2d, radd, rows_per_batch, norm.weight, norm.bias, norm.eps, self._qp_cat(Ls),
+                                        len(Ls), rows=rows)
 
     def ln(self, norm, x2d, qms):
         Ls = [self.L(q) for q in qms]
@@ -663,9 +671,10 @@ class Engine:
             oq, ok, ov = self.ln(blk.norm1, t, (a1.to_q, a1.to_k, a1.to_v))
             t = self.ldm_cross_attn(a1, oq, (ok, ov), B, N, N, residual=t)
             a2 = blk.attn2
+            pend = None                  # (vector per image, rows): a broadcast add folded into norm3 below
             if half_mode and blk is blocks0:
                 # the pair fans out here: t (one half) + the per-image cross-attention vectors of both halves
-                t = ops.add_rowbcast(t, self.ctx_r[id(blk)], N, rows=2 * B * N)
+                pend = (self.ctx_r[id(blk)], 2 * B * N)
                 x = torch.cat([x, x])
                 B *= 2
             elif context is not None and context.shape[1] == 1 and self.one_token_context:
@@ -678,7 +687,7 @@ class Engine:
                 r = self.ctx_r.get(id(blk)) if self.ctx_r is not None else None
                 if r is None:
                     r = self._one_token_branch(blk, t.reshape(B, N, C)[:, 0].contiguous(), context, B)
-                t = ops.add_rowbcast(t, r, N)
+                pend = (r, B * N)
             else:
                 (oq,) = self.ln(blk.norm2, t, (a2.to_q,))
                 if context is None:
@@ -690,7 +699,13 @@ class Engine:
                     nk = context.shape[1]
                 t = self.ldm_cross_attn(a2, oq, (ok, ov), B, N, nk, residual=t)
             ff0, ff2 = blk.ff.net[0].proj, blk.ff.net[2]
-            (of,) = self.ln(blk.norm3, t, (ff0,))
+            if pend is not None and self.fuse_rowadd_ln and C % 4 == 0:
+                # t + r per image and norm3 of the sum in one pass (the sum is the updated residual stream)
+                t, (of,) = self.ln_radd(blk.norm3, t, pend[0], N, (ff0,), pend[1])
+            else:
+                if pend is not None:
+                    t = ops.add_rowbcast(t, pend[0], N, rows=pend[1])
+                (of,) = self.ln(blk.norm3, t, (ff0,))
             L0, L2 = self.L(ff0), self.L(ff2)
             if getattr(L0, "geglu_interleaved", False):
                 g = self._gemm(L0, of, B * N, out_mode=3, oqp=L2.qp)

@@ -307,6 +307,18 @@ def groupnorm_apply(x_nhwc, stats, gamma, beta, G, silu, qp=None, nq=0, want_f32
     return out, qs
 
 
+def layernorm_quant_radd(x2d, radd, rows_per_batch, gamma, beta, eps, qp, nq, rows=None):
+    """LayerNorm(x2d[m % len(x2d)] + radd[m // rows_per_batch]) -> (the sum [rows][C], [int8 operands])."""
+    xr, C = x2d.shape
+    rows = xr if rows is None else int(rows)
+    summ = torch.empty(rows, C, dtype=torch.float32, device=x2d.device)
+    qs = [torch.empty(rows, C, dtype=torch.int8, device=x2d.device) for _ in range(nq)]
+    qq = qs + [None] * (3 - nq)
+    lib.call("edadm_layernorm_quant_radd", _pf(x2d), xr, _pf(radd), int(rows_per_batch), _pf(summ), _pf(gamma), _pf(beta),
+             rows, C, float(eps), _p(qq[0]), _p(qq[1]), _p(qq[2]), _pf(qp), nq, _stream())
+    return summ, qs
+
+
 def layernorm_quant(x2d, gamma, beta, eps, qp=None, nq=0, want_f32=False):
     rows, C = x2d.shape
     out = torch.empty_like(x2d) if want_f32 else None

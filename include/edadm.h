@@ -175,6 +175,12 @@ int edadm_groupnorm_final_cat(const float* ws1, int64_t C1, const float* ws2, in
 int edadm_layernorm_quant(const float* x, const float* gamma, const float* beta, int64_t rows, int64_t C,
                           float eps, float* out_f32, int8_t* q0, int8_t* q1, int8_t* q2, const float* qp,
                           int nq, void* stream);
+/* LayerNorm of x[row] + radd[row / rows_per_batch] (C % 4 == 0); the sum is written to sum_out [rows][C] -- the updated
+ * residual stream: edadm_add_rowbcast folded into the norm that consumes its result.  xrows: rows of x (a divisor of
+ * `rows`: x is read periodically -- the shared half of a guidance pair -- or rows itself) */
+int edadm_layernorm_quant_radd(const float* x, int64_t xrows, const float* radd, int64_t rows_per_batch, float* sum_out,
+                               const float* gamma, const float* beta, int64_t rows, int64_t C, float eps, int8_t* q0,
+                               int8_t* q1, int8_t* q2, const float* qp, int nq, void* stream);
 /* SiLU / GEGLU producers (quant_block.py:86-116 emb path; attention.py:37-45). */
 int edadm_silu_quant_i8(const float* x, int8_t* out, int64_t n, const float* qp, void* stream);
 int edadm_geglu_quant_i8(const float* x, int8_t* out, int64_t rows, int64_t inner, const float* qp,

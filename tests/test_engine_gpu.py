@@ -61,6 +61,9 @@ def test_one_token_context_shortcut_is_bit_exact(golden):
         eng.one_token_context = False
         full = eng(x, t, ctx)
     assert torch.equal(short, full)
+    with torch.no_grad():                      # ... and with the broadcast add as its own pass instead of inside norm3
+        eng.one_token_context, eng.fuse_rowadd_ln = True, False
+        assert torch.equal(eng(x, t, ctx), short)
 
 
 def test_context_branches_hoisted_out_of_the_step_graph_bit_exact(golden):
