@@ -16,34 +16,63 @@ def world():
 
 
 def shard_batches(n_batches, rank=None, size=None):
-    """Batch indices owned by `rank`: i with i % world == rank (stable, order preserving)."""
+    """Calibration batches owned by `rank`: one contiguous block of ceil(n / world) indices per rank (the last ranks may
+    own fewer, or none), so that the all-gathered slab IS the cache in batch order -- no re-ordering copy."""
     if rank is None:
         rank, size = world()
-    return [i for i in range(n_batches) if i % size == rank]
+    per = (n_batches + size - 1) // size
+    return list(range(min(rank * per, n_batches), min((rank + 1) * per, n_batches)))
+
+
+def shard_round_robin(n, rank=None, size=None):
+    """Sampling batches owned by `rank`: i with i % world == rank (rank r generates batches
+    {i : i mod world = r} of the reference's batch sequence)."""
+    if rank is None:
+        rank, size = world()
+    return [i for i in range(n) if i % size == rank]
+
+
+def gather_rows(local, n_batches, group=None):
+    """local: {batch index: tensor [rows, ...]} for this rank's block -> ONE tensor [n_batches * rows, ...] holding all
+    batches in index order on every rank.  Each rank writes its batches straight into its slot of the output and one
+    all_gather_into_tensor (RCCL: every GPU has a direct xGMI link to each peer) fills the rest in place: peak memory is
+    the cache itself, not twice it.  Every rank must own at least one batch (checked before any collective, on all
+    ranks alike, so a bad configuration raises everywhere instead of hanging the ranks that did enter)."""
+    rank, size = world()
+    if size == 1:
+        return torch.cat([local[i] for i in range(n_batches)])
+    per = (n_batches + size - 1) // size
+    if (size - 1) * per >= n_batches:
+        raise ValueError("%d calibration batches cannot be sharded over %d ranks (a rank would own none)" % (n_batches, size))
+    ref = next(iter(local.values()))
+    rows = ref.shape[0]
+    out = torch.empty((size * per * rows,) + tuple(ref.shape[1:]), dtype=ref.dtype, device=ref.device)
+    slot = out[rank * per * rows:(rank + 1) * per * rows]
+    mine = shard_batches(n_batches, rank, size)
+    for j, i in enumerate(mine):
+        slot[j * rows:(j + 1) * rows].copy_(local[i])
+    if len(mine) < per:
+        slot[len(mine) * rows:].zero_()                       # the padding of the last block travels too
+    if dist.get_backend(group) == "gloo":                     # CPU tests: gloo has no in-place flat all-gather
+        dist.all_gather([out[r * per * rows:(r + 1) * per * rows] for r in range(size)], slot.clone(), group=group)
+    else:
+        dist.all_gather_into_tensor(out, slot, group=group)
+    GATHER_STATS["bytes"] += out.numel() * out.element_size()
+    GATHER_STATS["calls"] += 1
+    return out[:n_batches * rows]
+
+
+GATHER_STATS = {"bytes": 0, "calls": 0}      # bytes of gathered slabs (bench.py's multi-rank calibration leg)
 
 
 def all_gather_batches(local, n_batches, group=None):
-    """local: {batch index: tensor}; returns the list of all n_batches tensors in index order on
-    every rank.  All tensors share a shape; ranks may own different numbers of batches."""
-    rank, size = world()
-    if size == 1:
+    """local: {batch index: tensor}; returns the list of all n_batches tensors in index order on every rank (views of
+    the one gathered slab)."""
+    if world()[1] == 1:
         return [local[i] for i in range(n_batches)]
-    per_rank = (n_batches + size - 1) // size
-    ref = next(iter(local.values())) if local else None
-    shape_t = torch.tensor(list(ref.shape) if ref is not None else [0], device=ref.device if ref is not None else "cpu")
-    if ref is None:
-        raise RuntimeError("a rank without any calibration batch cannot infer the slab shape; use n_batches >= world")
-    mine = shard_batches(n_batches, rank, size)
-    slab = torch.zeros((per_rank,) + tuple(ref.shape), dtype=ref.dtype, device=ref.device)
-    for j, i in enumerate(mine):
-        slab[j] = local[i]
-    out = [torch.empty_like(slab) for _ in range(size)]
-    dist.all_gather(out, slab, group=group)
-    res = [None] * n_batches
-    for r in range(size):
-        for j, i in enumerate(shard_batches(n_batches, r, size)):
-            res[i] = out[r][j]
-    return res
+    full = gather_rows(local, n_batches, group)
+    rows = full.shape[0] // n_batches
+    return [full[i * rows:(i + 1) * rows] for i in range(n_batches)]
 
 
 def broadcast_params(tensors, src=0):

@@ -57,7 +57,6 @@ class FrozenLayer:
             self.kind = "dense"
         self.cin = w.shape[1]
         self.split = qm.split
-        assert qm.use_weight_quant or True
         wqs = [qm.weight_quantizer] + ([qm.weight_quantizer_0] if qm.split else [])
         aqs = [qm.act_quantizer] + ([qm.act_quantizer_0] if qm.split else [])
         bounds = [(0, self.cin)] if not qm.split else [(0, qm.split), (qm.split, self.cin)]

@@ -120,16 +120,18 @@ def _as_param(q):
     q.delta = torch.nn.Parameter(q.delta.detach().clone())
 
 
-def _attention_quantizers(module):
-    """q, k, v, w activation quantizers owned by an attention wrapper, in the reference's order."""
+def _attention_quantizers(module, control=True):
+    """q, k, v, w activation quantizers owned by an attention wrapper, in the reference's order.  The transformer
+    block's eight are trainables of the conditional walk only (qdiff_control/block_recon.py:82-110); qdiff/block_recon.py:66-93
+    knows QuantAttentionBlock and QuantAttnBlock, qdiff_control/block_recon.py:68-110 QuantAttnBlock and the transformer block."""
     from qdiff.quant_block import QuantAttnBlock, QuantAttentionBlock, QuantBasicTransformerBlock
     names = ("act_quantizer_q", "act_quantizer_k", "act_quantizer_v", "act_quantizer_w")
-    if isinstance(module, QuantAttentionBlock):
+    if isinstance(module, QuantAttentionBlock) and not control:
         qk, smv = module.attention.qkv_matmul, module.attention.smv_matmul
         return [qk.act_quantizer_q, qk.act_quantizer_k, smv.act_quantizer_v, smv.act_quantizer_w]
     if isinstance(module, QuantAttnBlock):
         return [getattr(module, n) for n in names]
-    if isinstance(module, QuantBasicTransformerBlock):
+    if isinstance(module, QuantBasicTransformerBlock) and control:
         return [getattr(a, n) for a in (module.attn1, module.attn2) for n in names]
     return []
 
@@ -196,7 +198,7 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
                     q.soft_targets = True
                     w_para.append(q.alpha)
         if isinstance(module, (QuantModule, BaseQuantBlock)):
-            aqs = _attention_quantizers(module) if act_quant else []
+            aqs = _attention_quantizers(module, control) if act_quant else []
             if act_quant and module.act_quantizer.delta is not None:
                 aqs = aqs + [module.act_quantizer]
                 if module.split != 0 and not (control and not is_block):
@@ -216,7 +218,8 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
                                                  input_prob=True, keep_gpu=keep_gpu)
     sz = cached_outs.size(0)
     model.block_count = model.block_count + 1
-    eng, model.engine = getattr(model, "engine", None), None
+    # a frozen int8 executor was compiled from the pre-reconstruction parameters: drop it (freeze() again after the walk)
+    model.engine = None
     feats = None
     # worth it when every sample is drawn more than once (bench.py forces it on its short run and scales the time)
     if is_block and hooks and (iters * batch_size >= 2 * sz or os.environ.get("EDADM_FP_FEAT_FORCE") == "1"):
@@ -275,7 +278,6 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
         torch.cuda.synchronize()
         TIMING["iter_s"] += time.time() - _t_steady
         TIMING["iters"] += iters - 1
-    model.engine = eng
     for module in modules:
         if isinstance(module, QuantModule):
             module.weight_quantizer.soft_targets = False

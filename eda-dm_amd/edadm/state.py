@@ -36,6 +36,8 @@ def load_quant_state(qnn, state, prefix=""):
     """Restore deltas / zero points / bit widths (and splits) captured by `quant_state_dict` or by
     the reference (golden fixtures use prefix 'qp/').  Returns the number of quantizers restored."""
     dev = next(qnn.parameters()).device
+    if hasattr(qnn, "engine"):
+        qnn.engine = None        # compiled from the previous state: freeze() / load_frozen() again
     for name, m in qnn.named_modules():
         if isinstance(m, QuantModule):
             k = prefix + name + "/split"
@@ -47,7 +49,7 @@ def load_quant_state(qnn, state, prefix=""):
     n = 0
     for name, m in qnn.named_modules():
         if not isinstance(m, UniformAffineQuantizer):
-            continue
+            continue                                   # AdaRound quantizers: below
         k = prefix + name
         if k + "/delta" not in state:
             continue
@@ -57,6 +59,31 @@ def load_quant_state(qnn, state, prefix=""):
         m.delta = torch.nn.Parameter(delta) if m.leaf_param else delta
         m.set_inited(True)
         n += 1
+    # learned rounding: a weight quantizer saved as an AdaRoundQuantizer comes back as one (hard mode), its alpha restored,
+    # so the quantiser-state file alone reproduces the calibrated integer weights
+    for name, m in qnn.named_modules():
+        if not isinstance(m, QuantModule):
+            continue
+        for attr in ("weight_quantizer", "weight_quantizer_0"):
+            k = "%s%s.%s/alpha" % (prefix, name, attr)
+            q = getattr(m, attr, None)
+            if k not in state or q is None:
+                continue
+            alpha = torch.as_tensor(np.asarray(state[k]), dtype=torch.float32, device=dev)
+            if not isinstance(q, AdaRoundQuantizer):
+                w = m.org_weight.data
+                if m.split:
+                    w = w[:, :m.split, ...] if attr == "weight_quantizer" else w[:, m.split:, ...]
+                q = AdaRoundQuantizer(uaq=q, round_mode='learned_hard_sigmoid', weight_tensor=w)
+                setattr(m, attr, q)
+            else:
+                q.delta, q.zero_point = (torch.as_tensor(np.asarray(state[k[:-5] + sfx]), dtype=torch.float32, device=dev)
+                                         for sfx in ("delta", "zero_point"))
+                q._d, q._z = q.delta.reshape(-1).contiguous(), q.zero_point.reshape(-1).contiguous()
+            assert tuple(alpha.shape) == tuple(q.alpha.shape), (k, alpha.shape, q.alpha.shape)
+            with torch.no_grad():
+                q.alpha.copy_(alpha)
+            q.soft_targets = False
     return n
 
 

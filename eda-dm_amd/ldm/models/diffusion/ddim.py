@@ -43,7 +43,7 @@ class DDIMSampler(object):
         C, H, W = shape
         size = (batch_size, C, H, W)
         if quant_unet:
-            return self._calibration_forward(cali_data, unconditional_guidance_scale)
+            return self._calibration_forward(cali_data, unconditional_guidance_scale, conditioning)
         samples, intermediates, feature_map = self.ddim_sampling(
             conditioning, size, x_T=x_T, temperature=temperature,
             unconditional_guidance_scale=unconditional_guidance_scale,
@@ -53,9 +53,9 @@ class DDIMSampler(object):
             return samples, intermediates
         return samples, intermediates, feature_map
 
-    def _calibration_forward(self, cali_data, scale):
+    def _calibration_forward(self, cali_data, scale, conditioning=None):
         x, t, index = cali_data[0], cali_data[1], cali_data[2]
-        return self.p_sample_ddim(x, None, t, index=index, quant_unet=True)
+        return self.p_sample_ddim(x, conditioning, t, index=index, quant_unet=True)          # ddim.py:100-105
 
     @torch.no_grad()
     def ddim_sampling(self, cond, shape, x_T=None, temperature=1., unconditional_guidance_scale=1.,

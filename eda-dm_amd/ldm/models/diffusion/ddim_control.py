@@ -7,7 +7,7 @@ from ldm.models.diffusion.ddim import DDIMSampler
 class DDIMSampler_control(DDIMSampler):
     cfg_capable = True
 
-    def _calibration_forward(self, cali_data, scale):
+    def _calibration_forward(self, cali_data, scale, conditioning=None):
         x, t, index, c, uc = cali_data[:5]
         return self.p_sample_ddim(x, c, t, index=index, unconditional_guidance_scale=scale,
                                   unconditional_conditioning=uc, quant_unet=True)

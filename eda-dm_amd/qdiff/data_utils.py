@@ -244,11 +244,14 @@ def _quant_prefix_input(model, layer, model_input, device, act_quant, trace=None
     patched, guards = [], []
     clean = [True]        # no pending unit has executed yet in this pass: everything so far is final
     if trace is not None and trace.memo_budget > 0:
-        for v in recon_units(model):
+        top = recon_units(model)
+        for v in top:
             if v not in trace.done:
                 guards.append(v.register_forward_hook(lambda *_: clean.__setitem__(0, False)))
         for u in trace.done:
-            if u is layer or "forward" in u.__dict__:
+            # units of the walk only: a layer reconstructed from inside a block (recon_layer_Qmodel) sits behind
+            # siblings that may still change, and the guards above only see whole units
+            if u is layer or "forward" in u.__dict__ or not any(u is v for v in top):
                 continue
 
             def fwd(*a, _u=u, _orig=u.forward, **k):
@@ -285,6 +288,11 @@ def save_inp_oup_data(model, layer, cali_data, asym=False, act_quant=False, batc
     device = next(model.parameters()).device
     get = GetLayerInpOut(model, layer, device=device, asym=asym, input_prob=input_prob, act_quant=act_quant)
     n_batches = int(cali_data[0].size(0) / batch_size)
+    if n_batches == 0:
+        raise ValueError("fewer calibration samples than the caching batch size (%d)" % batch_size)
+    if not edist.shard_batches(n_batches, edist.world()[1] - 1, edist.world()[1]):
+        # checked on every rank before any forward or collective: raises everywhere instead of hanging the others
+        raise ValueError("%d calibration batches cannot be sharded over %d ranks" % (n_batches, edist.world()[1]))
     mine = edist.shard_batches(n_batches)
     local = {}
     resblock = False
@@ -313,11 +321,9 @@ def save_inp_oup_data(model, layer, cali_data, asym=False, act_quant=False, batc
             res = get(batch_of(i))
             resblock = res[0]
             local[i] = res[1:]
-    if n_batches == 0:
-        raise ValueError("fewer calibration samples than the caching batch size (%d)" % batch_size)
 
     def gather(select):
-        return torch.cat(edist.all_gather_batches({i: select(v) for i, v in local.items()}, n_batches))
+        return edist.gather_rows({i: select(v) for i, v in local.items()}, n_batches)
 
     if resblock:
         inps = [gather(lambda v: v[0][0]), gather(lambda v: v[0][1])]

@@ -88,12 +88,20 @@ class _FakeQuantChannel(torch.autograd.Function):
     def forward(ctx, x, delta, zp, qmax):
         x = x.contiguous()
         inner = x[0].numel()
+        if ctx.needs_input_grad[0]:
+            ctx.save_for_backward(x, delta.detach(), zp.detach())
+            ctx.qmax = qmax
         return ops.fake_quant_fwd(x, delta.reshape(-1).contiguous(), zp.reshape(-1).float().contiguous(), qmax,
                                   inner=inner)
 
     @staticmethod
     def backward(ctx, gy):
-        return gy, None, None, None
+        # straight-through inside the clamp range, zero outside (the reference's torch.clamp, quant_layer.py:268-270);
+        # off the hot loop: inside reconstruction every weight quantizer is an AdaRoundQuantizer, which detaches
+        x, delta, zp = ctx.saved_tensors
+        shp = [x.shape[0]] + [1] * (x.dim() - 1)
+        code = torch.round(x / delta.reshape(shp)) + zp.reshape(shp)
+        return gy * ((code >= 0) & (code <= ctx.qmax)).to(gy.dtype), None, None, None
 
 
 def _first_argmin(scores, dim=0):
@@ -221,13 +229,8 @@ class UniformAffineQuantizer(nn.Module):
 
 def _contract(fwd_func, x, weight, bias, kw):
     """The contraction of quant_layer.py:434 on the fp32-MFMA kernels of edadm.contract (im2col + NT
-    GEMM, autograd backward through the same kernels). EDADM_CONTRACT=blas routes the GEMM through
-    torch.matmul (rocBLAS) instead -- a measurement leg only (tools/calib_bench.py), never a fallback:
-    host tensors go to the plain torch functional, as the reference's do."""
-    if not x.is_cuda:
-        return fwd_func(x, weight, bias, **kw)
-    if os.environ.get("EDADM_CONTRACT", "") == "blas":
-        return _contract_blas(fwd_func, x, weight, bias, kw)
+    GEMM, autograd backward through the same kernels).  There is no other backend: a host tensor raises in
+    edadm.ops (no CPU path)."""
     from edadm import contract
     if fwd_func is F.linear:
         return contract.linear(x, weight, bias)
@@ -237,24 +240,6 @@ def _contract(fwd_func, x, weight, bias, kw):
             and kw["stride"][0] == kw["stride"][1] and kw["padding"][0] == kw["padding"][1]):
         return contract.conv2d(x, weight, bias, kw["stride"][0], kw["padding"][0])
     raise NotImplementedError("contraction %s %s %s" % (fwd_func.__name__, tuple(weight.shape), kw))
-
-
-def _contract_blas(fwd_func, x, weight, bias, kw):
-    if fwd_func is F.conv2d:
-        kh, kw_ = weight.shape[2], weight.shape[3]
-        if kh == 1 and kw_ == 1 and tuple(kw["stride"]) == (1, 1) and tuple(kw["padding"]) == (0, 0):
-            out = torch.einsum("oc,bchw->bohw", weight[:, :, 0, 0], x)
-        else:
-            B, C, H, W = x.shape
-            cols = F.unfold(x, (kh, kw_), padding=kw["padding"], stride=kw["stride"])      # [B, C*kh*kw, L]
-            out = torch.matmul(weight.reshape(weight.shape[0], -1), cols)                 # [B, O, L]
-            Ho = (H + 2 * kw["padding"][0] - kh) // kw["stride"][0] + 1
-            out = out.reshape(B, weight.shape[0], Ho, -1)
-        return out if bias is None else out + bias.view(1, -1, 1, 1)
-    if fwd_func is F.conv1d:
-        out = torch.einsum("oc,bcl->bol", weight[:, :, 0], x)
-        return out if bias is None else out + bias.view(1, -1, 1)
-    return fwd_func(x, weight, bias, **kw)
 
 
 class QuantModule(nn.Module):
@@ -323,9 +308,8 @@ class QuantModule(nn.Module):
             bias = self.bias
         else:
             weight, bias = self.org_weight, self.org_bias
-        # the fp32 contraction of the calibration graph (interim, DESIGN.md "H1 contraction"): a plain GEMM
-        # over unfolded patches (rocBLAS) — MIOpen's untuned convolution search on gfx950 falls back to
-        # naive kernels that are 100x slower; the sampling path never comes here (edadm/engine.py)
+        # the fp32-grade contraction of the calibration graph (DESIGN.md "H1 contraction"); the sampling path never
+        # comes here (edadm/engine.py)
         out = _contract(self.fwd_func, input, weight, bias, self.fwd_kwargs)
         return self.activation_function(out)
 

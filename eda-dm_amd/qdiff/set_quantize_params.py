@@ -27,6 +27,8 @@ def _act_quantizers(root):
 
 def set_act_quantize_params(module: Union[QuantModel, QuantModule, BaseQuantBlock], cali_data, batch_size: int = 256):
     logger.info("set_act_quantize_params")
+    if hasattr(module, 'engine'):
+        module.engine = None          # a frozen executor was compiled from the old scales: freeze() again
     module.set_quant_state(True, True)
     for q in _act_quantizers(module):
         q.set_inited(False)
@@ -40,6 +42,8 @@ def set_act_quantize_params(module: Union[QuantModel, QuantModule, BaseQuantBloc
 
 def set_weight_quantize_params(model, cali_data):
     logger.info("set_weight_quantize_params")
+    if hasattr(model, 'engine'):
+        model.engine = None          # a frozen executor was compiled from the old scales: freeze() again
     model.set_quant_state(True, False)
     for m in model.modules():
         if isinstance(m, QuantModule):

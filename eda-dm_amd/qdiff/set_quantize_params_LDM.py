@@ -47,6 +47,8 @@ def _drive(model, args, cali_batch, sampler):
 def set_act_quantize_params_LDM(model, cali_data, args, batch_size: int = 32):
     logger.info("set_act_quantize_params")
     unet = model.model.diffusion_model
+    if hasattr(unet, 'engine'):
+        unet.engine = None          # a frozen executor was compiled from the old scales: freeze() again
     unet.set_quant_state(True, True)
     for q in all_act_quantizers(unet):
         q.set_inited(False)
@@ -62,6 +64,8 @@ def set_act_quantize_params_LDM(model, cali_data, args, batch_size: int = 32):
 def set_weight_quantize_params_LDM(model, cali_data, args):
     logger.info("set_weight_quantize_params")
     unet = model.model.diffusion_model
+    if hasattr(unet, 'engine'):
+        unet.engine = None          # a frozen executor was compiled from the old scales: freeze() again
     unet.set_quant_state(True, False)
     for m in unet.modules():
         if isinstance(m, QuantModule):

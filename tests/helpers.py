@@ -37,13 +37,6 @@ def build_ldm(g):
     return m.eval()
 
 
-def splits_from_golden(g, prefix="qp/"):
-    """split of a skip conv = number of input channels its first act quantizer covers; the
-    fixtures do not store it, but every split layer has a `weight_quantizer_0` whose delta is
-    per-output-channel, so the split comes from the network structure: set by one FP forward."""
-    return None
-
-
 def quantize_like_reference(model, g, kind, split=True):
     """QuantModel wrapped and configured exactly as the fixture generator did, with the
     reference's own deltas / zero points loaded."""

@@ -42,7 +42,7 @@ def test_shard_gather_broadcast_world2():
     port = _free_port()
     mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
     assert ret[0][0] and ret[1][0]
-    assert ret[0][1] == [0, 2, 4] and ret[1][1] == [1, 3]
+    assert ret[0][1] == [0, 1, 2] and ret[1][1] == [3, 4]          # contiguous blocks: the gathered slab is in batch order
 
 
 def test_single_process_is_identity():

@@ -6,6 +6,34 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "eda-dm_amd"))
 import torch
 import bench
+import torch.nn.functional as F
+
+
+def contract_blas(fwd_func, x, weight, bias, kw):
+    if fwd_func is F.conv2d:
+        kh, kw_ = weight.shape[2], weight.shape[3]
+        if kh == 1 and kw_ == 1 and tuple(kw["stride"]) == (1, 1) and tuple(kw["padding"]) == (0, 0):
+            out = torch.einsum("oc,bchw->bohw", weight[:, :, 0, 0], x)
+        else:
+            B, C, H, W = x.shape
+            cols = F.unfold(x, (kh, kw_), padding=kw["padding"], stride=kw["stride"])      # [B, C*kh*kw, L]
+            out = torch.matmul(weight.reshape(weight.shape[0], -1), cols)                 # [B, O, L]
+            Ho = (H + 2 * kw["padding"][0] - kh) // kw["stride"][0] + 1
+            out = out.reshape(B, weight.shape[0], Ho, -1)
+        return out if bias is None else out + bias.view(1, -1, 1, 1)
+    if fwd_func is F.conv1d:
+        out = torch.einsum("oc,bcl->bol", weight[:, :, 0], x)
+        return out if bias is None else out + bias.view(1, -1, 1)
+    return fwd_func(x, weight, bias, **kw)
+
+
+
+if os.environ.get("EDADM_CONTRACT", "") == "blas":
+    # comparison leg: rocBLAS / torch contraction patched over the product's own kernels (never part of the product)
+    import qdiff.quant_layer as _ql
+    _ql._contract = contract_blas
+
+
 torch.backends.cudnn.benchmark = os.environ.get("CUDNN_BENCH", "0") == "1"
 dev = torch.device("cuda", 0)
 t0 = time.time()
