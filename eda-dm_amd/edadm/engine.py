@@ -124,6 +124,7 @@ class Engine:
         self.gn_from_producer = os.environ.get("EDADM_GN_FROM_PRODUCER", "0") == "1"   # measured slower (58.4 vs 61.7 img/s): off
         self.graph = None
         self.prof = None
+        self.tap = None              # {layer name: [operands]}: diagnostics (per-layer code census), off on the hot path
         # GEGLU is computed in the ff.net[0].proj epilogue: its output channels are re-ordered so that
         # (a_j, gate_j) sit in adjacent columns (attention.py:37-45: x, gate = proj(x).chunk(2))
         for m in self.net.modules():
@@ -247,6 +248,8 @@ class Engine:
         return x2d
 
     def _gemm(self, L, a, M, geom=None, rowadd=None, rpb=1, residual=None, out_mode=0, oqp=None, gn_hw=0):
+        if self.tap is not None:
+            self.tap.setdefault(L.name, []).append(a.detach().clone())
         if out_mode:
             # the only consumer is an activation quantizer: emit its operand from the epilogue
             assert L.mode == "i8" and len(L.segs) == 1 and geom is None
@@ -412,6 +415,39 @@ class Engine:
         tab, layout = r
         B = timesteps.numel()
         return {k: tab[0, off:off + B * n].view(B, n) for k, (off, n) in layout.items()}
+
+    def run_layer(self, qm, x):
+        """ONE frozen QuantModule on its input in the reference's layout (NCHW, [B, C, T] for kernel-1 Conv1d, [..., C]
+        for Linear) -> output in the reference's layout: the quantise + integer contraction + epilogue the network
+        walk issues for that layer, on their own (per-layer parity tests and diagnostics; quant_layer.py:406-437)."""
+        import torch.nn.functional as F
+        L = self.L(qm)
+        with torch.no_grad():
+            x = x.float()
+            if qm.fwd_func is F.linear:
+                x2 = x.reshape(-1, x.shape[-1]).contiguous()
+                return self.lin(qm, x2).reshape(tuple(x.shape[:-1]) + (L.N,))
+            if qm.fwd_func is F.conv1d:
+                B, C, T = x.shape
+                x2 = x.permute(0, 2, 1).reshape(B * T, C).contiguous()
+                return self.lin(qm, x2).reshape(B, T, L.N).permute(0, 2, 1).contiguous()
+            xh = ops.nchw_to_nhwc(x.contiguous())
+            B, H, W, C = xh.shape
+            if L.mode == "f32":
+                o = ops.conv3x3_f32_smalln(xh, L.w_f32.reshape(L.N, 3, 3, C).contiguous(), L.bias)
+            elif L.kind == "dense":
+                o = self.lin(qm, xh.reshape(-1, C)).reshape(B, H, W, L.N)
+            elif C % 16 != 0:
+                o = self.first_conv(qm, xh)
+            else:
+                if L.stride == 2 and L.pad == 0:
+                    # the DDPM downsample pads (0,1,0,1) outside the module (diffusion.py:49-51): the module input is the
+                    # padded tensor, the engine folds the padding into the gather
+                    xh = xh[:, :H - 1, :W - 1].contiguous()
+                    H, W = H - 1, W - 1
+                a = self._quant(L, xh.reshape(-1, C)).reshape(B, H, W, C)
+                o = self.conv(qm, a, B, H, W)
+            return ops.nhwc_to_nchw(o.contiguous())
 
     # ------------------------------------------------------------------ attention core (K6)
     def _aq(self, q):
@@ -653,6 +689,60 @@ class Engine:
                     out[id(blk)] = self._one_token_branch(blk, torch.zeros(B, C, device=ctx.device), ctx, B)
         return out
 
+    def ldm_tblock(self, blk, t, B, N, C, context, fanout=None, out_qp=None):
+        """One QuantBasicTransformerBlock (quant_block.py:238-297) on the token rows t [B*N][C] -> (tokens, emitted).
+        fanout: the precomputed cross-attention vectors [2B][C] of a guidance pair whose shared half is t -- the block
+        output then has 2B*N rows.  out_qp: the consumer of the block output is one activation quantizer (proj_out of the
+        SpatialTransformer): ff.net.2 emits that int8 operand instead of fp32 tokens (emitted = True)."""
+        a1 = blk.attn1
+        oq, ok, ov = self.ln(blk.norm1, t, (a1.to_q, a1.to_k, a1.to_v))
+        t = self.ldm_cross_attn(a1, oq, (ok, ov), B, N, N, residual=t)
+        a2 = blk.attn2
+        pend = None                  # (vector per image, rows): a broadcast add folded into norm3 below
+        if fanout is not None:
+            # the pair fans out here: t (one half) + the per-image cross-attention vectors of both halves
+            pend = (fanout, 2 * B * N)
+            B *= 2
+        elif context is not None and context.shape[1] == 1 and self.one_token_context:
+            # One-token context (class-conditional LDM): softmax over a single key is exactly 1 for every query,
+            # so the branch's output is ONE vector per image.  It is computed for one query row per image through
+            # the same kernels (q/k/v projections, products, quantisers, to_out -- the same codes) and broadcast:
+            # bit-identical to evaluating it for all N tokens, at 1/N of the work.  Being independent of the
+            # query it is also independent of x and t: a sampling loop computes it once per context
+            # (context_branches) and hands it in through `self.ctx_r`.
+            r = self.ctx_r.get(id(blk)) if self.ctx_r is not None else None
+            if r is None:
+                r = self._one_token_branch(blk, t.reshape(B, N, C)[:, 0].contiguous(), context, B)
+            pend = (r, B * N)
+        else:
+            (oq,) = self.ln(blk.norm2, t, (a2.to_q,))
+            if context is None:
+                ok, ov = self.ln(blk.norm2, t, (a2.to_k, a2.to_v))
+                nk = N
+            else:
+                c2 = context.reshape(-1, context.shape[-1]).contiguous()
+                ok, ov = self._quant(self.L(a2.to_k), c2), self._quant(self.L(a2.to_v), c2)
+                nk = context.shape[1]
+            t = self.ldm_cross_attn(a2, oq, (ok, ov), B, N, nk, residual=t)
+        ff0, ff2 = blk.ff.net[0].proj, blk.ff.net[2]
+        if pend is not None and self.fuse_rowadd_ln and C % 4 == 0:
+            # t + r per image and norm3 of the sum in one pass (the sum is the updated residual stream)
+            t, (of,) = self.ln_radd(blk.norm3, t, pend[0], N, (ff0,), pend[1])
+        else:
+            if pend is not None:
+                t = ops.add_rowbcast(t, pend[0], N, rows=pend[1])
+            (of,) = self.ln(blk.norm3, t, (ff0,))
+        L0, L2 = self.L(ff0), self.L(ff2)
+        if getattr(L0, "geglu_interleaved", False):
+            g = self._gemm(L0, of, B * N, out_mode=3, oqp=L2.qp)
+        else:
+            g = ops.geglu_quant_i8(self._gemm(L0, of, B * N), L2.qp)
+        if out_qp is not None and L2.mode == "i8" and len(L2.segs) == 1:
+            # the block output only feeds proj_out's activation quantizer: ff.net.2 emits that operand
+            # (residual added in the epilogue), no fp32 token tensor, no separate quantise pass
+            return self._gemm(L2, g, B * N, residual=t, out_mode=2, oqp=out_qp), True
+        return self._gemm(L2, g, B * N, residual=t), False
+
     def ldm_transformer(self, st, x, context, pair_half=False):
         """pair_half: x is the shared half of a guidance pair.  Everything up to and including the first block's
         self-attention is context-independent; the halves part where the (precomputed) cross-attention vectors are added,
@@ -665,59 +755,18 @@ class Engine:
         N = H * W
         _, (a,) = self.gn(st.norm, x, False, (st.proj_in,))
         t = self._gemm(self.L(st.proj_in), a.reshape(B * N, C), B * N)            # tokens = NHWC rows
+        Lp = self.L(st.proj_out)
+        emitted = False
         for blk in st.transformer_blocks:
-            a1 = blk.attn1
-            oq, ok, ov = self.ln(blk.norm1, t, (a1.to_q, a1.to_k, a1.to_v))
-            t = self.ldm_cross_attn(a1, oq, (ok, ov), B, N, N, residual=t)
-            a2 = blk.attn2
-            pend = None                  # (vector per image, rows): a broadcast add folded into norm3 below
-            if half_mode and blk is blocks0:
-                # the pair fans out here: t (one half) + the per-image cross-attention vectors of both halves
-                pend = (self.ctx_r[id(blk)], 2 * B * N)
+            fan = self.ctx_r[id(blk)] if (half_mode and blk is blocks0) else None
+            last = blk is st.transformer_blocks[-1]
+            t, emitted = self.ldm_tblock(blk, t, B, N, C, context, fanout=fan,
+                                         out_qp=Lp.qp if (last and Lp.mode == "i8" and not Lp.split) else None)
+            if fan is not None:
                 x = torch.cat([x, x])
                 B *= 2
-            elif context is not None and context.shape[1] == 1 and self.one_token_context:
-                # One-token context (class-conditional LDM): softmax over a single key is exactly 1 for every query,
-                # so the branch's output is ONE vector per image.  It is computed for one query row per image through
-                # the same kernels (q/k/v projections, products, quantisers, to_out -- the same codes) and broadcast:
-                # bit-identical to evaluating it for all N tokens, at 1/N of the work.  Being independent of the
-                # query it is also independent of x and t: a sampling loop computes it once per context
-                # (context_branches) and hands it in through `self.ctx_r`.
-                r = self.ctx_r.get(id(blk)) if self.ctx_r is not None else None
-                if r is None:
-                    r = self._one_token_branch(blk, t.reshape(B, N, C)[:, 0].contiguous(), context, B)
-                pend = (r, B * N)
-            else:
-                (oq,) = self.ln(blk.norm2, t, (a2.to_q,))
-                if context is None:
-                    ok, ov = self.ln(blk.norm2, t, (a2.to_k, a2.to_v))
-                    nk = N
-                else:
-                    c2 = context.reshape(-1, context.shape[-1]).contiguous()
-                    ok, ov = self._quant(self.L(a2.to_k), c2), self._quant(self.L(a2.to_v), c2)
-                    nk = context.shape[1]
-                t = self.ldm_cross_attn(a2, oq, (ok, ov), B, N, nk, residual=t)
-            ff0, ff2 = blk.ff.net[0].proj, blk.ff.net[2]
-            if pend is not None and self.fuse_rowadd_ln and C % 4 == 0:
-                # t + r per image and norm3 of the sum in one pass (the sum is the updated residual stream)
-                t, (of,) = self.ln_radd(blk.norm3, t, pend[0], N, (ff0,), pend[1])
-            else:
-                if pend is not None:
-                    t = ops.add_rowbcast(t, pend[0], N, rows=pend[1])
-                (of,) = self.ln(blk.norm3, t, (ff0,))
-            L0, L2 = self.L(ff0), self.L(ff2)
-            if getattr(L0, "geglu_interleaved", False):
-                g = self._gemm(L0, of, B * N, out_mode=3, oqp=L2.qp)
-            else:
-                g = ops.geglu_quant_i8(self._gemm(L0, of, B * N), L2.qp)
-            Lp = self.L(st.proj_out)
-            last = blk is st.transformer_blocks[-1]
-            if last and Lp.mode == "i8" and not Lp.split and L2.mode == "i8" and len(L2.segs) == 1:
-                # the block output only feeds proj_out's activation quantizer: ff.net.2 emits that operand
-                # (residual added in the epilogue), no fp32 token tensor, no separate quantise pass
-                tq = self._gemm(L2, g, B * N, residual=t, out_mode=2, oqp=Lp.qp)
-                return self.lin(st.proj_out, None, residual=x.reshape(B * N, C), pre=tq).reshape(B, H, W, C)
-            t = self._gemm(L2, g, B * N, residual=t)
+        if emitted:
+            return self.lin(st.proj_out, None, residual=x.reshape(B * N, C), pre=t).reshape(B, H, W, C)
         return self.lin(st.proj_out, t, residual=x.reshape(B * N, C)).reshape(B, H, W, C)
 
     def ldm_legacy_attn(self, ab, x):

@@ -8,6 +8,7 @@ import torch
 from . import lib
 
 _ws = {}
+_ws_retired = []
 
 
 def _stream():
@@ -35,6 +36,11 @@ def workspace(device, floats=None):
     key = (device.index, "r" if floats is None else "x")
     w = _ws.get(key)
     if w is None or w.numel() < n:
+        if w is not None:
+            # a captured HIP graph may have this buffer's address baked into its launches (GroupNorm partials): the
+            # outgrown buffer stays alive for the life of the process instead of going back to the allocator, where a
+            # replay of such a graph would scribble over whatever tensor owned the memory next
+            _ws_retired.append(w)
         w = torch.empty(max(n, 1), dtype=torch.float32, device=device)
         _ws[key] = w
     return w

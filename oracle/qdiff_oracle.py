@@ -931,7 +931,9 @@ class OUNet(_Net):
     def __init__(self, sd, wq, aq, sm_abit=8, *, in_channels, out_channels, model_channels, attention_resolutions,
                  num_res_blocks, channel_mult, num_heads=-1, num_head_channels=-1, use_spatial_transformer=False,
                  context_dim=None, use_scale_shift_norm=False, resblock_updown=False, image_size=None,
-                 transformer_depth=1):
+                 transformer_depth=1, legacy=True):
+        # legacy: with a spatial transformer and num_head_channels == -1 both settings give dim_head = ch // num_heads
+        # (openaimodel.py:578-585)
         B = _Builder(sd, wq, aq, sm_abit)
         mc = self.mc = int(model_channels)
         self.split_shortcut = False
@@ -1047,18 +1049,28 @@ class OUNet(_Net):
 # ======================================================================================
 # Scale-init drivers                               qdiff/set_quantize_params.py:9-71
 # ======================================================================================
-def set_weight_quantize_params(net, cali, batch_size=32):
+def cfg_double(batch):
+    """(x, t, index, cond, uncond, ...) -> the classifier-free-guidance batch [x, x], [t, t], [uncond, cond] that the
+    calibration forward of the conditional samplers evaluates (ddim_control.py:221-228, plms.py:213-220)."""
+    return [torch.cat([batch[0]] * 2), torch.cat([batch[1]] * 2), torch.cat([batch[4], batch[3]])]
+
+
+def set_weight_quantize_params(net, cali, batch_size=32, transform=None):
+    """transform=cfg_double with batch_size=2: set_weight_quantize_params_Stable / _Conditional
+    (qdiff_control/set_quantize_params_Stable.py:107-145: one guided forward of the first two samples)."""
     net.set_quant_state(True, False)
     for l in net.all_layers():
         l.weight_quantizer.inited = False
     with torch.no_grad():
-        net(*[c[:batch_size] for c in cali])
+        b = [c[:batch_size] for c in cali]
+        net(*(transform(b) if transform else b))
     for q in net.all_quantizers():
         if not q.leaf_param:
             q.inited = True
 
 
-def set_act_quantize_params(net, cali, batch_size=256, all_attention=True):
+def set_act_quantize_params(net, cali, batch_size=256, all_attention=True, transform=None):
+    """transform=cfg_double: the Stable / Conditional drivers (set_quantize_params_Stable.py:12-105)."""
     net.set_quant_state(True, True)
     for q in net.all_quantizers():
         if q.leaf_param:
@@ -1066,7 +1078,8 @@ def set_act_quantize_params(net, cali, batch_size=256, all_attention=True):
     batch_size = min(batch_size, cali[0].size(0))
     with torch.no_grad():
         for i in range(int(cali[0].size(0) / batch_size)):
-            net(*[c[i * batch_size:(i + 1) * batch_size] for c in cali])
+            b = [c[i * batch_size:(i + 1) * batch_size] for c in cali]
+            net(*(transform(b) if transform else b))
     for q in net.all_quantizers():
         q.inited = True
 
@@ -1123,6 +1136,16 @@ def save_inp_oup_data(net, unit, cali, act_quant=True, batch_size=32):
 # a6/a7 — reconstruction loops            block_recon.py:13-232, layer_recon.py:13-129
 # ======================================================================================
 def _prepare_unit(unit, kind, act_quant, recon_w, recon_a):
+    if kind == "attn_layer":
+        # attn_layer_recon.py:44-63: no AdaRound, no layer step sizes -- only q, k, v, w of the QuantAttnBlock
+        a_para, ordered = [], list(unit.extra_quantizers())
+        if act_quant:
+            for q in ordered:
+                q.delta = q.delta.detach().clone().requires_grad_(True)
+                if recon_a:
+                    a_para.append(q.delta)
+                    q.is_training = True
+        return [], [], a_para, ordered
     layers = [unit] if kind == "layer" else unit.layers()
     w_para, a_para = [], []
     for l in layers:
@@ -1161,7 +1184,9 @@ def _prepare_unit(unit, kind, act_quant, recon_w, recon_a):
 def reconstruct_unit(net, unit, kind, cali, batch_size=32, iters=20000, act_quant=False, lr_a=4e-5, lr_w=1e-2,
                      p=2.0, input_prob=1.0, recon_w=False, recon_a=False, add_loss=0.0, cache_batch=32,
                      rand_fn=None, trace=None):
-    """block_reconstruction / layer_reconstruction with asym=True, opt_mode='mse', round loss 'none'."""
+    """block_reconstruction / layer_reconstruction with asym=True, opt_mode='mse', round loss 'none';
+    kind 'attn_layer' = AttnBlock_layer_reconstruction (attn_layer_recon.py:13-133: block output loss only, the
+    attention step sizes the only trainables, cur_inp = cur_sym when input_prob == 1 as in the block loop)."""
     unit.set_quant_state(True, act_quant)
     layers, w_para, a_para, aqs = _prepare_unit(unit, kind, act_quant, recon_w, recon_a)
     w_opt = OAdam(w_para, lr_w, iters) if w_para else None
@@ -1177,8 +1202,8 @@ def reconstruct_unit(net, unit, kind, cali, batch_size=32, iters=20000, act_quan
         if input_prob < 1.0:
             u = rand_fn(cur_inp) if rand_fn is not None else torch.rand_like(cur_inp)
             cur_inp = torch.where(u < input_prob, cur_inp, cur_sym)
-        elif kind == "block":
-            cur_inp = cur_sym          # block_recon.py:144-145 (the layer loop keeps cur_inp, layer_recon.py:106-107)
+        elif kind in ("block", "attn_layer"):
+            cur_inp = cur_sym          # block_recon.py:144-145, attn_layer_recon.py:101-102 (the layer loop keeps cur_inp, layer_recon.py:106-107)
         for o in (w_opt, a_opt):
             if o:
                 o.zero_grad()

@@ -284,11 +284,12 @@ def sd_of(model):
     return {"sd/" + k: v for k, v in model.state_dict().items()}
 
 
-def g13_cifar_unet():
+def g13_cifar_unet(wbits=4, fname="g13_cifar_unet", seed=1301):
     """G13a: tiny DDPM UNet (ddim/models/diffusion.py:199-392) FP and fake-quant forward after
-    the reference's own scale-init drivers (set_quantize_params.py:9-71), split shortcut on."""
-    seed_everything(1301)
-    g = torch.Generator().manual_seed(1301)
+    the reference's own scale-init drivers (set_quantize_params.py:9-71), split shortcut on.
+    wbits=8 -> g13_cifar_w8: BASELINE config 1's bit widths (W8A8, sample_diffusion_ddim.py --weight_bit 8)."""
+    seed_everything(seed)
+    g = torch.Generator().manual_seed(seed)
     cfg = cifar_cfg()
     model = DDPMModel(cfg).eval()
     d = sd_of(model)
@@ -298,7 +299,15 @@ def g13_cifar_unet():
     d["x"], d["t"] = x, t
     with torch.no_grad():
         d["out_fp"] = model(x, t)
-    qnn = QuantModel(model, WQ4, AQ8, sm_abit=8)
+    if fname != "g13_cifar_unet":
+        # same seed -> same weights and inputs as g13_cifar_unet: the variant stores only what differs
+        base = np.load(os.path.join(HERE, "g13_cifar_unet.npz"))
+        assert all(np.array_equal(base[k], A(v)) for k, v in d.items() if k.startswith("sd/"))
+        d = {k: v for k, v in d.items() if not k.startswith("sd/")}
+    wq = dict(WQ4)
+    wq["n_bits"] = wbits
+    d["cfg/wbits"] = wbits
+    qnn = QuantModel(model, wq, AQ8, sm_abit=8)
     qnn.eval()
     qnn.set_quant_state(False, False)
     qnn.set_first_last_layer_to_8bit()
@@ -331,7 +340,19 @@ def g13_cifar_unet():
         rb.block_reconstruction, rb.layer_reconstruction = ob, ol
     names = {m: n for n, m in qnn.named_modules()}
     d["units"] = np.array(["%s:%s:%s" % (k, names[m], type(m).__name__) for k, m in rec])
-    save("g13_cifar_unet", d)
+    # the --layer_recon walk (recon_layer_Qmodel.py:20-120) on the same model: unit order only
+    import qdiff.recon_layer_Qmodel  # noqa: F401
+    rl = sys.modules['qdiff.recon_layer_Qmodel']
+    lrec = []
+    ol, oa = rl.layer_reconstruction, rl.AttnBlock_layer_reconstruction
+    rl.layer_reconstruction = lambda m, lay, **k: lrec.append(("layer", lay))
+    rl.AttnBlock_layer_reconstruction = lambda m, blk, **k: lrec.append(("attn", blk))
+    try:
+        rl.recon_layer_Qmodel(None, qnn, cali, {}).recon()
+    finally:
+        rl.layer_reconstruction, rl.AttnBlock_layer_reconstruction = ol, oa
+    d["layer_units"] = np.array(["%s:%s" % (k, names[m]) for k, m in lrec])
+    save(fname, d)
     return model, qnn, cali
 
 
@@ -769,11 +790,229 @@ def g15_decoder():
     save("g15_decoder", d)
 
 
+def g7b_blocks():
+    """G7b: the Stable-Diffusion attention shapes at block level (quant_block.py:204-297,168-192; attention.py:218-287):
+    8 heads, a 77-token context; an 8-head legacy AttentionBlock; a ResBlock whose skip convolution is split over the
+    halves of a skip concatenation (quant_block.py:72-84)."""
+    from ldm.modules.attention import SpatialTransformer
+    seed_everything(7070)
+    g = torch.Generator().manual_seed(7070)
+    d = {}
+    st = SpatialTransformer(64, 8, 8, depth=1, context_dim=48).eval()
+    tr8 = BasicTransformerBlock(64, 8, 8, context_dim=48, checkpoint=False).eval()
+    ab8 = AttentionBlock(64, num_heads=8).eval()
+    res_split = ResBlock(64, 64, 0.0, out_channels=32).eval()
+    holder = nn.Module()
+    holder.in_channels = 3
+    holder.st, holder.tr8, holder.ab8, holder.res_split = st, tr8, ab8, res_split
+    reinit_zero_modules(holder, g)
+    for k, v in holder.state_dict().items():
+        d["sd/" + k] = v
+    qh = QuantModel(holder, WQ4, AQ8, sm_abit=8)
+    qh.set_grad_ckpt(False)
+    x = torch.randn(2, 64, 4, 4, generator=g)
+    xc = torch.randn(2, 64, 4, 4, generator=g) * torch.cat([torch.ones(32), 2.5 * torch.ones(32)]).view(1, 64, 1, 1)
+    emb = torch.randn(2, 64, generator=g)
+    xs = torch.randn(2, 16, 64, generator=g)
+    ctx77 = torch.randn(2, 77, 48, generator=g)
+    ctx1 = torch.randn(2, 1, 48, generator=g)
+    d["x"], d["xc"], d["emb"], d["xs"], d["ctx77"], d["ctx1"] = x, xc, emb, xs, ctx77, ctx1
+    m = qh.model
+    assert isinstance(m.st.transformer_blocks[0], QuantBasicTransformerBlock) and isinstance(m.res_split, QuantResBlock)
+    with torch.no_grad():
+        d["st_fp"] = m.st(x, ctx77)
+        d["tr8_fp77"], d["tr8_fp1"] = m.tr8(xs, ctx77), m.tr8(xs, ctx1)
+        d["ab8_fp"] = m.ab8(x)
+        d["res_split_fp"] = m.res_split(xc, emb, split=32)
+        qh.set_quant_state(True, True)
+        m.st(x, ctx77), m.tr8(xs, ctx77), m.ab8(x), m.res_split(xc, emb, split=32)      # initialises every quantizer
+        for mm in qh.modules():
+            if isinstance(mm, UniformAffineQuantizer):
+                mm.set_inited(True)
+        d["st_q"] = m.st(x, ctx77)
+        d["tr8_q77"], d["tr8_q1"] = m.tr8(xs, ctx77), m.tr8(xs, ctx1)
+        d["ab8_q"] = m.ab8(x)
+        d["res_split_q"] = m.res_split(xc, emb, split=32)
+    d.update(qparams_of(qh))
+    save("g7b_blocks", d)
+
+
+SD_KW = dict(image_size=8, in_channels=4, out_channels=4, model_channels=64, attention_resolutions=[1, 2],
+             num_res_blocks=1, channel_mult=[1, 2], num_heads=8, use_spatial_transformer=True, transformer_depth=1,
+             context_dim=24, legacy=False)
+
+
+def g13_ldm_sd():
+    """G13d: BASELINE config 5 in miniature -- a Stable-Diffusion-shaped UNetModel (v1-inference.yaml unet_config family:
+    8 heads, 77-token context, transformer_depth 1, legacy False, NO split: sample_txt2img.py:183-184 sets an unused
+    attribute) calibrated by the reference's own `set_{weight,act}_quantize_params_Stable` through its PLMSSampler
+    (qdiff_control/set_quantize_params_Stable.py:12-145 with args.plms, plms.py:99-115,259-260), then FP / weight-quant /
+    fake-quant forwards of the classifier-free-guidance batch.  Weights are formula weights (_weights.py), not stored."""
+    from _weights import formula_state_dict
+    from qdiff_control.set_quantize_params_Stable import (set_act_quantize_params_Stable,
+                                                          set_weight_quantize_params_Stable)
+    seed_everything(1305)
+    g = torch.Generator().manual_seed(1305)
+    model = UNetModel(**SD_KW).eval()
+    sd = formula_state_dict([(k, v.shape) for k, v in model.state_dict().items()], 1305)
+    model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    d = {}
+    for k, v in SD_KW.items():
+        d["cfg/" + k] = np.asarray(v)
+    d["weights_seed"] = np.int64(1305)
+    N, S = 4, 8
+    b = make_beta_schedule("linear", 1000, linear_start=0.00085, linear_end=0.012)
+    ac = np.cumprod(1.0 - b, axis=0)
+    ts = make_ddim_timesteps("uniform", S, 1000, verbose=False)
+    index = torch.tensor([7, 5, 2, 0])
+    x = torch.randn(N, 4, 8, 8, generator=g)
+    t = torch.tensor(ts[index.numpy()]).long()
+    t_next = torch.tensor(ts[np.maximum(index.numpy() - 1, 0)]).long()
+    cond = torch.randn(N, 77, 24, generator=g)
+    uncond = torch.randn(1, 77, 24, generator=g).expand(N, 77, 24).contiguous()
+    cali = (x, t, index, cond, uncond, t_next)
+    d["x"], d["t"], d["index"], d["cond"], d["uncond"], d["t_next"] = cali
+
+    qnn = QuantModel(model, WQ4, AQ8, sm_abit=8, act_quant_mode="qdiff")
+    qnn.eval()
+    qnn.set_quant_state(False, False)
+    qnn.set_first_last_layer_to_8bit()
+    qnn.disable_network_output_quantization()
+    qnn.set_grad_ckpt(False)
+
+    class Wrap(nn.Module):
+        def __init__(self, net):
+            super().__init__()
+            self.diffusion_model = net
+
+    class FakeLD(nn.Module):
+        """stand-in for LatentDiffusion (ddpm.py:895-997 contract): schedules, apply_model, conditioning"""
+
+        def __init__(self, net):
+            super().__init__()
+            self.model = Wrap(net)
+            self.num_timesteps = 1000
+            self.betas = torch.tensor(b, dtype=torch.float32)
+            self.alphas_cumprod = torch.tensor(ac, dtype=torch.float32)
+            self.alphas_cumprod_prev = torch.tensor(np.append(1.0, ac[:-1]), dtype=torch.float32)
+            self.device = torch.device("cpu")
+
+        def apply_model(self, x_, t_, c_):
+            return self.model.diffusion_model(x_, t_, context=c_)
+
+        def get_learned_conditioning(self, prompts):
+            return torch.zeros(len(prompts), 77, 24)          # CLIP stand-in: the PLMS calibration forward reads cali_data
+
+    ld = FakeLD(qnn)
+    args = SimpleNamespace(custom_steps=S, scale=7.5, ddim_eta=0.0, plms=True, C=4, H=64, W=64, f=8,
+                           list_prompts=["a", "b", "c", "d"])
+    for k in ("custom_steps", "scale", "ddim_eta", "C", "H", "W", "f"):
+        d["args/" + k] = np.asarray(getattr(args, k))
+    set_weight_quantize_params_Stable(ld, cali, args)
+    set_act_quantize_params_Stable(ld, cali, args, batch_size=2)
+    x8, t8, c8 = torch.cat([x] * 2), torch.cat([t] * 2), torch.cat([uncond, cond])
+    with torch.no_grad():
+        qnn.set_quant_state(False, False)
+        d["out_fp"] = qnn(x8, t8, c8)
+        qnn.set_quant_state(True, False)
+        d["out_wq"] = qnn(x8, t8, c8)
+        qnn.set_quant_state(True, True)
+        d["out_q"] = qnn(x8, t8, c8)
+    d.update(qparams_of(qnn))
+    n_split = sum(1 for m in qnn.modules() if isinstance(m, QuantModule) and m.split != 0)
+    d["n_split_layers"] = np.int64(n_split)
+    import qdiff_control.recon_block_Qmodel  # noqa: F401
+    rbc = sys.modules['qdiff_control.recon_block_Qmodel']
+    rec = []
+    ob, ol = rbc.block_reconstruction, rbc.layer_reconstruction
+    rbc.block_reconstruction = lambda m, blk, **k: rec.append(("block", blk))
+    rbc.layer_reconstruction = lambda m, lay, **k: rec.append(("layer", lay))
+    try:
+        rbc.recon_block_Qmodel(None, qnn, cali, {}).recon()
+    finally:
+        rbc.block_reconstruction, rbc.layer_reconstruction = ob, ol
+    names = {m: n for n, m in qnn.named_modules()}
+    d["units"] = np.array(["%s:%s:%s" % (k, names[m], type(m).__name__) for k, m in rec])
+    save("g13_ldm_sd", d)
+
+
+def g16_layer_recon():
+    """G16: the --layer_recon mode on the 2-block toy model: the reference's recon_layer_Qmodel walk
+    (recon_layer_Qmodel.py:20-120: every QuantModule on its own, a QuantAttnBlock as q, k, v, its four attention step
+    sizes alone via AttnBlock_layer_reconstruction, attn_layer_recon.py:13-133, then proj_out) with prob = input_prob = 1
+    (no device RNG), 12 iterations per unit: unit order, alpha / delta after every Adam step, final state."""
+    import qdiff.recon_layer_Qmodel  # noqa: F401
+    rl = sys.modules['qdiff.recon_layer_Qmodel']
+    seed_everything(1616)
+    g = torch.Generator().manual_seed(1616)
+    net = _ToyNet().eval()
+    d = {"sd/" + k: v for k, v in net.state_dict().items()}
+    aq = dict(AQ8)
+    aq["prob"] = 1.0
+    qnn = QuantModel(net, WQ4, aq, sm_abit=8)
+    qnn.eval()
+    N = 64
+    x = torch.randn(N, 3, 8, 8, generator=g)
+    t = torch.randint(0, 1000, (N,), generator=g).float()
+    d["x"], d["t"] = x, t
+    cali = (x, t)
+    set_weight_quantize_params(qnn, cali)
+    set_act_quantize_params(qnn, cali, batch_size=32)
+    for k, v in qparams_of(qnn).items():
+        d["init/" + k] = v
+    kwargs = dict(cali_data=cali, iters=12, act_quant=True, asym=True, opt_mode="mse", lr_a=1e-4, lr_w=5e-2,
+                  p=2.0, weight=0.0001, b_range=(20, 2), warmup=0.2, batch_size=16, input_prob=1.0,
+                  add_loss=0.8, recon_w=True, recon_a=True, keep_gpu=True)
+    names = {m: n for n, m in qnn.named_modules()}
+    traj, order, cur = {}, [], {"name": None}
+    orig_step = torch.optim.Adam.step
+
+    def step(self, *a, **k):
+        r = orig_step(self, *a, **k)
+        ps = [p for gr in self.param_groups for p in gr["params"]]
+        key = "%s/%s" % (cur["name"], "a" if ps[0].numel() == 1 else "w")
+        traj.setdefault(key, []).append(torch.cat([p.detach().flatten() for p in ps]).clone())
+        return r
+
+    ol, oa = rl.layer_reconstruction, rl.AttnBlock_layer_reconstruction
+
+    def wrap(kind, fn):
+        def run(model, unit, **kw):
+            cur["name"] = "%s:%s" % (kind, names[unit])
+            order.append(cur["name"])
+            return fn(model, unit, **kw)
+        return run
+
+    torch.optim.Adam.step = step
+    rl.layer_reconstruction = wrap("layer", ol)
+    rl.AttnBlock_layer_reconstruction = wrap("attn", oa)
+    try:
+        random.seed(1616)
+        rl.recon_layer_Qmodel(None, qnn, cali, kwargs).recon()
+    finally:
+        torch.optim.Adam.step = orig_step
+        rl.layer_reconstruction, rl.AttnBlock_layer_reconstruction = ol, oa
+    d["order"] = np.array(order)
+    for k, v in traj.items():
+        d["traj/" + k] = torch.stack(v)
+    for k, v in qparams_of(qnn).items():
+        d["final/" + k] = v
+    for name, m in qnn.named_modules():
+        if isinstance(m, AdaRoundQuantizer):
+            d["final/alpha/" + name] = m.alpha
+    qnn.set_quant_state(True, True)
+    with torch.no_grad():
+        d["final/out_q"] = qnn(x[:8], t[:8])
+    d["block_count"] = np.int64(qnn.block_count)
+    save("g16_layer_recon", d)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     jobs = dict(g1=g1_weight_init, g2=g2_act_init, g3=g3_uaq_forward, g4=g4_adaround, g5=g5_loss,
                 g6=g6_quant_module, g7=g7_blocks, g8=g8_g12_recon, g9=g9_tdac, g10=g10_steps,
-                g13c=g13_cifar_unet, g13i=lambda: g13_ldm_unet("imagenet"), g13h=lambda: g13_ldm_unet("church"), g14=g14_plms, g15=g15_decoder)
+                g13c=g13_cifar_unet, g13i=lambda: g13_ldm_unet("imagenet"), g13h=lambda: g13_ldm_unet("church"), g14=g14_plms, g15=g15_decoder,
+                g7b=g7b_blocks, g13w8=lambda: g13_cifar_unet(8, "g13_cifar_w8", 1301), g13sd=g13_ldm_sd, g16=g16_layer_recon)
     for k, fn in jobs.items():
         if not only or k in only:
             print("==", k)

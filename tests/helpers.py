@@ -37,6 +37,38 @@ def build_ldm(g):
     return m.eval()
 
 
+def ldm_state_dict_shapes(g):
+    """(key, shape) of every state_dict entry of the fixture's UNetModel config, in the product's own classes (the
+    names and shapes are those of the reference's, which is what makes its fixtures loadable)."""
+    from edadm.nets.ldm_unet import UNetModel
+    kw = {}
+    for k in g.files:
+        if k.startswith("cfg/"):
+            v = g[k]
+            kw[k[4:]] = v.tolist() if v.ndim else v.item()
+    with torch.device("meta"):
+        m = UNetModel(**kw)
+    return [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+
+
+def build_ldm_formula(g):
+    """UNetModel of a fixture whose weights are formula weights (tests/golden/_weights.py), not stored."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from _weights import formula_state_dict
+    from edadm.nets.ldm_unet import UNetModel
+    kw = {}
+    for k in g.files:
+        if k.startswith("cfg/"):
+            v = g[k]
+            kw[k[4:]] = v.tolist() if v.ndim else v.item()
+    m = UNetModel(**kw)
+    sd = formula_state_dict([(k, tuple(v.shape)) for k, v in m.state_dict().items()], int(g["weights_seed"]))
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    return m.eval()
+
+
 def quantize_like_reference(model, g, kind, split=True):
     """QuantModel wrapped and configured exactly as the fixture generator did, with the
     reference's own deltas / zero points loaded."""

@@ -119,3 +119,56 @@ def test_tdac_allocation_matches_reference(golden):
             np.testing.assert_array_equal(dense.numpy(), g[key + "/dense_num"])
             np.testing.assert_allclose(cd.numpy(), g[key + "/cos_dis"], rtol=1e-5)
             np.testing.assert_array_equal(t_num.numpy(), g[key + "/t_num_" + variant])
+
+
+def test_layer_recon_walk_order(golden):
+    """--layer_recon: recon_layer_Qmodel takes the blocks apart exactly as the reference does
+    (recon_layer_Qmodel.py:20-120; `layer_units` captured by running the reference's walk with stubbed unit functions)."""
+    import qdiff  # noqa: F401
+    rl = sys.modules['qdiff.recon_layer_Qmodel']
+    g = golden("g13_cifar_unet")
+    qnn = _wrap(g, "cifar")
+    rec = []
+    ol, oa = rl.layer_reconstruction, rl.AttnBlock_layer_reconstruction
+    rl.layer_reconstruction = lambda m, lay, **k: rec.append(("layer", lay))
+    rl.AttnBlock_layer_reconstruction = lambda m, blk, **k: rec.append(("attn", blk))
+    try:
+        rl.recon_layer_Qmodel(None, qnn, None, {}).recon()
+    finally:
+        rl.layer_reconstruction, rl.AttnBlock_layer_reconstruction = ol, oa
+    names = {m: n for n, m in qnn.named_modules()}
+    assert ["%s:%s" % (k, names[m]) for k, m in rec] == [str(u) for u in g["layer_units"]]
+
+
+def test_sd_shaped_unit_order_conditional_walk(golden):
+    """BASELINE config 5: the conditional walk (qdiff_control/recon_block_Qmodel.py:10-43) over the SD-shaped UNet."""
+    from helpers import build_ldm_formula
+    from qdiff import QuantModel
+    import qdiff_control  # noqa: F401
+    rb = sys.modules['qdiff_control.recon_block_Qmodel']
+    g = golden("g13_ldm_sd")
+    qnn = QuantModel(build_ldm_formula(g), WQ4, AQ8, sm_abit=8)
+    rec = []
+    ob, ol = rb.block_reconstruction, rb.layer_reconstruction
+    rb.block_reconstruction = lambda m, blk, **k: rec.append(("block", blk))
+    rb.layer_reconstruction = lambda m, lay, **k: rec.append(("layer", lay))
+    try:
+        rb.recon_block_Qmodel(None, qnn, None, {}).recon()
+    finally:
+        rb.block_reconstruction, rb.layer_reconstruction = ob, ol
+    names = {m: n for n, m in qnn.named_modules()}
+    assert ["%s:%s:%s" % (k, names[m], type(m).__name__) for k, m in rec] == [str(u) for u in g["units"]]
+
+
+def test_attention_step_sizes_trained_by_the_right_walk(golden):
+    """Which attention step sizes join the trainables: qdiff/block_recon.py:66-93 knows QuantAttentionBlock and
+    QuantAttnBlock, qdiff_control/block_recon.py:68-110 QuantAttnBlock and QuantBasicTransformerBlock."""
+    from edadm.recon import _attention_quantizers
+    from qdiff.quant_block import QuantBasicTransformerBlock, QuantAttnBlock
+    qnn = _wrap(golden("g13_ldm_imagenet"), "imagenet")
+    tb = [m for m in qnn.modules() if isinstance(m, QuantBasicTransformerBlock)]
+    assert tb
+    assert len(_attention_quantizers(tb[0], control=True)) == 8 and _attention_quantizers(tb[0], control=False) == []
+    qc = _wrap(golden("g13_cifar_unet"), "cifar")
+    ab = [m for m in qc.modules() if isinstance(m, QuantAttnBlock)]
+    assert len(_attention_quantizers(ab[0], control=True)) == 4 and len(_attention_quantizers(ab[0], control=False)) == 4
