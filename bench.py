@@ -257,14 +257,35 @@ def main():
     ap.add_argument("--calib-iters", type=int, default=None)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: start N ranks (one process per GPU) through torch.distributed.run as a
+        # CHILD process and hand its output through.  Nothing in this process has touched the GPU (an exec or a
+        # fork after HIP initialisation is not allowed on this pool).
+        import socket
+        import subprocess
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(args.gpus, 1):
+        raise SystemExit("bench.py --gpus %d launched with WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    ranks_seen = 1
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+        assert dist.get_world_size() == args.gpus
+        seen = torch.ones(1, device=dev)
+        dist.all_reduce(seen)                                  # RCCL over xGMI: every rank contributes a 1
+        ranks_seen = int(seen.item())
+        assert ranks_seen == world, (ranks_seen, world)
 
     from edadm import lib
     lib.load()                                                # fail loudly if the HIP library is missing
@@ -288,9 +309,12 @@ def main():
     eng = qnn.freeze()
     B = args.batch
     loop = DDIMLoop(eng, (3, 64, 64), B, steps=20, eta=0.0, scale=3.0, context_shape=(1, 512), device=dev)
-    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    # a batch is a pure function of (seed, global batch index) (edadm/sample_driver.py): rank r makes the batches
+    # {i : i mod world = r} of the one global sequence, so the union over ranks is the same images whatever N is
+    from edadm.sample_driver import batch_noise, batch_generator
     n_total = args.steps + args.warmup
-    noise = [torch.randn(B, 3, 64, 64, generator=gen, device=dev) for _ in range(n_total)]
+    noise = [batch_noise(1234, k * world + rank, (B, 3, 64, 64), dev) for k in range(n_total)]
+    gen = batch_generator(1234, 10 ** 9, dev)                  # the class embeddings: shared by all ranks
     cond = torch.randn(B, 1, 512, generator=gen, device=dev)
     uncond = torch.randn(1, 1, 512, generator=gen, device=dev).expand(B, 1, 512).contiguous()
 
@@ -363,7 +387,7 @@ def main():
         achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12
         line = {
             "metric": "images/sec W4A8 LDM-4 ImageNet 256x256 sampling (20 DDIM steps, CFG 3.0)",
-            "value": images / elapsed, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "value": images / elapsed, "unit": "images/sec", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int8 (i8 MFMA, i32 accumulate; fp32 epilogues)",
             "data": "synthetic",

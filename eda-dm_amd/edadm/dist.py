@@ -53,8 +53,13 @@ def gather_rows(local, n_batches, group=None):
         slot[j * rows:(j + 1) * rows].copy_(local[i])
     if len(mine) < per:
         slot[len(mine) * rows:].zero_()                       # the padding of the last block travels too
-    if dist.get_backend(group) == "gloo":                     # CPU tests: gloo has no in-place flat all-gather
-        dist.all_gather([out[r * per * rows:(r + 1) * per * rows] for r in range(size)], slot.clone(), group=group)
+    if dist.get_backend(group) == "gloo":
+        # CPU tests, and the 2-processes-on-one-GPU test (RCCL refuses two ranks per device): gloo gathers host tensors
+        parts = [torch.empty(slot.shape, dtype=slot.dtype) for _ in range(size)]
+        dist.all_gather(parts, slot.detach().cpu(), group=group)
+        for r in range(size):
+            if r != rank:
+                out[r * per * rows:(r + 1) * per * rows].copy_(parts[r])
     else:
         dist.all_gather_into_tensor(out, slot, group=group)
     GATHER_STATS["bytes"] += out.numel() * out.element_size()
@@ -79,5 +84,12 @@ def broadcast_params(tensors, src=0):
     _, size = world()
     if size == 1:
         return
+    gloo = dist.get_backend() == "gloo"
     for t in tensors:
-        dist.broadcast(t.data if hasattr(t, "data") else t, src=src)
+        d = t.data if hasattr(t, "data") else t
+        if gloo and d.is_cuda:                      # see gather_rows
+            h = d.detach().cpu()
+            dist.broadcast(h, src=src)
+            d.copy_(h)
+        else:
+            dist.broadcast(d, src=src)

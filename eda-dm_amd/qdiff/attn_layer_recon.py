@@ -33,7 +33,7 @@ def AttnBlock_layer_reconstruction(model, block, cali_data, batch_size: int = 32
     loss_func = LossFunction(block, round_loss='none', weight=weight, max_count=iters, rec_loss=opt_mode,
                              b_range=b_range, decay_start=0, warmup=warmup, p=p)
     _, cached_inps, cached_outs = save_inp_oup_data(model, block, cali_data, asym, act_quant, batch_size=32,
-                                                    input_prob=True, keep_gpu=keep_gpu)
+                                                    input_prob=True, keep_gpu=keep_gpu, final=False)
     sz = cached_outs.size(0)
     model.block_count = model.block_count + 1
     model.engine = None          # a frozen executor holds the old step sizes: freeze() again after calibration

@@ -281,7 +281,7 @@ def _quant_prefix_input(model, layer, model_input, device, act_quant, trace=None
 
 
 def save_inp_oup_data(model, layer, cali_data, asym=False, act_quant=False, batch_size=32, input_prob=False,
-                      keep_gpu=True, batch_transform=None):
+                      keep_gpu=True, batch_transform=None, final=True):
     """Returns (Resblock, cached_inps, cached_outs) with the reference's tuple nesting (:67-75).
     `batch_transform` maps a raw calibration batch to the model inputs (the conditional variant
     doubles the batch for classifier-free guidance, qdiff_control/data_utils.py:28-31)."""
@@ -308,7 +308,10 @@ def save_inp_oup_data(model, layer, cali_data, asym=False, act_quant=False, batc
             STATS["fp_captures"] += 1
         STATS["units_served"] += 1
         fp = trace.store.pop(layer)
-        trace.done.add(layer)
+        if final:
+            # final=False: the caller does not finish the unit (AttnBlock_layer_reconstruction tunes a block's attention
+            # step sizes while its proj_out is still to be reconstructed): its output must not be memoised yet
+            trace.done.add(layer)
         pack = GetLayerInpOut._pack
         for i in mine:
             sym_in, out = fp.pop(i)

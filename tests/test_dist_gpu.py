@@ -1,0 +1,88 @@
+"""-m gpu: the multi-rank calibration path on real kernels.  The pool gives ONE GPU and RCCL refuses two ranks on one
+device, so two processes share cuda:0 and talk through gloo (edadm/dist.py stages the slabs through the host for that
+backend): same sharding, same gather order, same broadcast as the RCCL run -- only the transport differs."""
+import os
+import random
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _calibrate(world_rank=None):
+    for p in (os.path.join(ROOT, "tests"), os.path.join(ROOT, "eda-dm_amd"), ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from helpers import build_toynet, WQ4, AQ8
+    from qdiff import QuantModel, set_weight_quantize_params, set_act_quantize_params
+    from qdiff.data_utils import save_inp_oup_data
+    from qdiff.block_recon import block_reconstruction
+    from qdiff.quant_layer import seed_mask_rng
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g8_recon.npz"))
+    aq = dict(AQ8)
+    aq["prob"] = 1.0
+    torch.cuda.set_device(0)
+    qnn = QuantModel(build_toynet(g), WQ4, aq, sm_abit=8).cuda().eval()
+    x, t = torch.as_tensor(g["x"]).cuda(), torch.as_tensor(g["t"]).cuda()
+    cali = (x, t)
+    set_weight_quantize_params(qnn, cali)
+    set_act_quantize_params(qnn, cali, batch_size=32)
+    qnn.set_quant_state(True, True)
+    res, ci, co = save_inp_oup_data(qnn, qnn.model.rb, cali, True, True, batch_size=16, input_prob=True)
+    random.seed(99)
+    seed_mask_rng(99)
+    block_reconstruction(qnn, qnn.model.rb, cali_data=cali, iters=6, act_quant=True, asym=True, opt_mode="mse", lr_a=1e-4,
+                         lr_w=5e-2, p=2.0, weight=0.0001, b_range=(20, 2), warmup=0.2, batch_size=16, input_prob=0.5,
+                         add_loss=0.8, recon_w=True, recon_a=True)
+    torch.cuda.synchronize()
+    return {"inp_q": ci[0][0].cpu().numpy(), "temb_q": ci[0][1].cpu().numpy(), "inp_fp": ci[1][0].cpu().numpy(),
+            "out_fp": co.cpu().numpy(), "alpha": qnn.model.rb.conv1.weight_quantizer.alpha.detach().cpu().numpy(),
+            "delta": qnn.model.rb.conv2.act_quantizer.delta.detach().cpu().numpy()}
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "eda-dm_amd"))
+        from edadm import dist as ed
+        ed.GATHER_STATS.update(bytes=0, calls=0)
+        out = _calibrate()
+        out["gathered_bytes"], out["gather_calls"] = ed.GATHER_STATS["bytes"], ed.GATHER_STATS["calls"]
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_shard_the_caching_and_end_identical():
+    """save_inp_oup_data with the calibration batches sharded over two ranks (contiguous blocks, one gathered slab per
+    cached tensor) returns the very tensors one rank computes alone, bit for bit; the replicated reconstruction loop
+    plus rank 0's broadcast leaves both ranks with identical alphas and step sizes."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    alone = _calibrate()
+    r0, r1 = ret[0], ret[1]
+    for k in ("inp_q", "temb_q", "inp_fp", "out_fp"):
+        assert np.array_equal(r0[k], r1[k]), k
+        assert np.array_equal(r0[k], alone[k]), k
+    for k in ("alpha", "delta"):
+        assert np.array_equal(r0[k], r1[k]), k                 # replicas bit-identical after the broadcast
+    # the loop itself is deterministic given (idx stream, mask seeds): the two-rank run equals the one-rank run
+    assert np.array_equal(r0["alpha"], alone["alpha"]) and np.array_equal(r0["delta"], alone["delta"])
+    assert r0["gather_calls"] >= 5 and r0["gathered_bytes"] > 0

@@ -1,0 +1,265 @@
+"""-m gpu, round 2: BASELINE configs 5 (Stable-Diffusion-shaped UNet through the Stable / PLMS drivers) and 1 (W8A8 CIFAR)
+on the HIP path, and the --layer_recon mode (recon_layer_Qmodel + AttnBlock_layer_reconstruction) against G16."""
+import random
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import WQ4, AQ8, build_ldm_formula, build_toynet, build_cifar
+from test_blocks_gpu import flips, T
+
+pytestmark = pytest.mark.gpu
+
+
+def _sd_qnn(g):
+    from qdiff import QuantModel
+    qnn = QuantModel(build_ldm_formula(g), WQ4, AQ8, sm_abit=8, act_quant_mode="qdiff").cuda().eval()
+    qnn.set_quant_state(False, False)
+    qnn.set_first_last_layer_to_8bit()
+    qnn.disable_network_output_quantization()
+    qnn.set_grad_ckpt(False)
+    return qnn
+
+
+def test_config5_sd_shaped_unet_stable_plms_calibration_and_sampling(golden):
+    """qdiff_control.set_{weight,act}_quantize_params_Stable with args.plms (set_quantize_params_Stable.py:58,122) on the
+    product: scales vs the reference's (weights bit-exact), then the reference's scales loaded: fake-quant graph, int8
+    engine (general cross-attention path: 8 heads, 77 keys) and the PLMS loop on the engine."""
+    from qdiff_control import set_act_quantize_params_Stable, set_weight_quantize_params_Stable
+    from qdiff.quant_layer import QuantModule, UniformAffineQuantizer
+    from edadm.latent import LatentDiffusionLite
+    from edadm.state import load_quant_state
+    from edadm.sampling import PLMSLoop
+    from ldm.models.diffusion.plms import PLMSSampler
+    g = golden("g13_ldm_sd")
+    qnn = _sd_qnn(g)
+    ld = LatentDiffusionLite(qnn, timesteps=1000, linear_start=0.00085, linear_end=0.012, conditioning_key="crossattn").cuda()
+    args = SimpleNamespace(custom_steps=int(g["args/custom_steps"]), scale=float(g["args/scale"]), ddim_eta=0.0, plms=True,
+                           C=4, H=64, W=64, f=8, list_prompts=["a", "b", "c", "d"])
+    cali = tuple(T(g[k]).cuda() for k in ("x", "t", "index", "cond", "uncond", "t_next"))
+    set_weight_quantize_params_Stable(ld, cali, args)
+    set_act_quantize_params_Stable(ld, cali, args, batch_size=2)
+    assert not any(m.split for m in qnn.modules() if isinstance(m, QuantModule))          # sample_txt2img.py:183-184 quirk
+    n = 0
+    for name, m in qnn.named_modules():
+        if isinstance(m, UniformAffineQuantizer) and m.delta is not None:
+            k = "qp/" + name
+            got_d, got_z = m.delta.detach().cpu().numpy().reshape(-1), m.zero_point.cpu().numpy().reshape(-1)
+            ref_d, ref_z = g[k + "/delta"].reshape(-1), g[k + "/zero_point"].reshape(-1)
+            assert m.n_bits == int(g[k + "/n_bits"]), name
+            if m.leaf_param:
+                # activations arrive through GPU contractions: a near-tie of two of the 100 candidates (1 % apart) may flip
+                np.testing.assert_allclose(got_d, ref_d, rtol=5e-2, err_msg=name)
+                assert np.abs(got_z - ref_z).max() <= 1, name
+            else:
+                np.testing.assert_array_equal(got_d, ref_d, err_msg=name)
+                np.testing.assert_array_equal(got_z, ref_z, err_msg=name)
+            n += 1
+    assert n == len([k for k in g.files if k.startswith("qp/") and k.endswith("/delta")])
+    # the reference's own scales from here on
+    assert load_quant_state(qnn, {k: g[k] for k in g.files if k.startswith("qp/")}, prefix="qp/") == n
+    x, t, cond, uncond = cali[0], cali[1], cali[3], cali[4]
+    x8, t8, c8 = torch.cat([x] * 2), torch.cat([t] * 2), torch.cat([uncond, cond])
+    rng = np.abs(g["out_q"]).max()
+
+    def cmp(name, got, ref, tol_max, tol_mean):
+        err = np.abs(got.detach().cpu().numpy().astype(np.float64) - ref)
+        print("%s: max %.3e mean %.3e of range" % (name, err.max() / rng, err.mean() / rng))
+        assert err.max() <= tol_max * rng and err.mean() <= tol_mean * rng, name
+
+    with torch.no_grad():
+        qnn.set_quant_state(False, False)
+        cmp("fp graph", qnn(x8, t8, c8), g["out_fp"], 1e-4, 1e-5)
+        qnn.set_quant_state(True, False)
+        cmp("weight-quant graph", qnn(x8, t8, c8), g["out_wq"], 2e-3, 2e-4)
+        qnn.set_quant_state(True, True)
+        fq = qnn(x8, t8, c8)
+        cmp("fake-quant graph", fq, g["out_q"], 6e-2, 6e-3)
+        eng = qnn.freeze()
+        out = qnn(x8, t8, c8)
+        assert qnn.engine is eng
+        cmp("int8 engine vs reference", out, g["out_q"], 6e-2, 6e-3)
+        # PLMS on the engine: the loop (HIP graph, guidance pair) against the sampler class stepping the same engine
+        S, B = int(g["args/custom_steps"]), 2
+        xT = torch.randn(B, 4, 8, 8, generator=torch.Generator().manual_seed(5)).cuda()
+        loop = PLMSLoop(eng, (4, 8, 8), B, steps=S, scale=float(g["args/scale"]), context_shape=(77, 24), device="cuda")
+        inter = {}
+        img = loop.sample(xT, cond[:B].contiguous(), uncond[:B].contiguous(), intermediates=inter)
+        sampler = PLMSSampler(ld)
+        ref_img, ref_inter = sampler.sample(S=S, batch_size=B, shape=[4, 8, 8], conditioning=cond[:B].contiguous(),
+                                            verbose=False, unconditional_guidance_scale=float(g["args/scale"]),
+                                            unconditional_conditioning=uncond[:B].contiguous(), eta=0.0, x_T=xT.clone())
+        assert torch.isfinite(img).all()
+        assert torch.equal(img, ref_img), float((img - ref_img).abs().max())
+        assert len(inter["x_inter"]) == S and len(ref_inter["x_inter"]) == S + 1
+
+
+def test_config1_cifar_w8a8_through_the_engine(golden):
+    """BASELINE config 1's bit widths (W8A8): the DDPM UNet with 8-bit weights through scale search, fake-quant graph and
+    the frozen engine (8-bit weights run on the int8 MFMA, or on the exact f16 MFMA when a row spans [-127, 128])."""
+    from qdiff import QuantModel, set_weight_quantize_params, set_act_quantize_params
+    from qdiff.quant_layer import UniformAffineQuantizer
+    from edadm.state import load_quant_state
+    g, base = golden("g13_cifar_w8"), golden("g13_cifar_unet")
+    wq = dict(WQ4)
+    wq["n_bits"] = 8
+    qnn = QuantModel(build_cifar(base), wq, AQ8, sm_abit=8).cuda().eval()
+    qnn.set_quant_state(False, False)
+    qnn.set_first_last_layer_to_8bit()
+    qnn.disable_network_output_quantization()
+    qnn.model.config.split_shortcut = True
+    x, t = T(g["x"]).cuda(), T(g["t"]).cuda()
+    set_weight_quantize_params(qnn, (x, t))
+    set_act_quantize_params(qnn, (x, t), batch_size=4)
+    n = 0
+    for name, m in qnn.named_modules():
+        if isinstance(m, UniformAffineQuantizer) and m.delta is not None:
+            k = "qp/" + name
+            assert m.n_bits == 8 == int(g[k + "/n_bits"]), name
+            got_d, ref_d = m.delta.detach().cpu().numpy().reshape(-1), g[k + "/delta"].reshape(-1)
+            if m.leaf_param:
+                np.testing.assert_allclose(got_d, ref_d, rtol=5e-2, err_msg=name)
+            else:
+                np.testing.assert_array_equal(got_d, ref_d, err_msg=name)          # 8-bit search: 100 x 1-D candidates
+                np.testing.assert_array_equal(m.zero_point.cpu().numpy().reshape(-1), g[k + "/zero_point"].reshape(-1))
+            n += 1
+    assert n == len([k for k in g.files if k.startswith("qp/") and k.endswith("/delta")])
+    load_quant_state(qnn, {k: g[k] for k in g.files if k.startswith("qp/")}, prefix="qp/")
+    rng = np.abs(g["out_q"]).max()
+    with torch.no_grad():
+        qnn.set_quant_state(True, False)
+        e = np.abs(qnn(x, t).cpu().numpy() - g["out_wq"]).max() / rng
+        assert e <= 2e-3, e
+        qnn.set_quant_state(True, True)
+        fq = qnn(x, t).cpu().numpy()
+        eng = qnn.freeze()
+        out = qnn(x, t).cpu().numpy()
+    modes = {}
+    for L in eng.layers.values():
+        modes[L.mode] = modes.get(L.mode, 0) + 1
+    for name, got in (("fake-quant graph", fq), ("engine", out)):
+        err = np.abs(got - g["out_q"]) / rng
+        print("W8A8 %s: max %.3e mean %.3e of range; engine layer modes %s" % (name, err.max(), err.mean(), modes))
+        assert err.max() <= 5e-2 and err.mean() <= 5e-3, name
+    assert modes.get("f32", 0) == 1 and modes.get("i8", 0) + modes.get("f16", 0) == len(eng.layers) - 1
+
+
+G16_UNITS = (("layer:model.conv_in", "conv_in", "layer"), ("layer:model.temb_lin", "temb_lin", "layer"),
+             ("layer:model.rb.conv1", "rb.conv1", "layer"), ("layer:model.rb.temb_proj", "rb.temb_proj", "layer"),
+             ("layer:model.rb.conv2", "rb.conv2", "layer"), ("layer:model.at.q", "at.q", "layer"),
+             ("layer:model.at.k", "at.k", "layer"), ("layer:model.at.v", "at.v", "layer"),
+             ("attn:model.at", "at", "attn_layer"), ("layer:model.at.proj_out", "at.proj_out", "layer"),
+             ("layer:model.conv_out", "conv_out", "layer"))
+
+
+def test_layer_recon_walk_with_attention_step_sizes(golden):
+    """recon_layer_Qmodel (recon_layer_Qmodel.py:20-120) on the device: the order of the walk, and every unit's alpha / delta
+    trajectory against an oracle twin started from the product's own initial scales (the twin is pinned against the
+    reference's G16 trajectories on the CPU, tests/test_oracle_round2.py) -- including AttnBlock_layer_reconstruction
+    (attn_layer_recon.py:13-133), which trains the four attention step sizes alone."""
+    import sys
+    from qdiff import QuantModel, set_weight_quantize_params, set_act_quantize_params
+    import qdiff  # noqa: F401
+    from qdiff.quant_layer import UniformAffineQuantizer
+    from qdiff.adaptive_rounding import AdaRoundQuantizer
+    import edadm.recon as recon
+    from oracle import qdiff_oracle as O
+    from test_oracle_nets import ToyNet as OToyNet, sub_sd as o_sub_sd
+    rl = sys.modules['qdiff.recon_layer_Qmodel']
+    g = golden("g16_layer_recon")
+    aq = dict(AQ8)
+    aq["prob"] = 1.0
+    qnn = QuantModel(build_toynet(g), WQ4, aq, sm_abit=8).cuda().eval()
+    x, t = T(g["x"]).cuda(), T(g["t"]).cuda()
+    cali = (x, t)
+    set_weight_quantize_params(qnn, cali)
+    set_act_quantize_params(qnn, cali, batch_size=32)
+    onet = OToyNet(o_sub_sd(g, "sd/"), WQ4, aq)
+    with torch.no_grad():
+        onet(x.cpu(), t.cpu())
+    st = {}
+    for name, m in qnn.named_modules():
+        if isinstance(m, UniformAffineQuantizer) and m.delta is not None:
+            st["qp/" + name + "/delta"] = m.delta.detach().cpu().numpy()
+            st["qp/" + name + "/zero_point"] = m.zero_point.cpu().numpy()
+            st["qp/" + name + "/n_bits"] = np.int64(m.n_bits)
+            if not m.leaf_param:
+                np.testing.assert_array_equal(st["qp/" + name + "/delta"].reshape(-1), g["init/qp/" + name + "/delta"].reshape(-1))
+    onet.load_qparams(st)
+    kwargs = dict(cali_data=cali, iters=12, act_quant=True, asym=True, opt_mode="mse", lr_a=1e-4, lr_w=5e-2, p=2.0,
+                  weight=0.0001, b_range=(20, 2), warmup=0.2, batch_size=16, input_prob=1.0, add_loss=0.8,
+                  recon_w=True, recon_a=True, keep_gpu=True)
+    names = {m: n for n, m in qnn.named_modules()}
+    traj, order, cur = {}, [], {"name": None}
+    orig_step = recon.FusedAdam.step
+    ol, oa = rl.layer_reconstruction, rl.AttnBlock_layer_reconstruction
+
+    def step(self):
+        orig_step(self)
+        key = "%s/%s" % (cur["name"], "a" if self.params[0].numel() == 1 else "w")
+        traj.setdefault(key, []).append(self.flat.detach().cpu().clone())
+
+    def wrap(kind, fn):
+        def run(model, unit, **kw):
+            cur["name"] = "%s:%s" % (kind, names[unit])
+            order.append(cur["name"])
+            return fn(model, unit, **kw)
+        return run
+
+    recon.FusedAdam.step = step
+    rl.layer_reconstruction, rl.AttnBlock_layer_reconstruction = wrap("layer", ol), wrap("attn", oa)
+    try:
+        random.seed(1616)
+        rl.recon_layer_Qmodel(None, qnn, cali, kwargs).recon()
+    finally:
+        recon.FusedAdam.step = orig_step
+        rl.layer_reconstruction, rl.AttnBlock_layer_reconstruction = ol, oa
+    assert order == [str(u) for u in g["order"]] == [u[0] for u in G16_UNITS]
+    assert qnn.block_count == int(g["block_count"])
+    assert "attn:model.at/w" not in traj and torch.stack(traj["attn:model.at/a"]).shape == (12, 4)
+    # the oracle twin, same idx stream
+    random.seed(1616)
+    okw = dict(cali=(x.cpu(), t.cpu()), iters=12, act_quant=True, lr_a=1e-4, lr_w=5e-2, p=2.0, batch_size=16,
+               input_prob=1.0, add_loss=0.8, recon_w=True, recon_a=True, cache_batch=32)
+    for key, path, kind in G16_UNITS:
+        unit = onet
+        for p in path.split("."):
+            unit = getattr(unit, p)
+        tw, ta = [], []
+        O.reconstruct_unit(onet, unit, kind,
+                           trace=lambda it, wp, ap, l: (tw.append(torch.cat([p.detach().flatten() for p in wp]).clone()) if wp else None,
+                                                        ta.append(torch.cat([p.detach().flatten() for p in ap]).clone())),
+                           **okw)
+        got_a, ref_a = torch.stack(traj[key + "/a"]).numpy(), torch.stack(ta).numpy()
+        arel = (np.abs(got_a - ref_a) / np.abs(ref_a)).max()
+        if kind == "attn_layer":
+            print("%-26s attention step sizes: max rel %.3g; vs the reference's own trajectory %.3g" % (
+                key, arel, (np.abs(got_a - g["traj/" + key + "/a"]) / np.abs(g["traj/" + key + "/a"])).max()))
+            assert arel < 3e-2, arel
+            # the units behind continue from the product's trained step sizes (a 1e-3 difference of the softmax step size
+            # flips a tenth of the codes near 100: that amplification is not what the next units should measure)
+            for q, v in zip(onet.at.extra_quantizers(), got_a[-1]):
+                q.delta = torch.tensor(float(v)).reshape(q.delta.shape)
+            continue
+        got_w, ref_w = torch.stack(traj[key + "/w"]).numpy(), torch.stack(tw).numpy()
+        dw = np.abs(got_w - ref_w)
+        print("%-26s alpha: median %.2e first step %.2e frac>1e-2 %.4f max %.3g | delta max rel %.3g" % (
+            key, np.median(dw), np.median(dw[0]), (dw > 1e-2).mean(), dw.max(), arel))
+        assert np.median(dw[0]) < 1e-4, key
+        assert np.median(dw) < 4e-3 and (dw > 1e-2).mean() < 0.2 and dw.max() < 0.25, key
+        assert arel < 3e-2, (key, arel)
+    for name, m in qnn.named_modules():
+        if isinstance(m, AdaRoundQuantizer):
+            ref = g["final/alpha/" + name]
+            agree = np.mean((m.alpha.detach().cpu().numpy() >= 0) == (ref >= 0))
+            assert agree > 0.99, (name, agree)
+            assert m.soft_targets is False
+    for q in (qnn.model.at.act_quantizer_q, qnn.model.at.act_quantizer_k, qnn.model.at.act_quantizer_v, qnn.model.at.act_quantizer_w):
+        assert q.is_training is False
+    qnn.set_quant_state(True, True)
+    with torch.no_grad():
+        out = qnn(x[:8], t[:8]).cpu().numpy()
+    ref = g["final/out_q"]
+    assert np.abs(out - ref).max() < 0.08 * np.abs(ref).max()
