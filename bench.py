@@ -363,8 +363,9 @@ def main():
         e1.synchronize()
         return e0.elapsed_time(e1) / reps
 
-    i8 = [(f, kernel_ms(run)) for mode, _, _, _, _, f, run in prof if mode == "i8"]
-    gemm_flop, gemm_ms = sum(f for f, _ in i8), sum(ms for _, ms in i8)
+    i8 = [(f, kernel_ms(run), sum(v for k, v in by.items() if k != "kind")) for mode, _, _, _, _, f, run, by in prof if mode == "i8"]
+    gemm_flop, gemm_ms = sum(r[0] for r in i8), sum(r[1] for r in i8)
+    gemm_alg_bytes = sum(r[2] for r in i8)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     loop.unet(x_in, t_in, c_in, step=0)      # new context tensor: its branch graph replays here, outside the timing
     ev0.record()
@@ -401,6 +402,10 @@ def main():
                        "images_per_step": B, "ddim_steps": 20, "cfg_scale": 3.0, "parallelism": "dp%d (independent batches, no collective)" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": I8_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / I8_PEAK_TFLOPS, "traffic": traffic,
+                         "algorithmic_bytes": gemm_alg_bytes / max(len(i8), 1),
+                         "algorithmic_bytes_note": "per GEMM call, like `traffic`: int8 activation tensor + integer weights + output in "
+                                                   "its stored type + fp32 residual, each element once (a convolution's input counted "
+                                                   "once, not 9x); traffic / algorithmic_bytes = re-read factor",
                          "kernel": "int8 GEMM (edadm_qgemm_i8/_q: k_gemm_nt8, k_gemm_p, k_gemm_nt): %d launches per UNet call of a DDIM step, %.1f GFLOP, %.2f ms summed"
                                    % (len(i8), gemm_flop / 1e9, gemm_ms),
                          "hbm": {"note": "same launches against the HBM roof: PMC bytes per launch x launches / summed time",

@@ -83,6 +83,13 @@ class FrozenLayer:
             self.K = self.w_f32.shape[1]
             return
         self.mode = "i8" if fits_i8 else "f16"
+        # the contraction kernels take K in whole 16-byte pieces: a dense layer whose K is not (a 24-channel context in a
+        # fixture; every shipped configuration is) gets zero weights appended and its operand padded to match (_quant)
+        kq = 16 if self.mode == "i8" else 8
+        self.kpad = 0
+        if self.kind == "dense" and not qm.split and wints[0][0].shape[1] % kq:
+            self.kpad = kq - wints[0][0].shape[1] % kq
+            wints = [(torch.nn.functional.pad(wints[0][0], (0, self.kpad)), wints[0][1], wints[0][2])]
         entries = []
         for (lo, hi), aq, (wint, _, dw) in zip(bounds, aqs, wints):
             dx, zx, qmax = aq.delta.detach().reshape(()).float(), aq.zero_point.detach().reshape(()).float(), aq.n_levels - 1
@@ -241,11 +248,19 @@ class Engine:
         if isinstance(x2d, ops.Cat) and L.mode != "i8":
             x2d = torch.cat([x2d.a, x2d.full_b()], dim=-1)
         if L.mode == "i8":
-            return ops.quant_i8(x2d, L.qp, split=L.split)
-        if L.mode == "f16":
-            assert not L.split
-            return ops.quant_f16(x2d, L.qp)
-        return x2d
+            a = ops.quant_i8(x2d, L.qp, split=L.split)
+        elif L.mode == "f16":
+            if L.split:                                  # one quantiser per channel range (quant_layer.py:415-418)
+                a = torch.empty(x2d.shape, dtype=torch.float16, device=x2d.device)
+                for i, sg in enumerate(L.segs):
+                    ops.quant_f16(x2d[:, sg["lo"]:sg["hi"]], L.qp[4 * i:4 * i + 4].contiguous(), out=a[:, sg["lo"]:sg["hi"]])
+            else:
+                a = ops.quant_f16(x2d, L.qp)
+        else:
+            return x2d
+        if getattr(L, "kpad", 0):
+            a = torch.nn.functional.pad(a, (0, L.kpad))
+        return a
 
     def _gemm(self, L, a, M, geom=None, rowadd=None, rpb=1, residual=None, out_mode=0, oqp=None, gn_hw=0):
         if self.tap is not None:
@@ -257,7 +272,9 @@ class Engine:
             run = lambda: ops.qgemm_i8_q(a, s0["w"], M, L.N, s0["K"], s0["scale"], L.bias, out_mode, oqp, lda=a.shape[-1],
                                          residual=residual, rows_per_batch=rpb)
             if self.prof is not None:       # bench.py's roofline pass re-launches each recorded GEMM under HIP events
-                self.prof.append((L.mode, L.name, M, L.N, L.K, 2.0 * M * L.N * L.K, run))
+                obytes = {1: 2.0, 2: 1.0, 3: 0.5, 4: 2.0}[out_mode] * M * L.N
+                self.prof.append((L.mode, L.name, M, L.N, L.K, 2.0 * M * L.N * L.K, run,
+                                  self._alg_bytes(L, a, M, obytes, residual, "dense")))
             return run()
         out = torch.empty(M, L.N, dtype=torch.float32, device=self.dev)
         fn = ops.qgemm_i8 if L.mode == "i8" else ops.qgemm_f16
@@ -288,9 +305,19 @@ class Engine:
                        rowadd=rowadd if i == 0 else None, rows_per_batch=rpb, residual=residual if i == 0 else out,
                        **(gkw if i == len(L.segs) - 1 else {}))
         if self.prof is not None:
-            self.prof.append((L.mode, L.name, M, L.N, L.K, 2.0 * M * L.N * L.K, run))
+            self.prof.append((L.mode, L.name, M, L.N, L.K, 2.0 * M * L.N * L.K, run,
+                              self._alg_bytes(L, a, M, 4.0 * M * L.N, residual, "conv%d" % L.kh if geom is not None else "dense")))
         run()
         return out
+
+    @staticmethod
+    def _alg_bytes(L, a, M, out_bytes, residual, kind):
+        """ALGORITHMIC bytes of one layer launch: every operand element once -- the activation tensor as it lies in HBM
+        (for a convolution the NHWC tensor, not its 9x im2col view), the integer weights, the output in its stored type,
+        the fp32 residual when the epilogue adds one."""
+        wb = sum(sg["w"].numel() * sg["w"].element_size() for sg in L.segs)
+        return {"kind": kind, "a": float(a.numel() * a.element_size()), "w": float(wb), "out": float(out_bytes),
+                "res": 4.0 * M * L.N if residual is not None else 0.0}
 
     def lin(self, qm, x2d, rowadd=None, rpb=1, residual=None, pre=None):
         """x2d fp32 [M][C] (or a ready operand via `pre`) -> fp32 [M][N]."""
