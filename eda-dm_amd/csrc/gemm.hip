@@ -110,8 +110,11 @@ __device__ __forceinline__ void gemm_epilogue(typename Acc<DT>::type (&acc)[TM][
                                               float* __restrict__ out, int64_t ldo, int out_mode) {
     constexpr int EST = TN * 32 + 4;
     const int fr = lane & 31, fh = lane >> 5;
+    // the vector path stores 16 (fp32), 8 (f16 codes), 4 (int8 codes) or 2 (GEGLU pair) bytes per lane: that is the
+    // alignment the output base needs (a per-head view of an int8 [rows][heads * d] tensor starts at a multiple of d bytes)
+    const uintptr_t oalign = out_mode == 0 ? 15 : out_mode == 1 ? 7 : out_mode == 2 ? 3 : 1;
     const bool vec = ((N & 3) == 0) && ((ldo & 3) == 0) && (!residual || (ldr & 3) == 0) &&
-                     ((((uintptr_t)out) & 15) == 0) && (!residual || (((uintptr_t)residual) & 15) == 0);
+                     ((((uintptr_t)out) & oalign) == 0) && (!residual || (((uintptr_t)residual) & 15) == 0);
     __syncthreads();                                       // stage buffers free, epilogue constants visible
     if (vec) {
         float* ep = reinterpret_cast<float*>(smem) + wave * (32 * EST);
@@ -210,7 +213,14 @@ __device__ __forceinline__ void gemm_epilogue(typename Acc<DT>::type (&acc)[TM][
                 float v = (float)acc[i][j][r] * s + bs;
                 if (has_rowadd) v += ec[(2 + (int)(row / rows_per_batch - b0)) * BN + ecol];
                 if (residual) v += residual[row * ldr + col];
-                out[row * ldo + col] = v;
+                if (out_mode == 0) {
+                    out[row * ldo + col] = v;
+                } else {                                   // element-wise form of the quantised outputs (modes 1, 2)
+                    const float od = ec[(2 + RA) * BN], oz = ec[(2 + RA) * BN + 1], oq = ec[(2 + RA) * BN + 2];
+                    const float qv = fminf(fmaxf(rint_div(v, od, 1.0f / od) + oz, 0.f), oq);
+                    if (out_mode == 1) reinterpret_cast<__half*>(out)[row * ldo + col] = __float2half(qv - oz);
+                    else reinterpret_cast<int8_t*>(out)[row * ldo + col] = (int8_t)((int)qv - 128);
+                }
             }
         }
     }
@@ -641,7 +651,9 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
     // full fp32 tiles take the register-direct epilogue (workgroup-uniform choice)
     const bool full = m0 + BM <= M && n0 + BN <= N;
     const bool direct = out_mode == 0 && full && (!rowadd || rows_per_batch >= TM * 32);
-    const bool qdirect = out_mode != 0 && full && !rowadd && (!residual || !(ldr & 3));   // transposed accumulators, see the epilogue
+    // transposed accumulators, see the epilogue; its 16-byte stores need the (per-head) output view aligned
+    const bool qdirect = out_mode != 0 && full && !rowadd && (!residual || !(ldr & 3)) &&
+                         (out_mode == 4 || ((((uintptr_t)out) & 15) == 0 && ((ldo * (out_mode == 1 ? 2 : 1)) & 15) == 0));
 
     typename Acc<DT>::type acc[TM][TN];
 #pragma unroll
@@ -888,7 +900,9 @@ k_gemm_nt8(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, cons
     // full fp32 tiles take the register-direct epilogue (workgroup-uniform choice)
     const bool full = m0 + BM <= M && n0 + BN <= N;
     const bool direct = out_mode == 0 && full && (!rowadd || rows_per_batch >= TM * 32);
-    const bool qdirect = out_mode != 0 && full && !rowadd && (!residual || !(ldr & 3));   // transposed accumulators, see the epilogue
+    // transposed accumulators, see the epilogue; its 16-byte stores need the (per-head) output view aligned
+    const bool qdirect = out_mode != 0 && full && !rowadd && (!residual || !(ldr & 3)) &&
+                         (out_mode == 4 || ((((uintptr_t)out) & 15) == 0 && ((ldo * (out_mode == 1 ? 2 : 1)) & 15) == 0));
     STAMP(t_consts);
 
     typename Acc<DT>::type acc[TM][TN];

@@ -265,6 +265,11 @@ class Engine:
     def _gemm(self, L, a, M, geom=None, rowadd=None, rpb=1, residual=None, out_mode=0, oqp=None, gn_hw=0):
         if self.tap is not None:
             self.tap.setdefault(L.name, []).append(a.detach().clone())
+        if out_mode and (L.mode != "i8" or len(L.segs) != 1):
+            # a layer off the int8 path (exact-f16 weights, split quantisers): fp32 output, then the consumer's quantise pass
+            assert out_mode in (1, 2) and geom is None
+            y = self._gemm(L, a, M, rowadd=rowadd, rpb=rpb, residual=residual)
+            return ops.quant_f16(y, oqp) if out_mode == 1 else ops.quant_i8(y, oqp)
         if out_mode:
             # the only consumer is an activation quantizer: emit its operand from the epilogue
             assert L.mode == "i8" and len(L.segs) == 1 and geom is None
@@ -369,7 +374,18 @@ class Engine:
         consumes x itself: its int8 operand comes out of the same pass as a third element."""
         st = self._gn_stats(norm, x)
         Ls = [self.L(q) for q in qms]
-        assert all(l.mode == "i8" and not l.split for l in Ls)
+        if not all(l.mode == "i8" and not l.split for l in Ls) or (raw is not None and raw.mode != "i8"):
+            # a consumer whose weights run on the exact f16 MFMA (8-bit weights spanning [-127, 128]: W8A8 configurations)
+            # or with split quantisers: normalise to fp32, then each consumer's own quantise pass (the same codes)
+            if isinstance(x, ops.Cat):
+                x = ops.concat_c(x.a, x.full_b())
+            y, _ = ops.groupnorm_apply(x, st, norm.weight, norm.bias, norm.num_groups, silu, want_f32=True,
+                                       scale_shift=scale_shift)
+            C = y.shape[-1]
+            qs = [self._quant(l, y.reshape(-1, C)).reshape(y.shape) for l in Ls]
+            if raw is not None:
+                return (y if want_f32 else None), qs, self._quant(raw, x.reshape(-1, C)).reshape(x.shape)
+            return (y if want_f32 else None), qs
         qp = self._qp_cat(Ls) if Ls else None
         kw = dict(raw_qp=raw.qp, raw_split=raw.split) if raw is not None else {}
         return ops.groupnorm_apply(x, st, norm.weight, norm.bias, norm.num_groups, silu, qp=qp, nq=len(Ls),
@@ -386,13 +402,17 @@ class Engine:
     def ln_radd(self, norm, x2d, radd, rows_per_batch, qms, rows):
         """LayerNorm(x2d + radd per image) -> (the sum = updated residual stream, operands)."""
         Ls = [self.L(q) for q in qms]
-        assert all(l.mode == "i8" and not l.split for l in Ls)
+        if not all(l.mode == "i8" and not l.split for l in Ls):
+            t = ops.add_rowbcast(x2d, radd, rows_per_batch, rows=rows)
+            return t, self.ln(norm, t, qms)
         return ops.layernorm_quant_radd(x2d, radd, rows_per_batch, norm.weight, norm.bias, norm.eps, self._qp_cat(Ls),
                                         len(Ls), rows=rows)
 
     def ln(self, norm, x2d, qms):
         Ls = [self.L(q) for q in qms]
-        assert all(l.mode == "i8" and not l.split for l in Ls)
+        if not all(l.mode == "i8" and not l.split for l in Ls):
+            y, _ = ops.layernorm_quant(x2d, norm.weight, norm.bias, norm.eps, want_f32=True)
+            return [self._quant(l, y) for l in Ls]
         _, qs = ops.layernorm_quant(x2d, norm.weight, norm.bias, norm.eps, qp=self._qp_cat(Ls), nq=len(Ls))
         return qs
 
@@ -402,7 +422,8 @@ class Engine:
             r = self.emb_r[id(qm)]
             return r if self._emb_n is None else r[:self._emb_n]
         L = self.L(qm)
-        assert L.mode == "i8"
+        if L.mode != "i8":
+            return self._gemm(L, self._quant(L, ops.silu(emb)), emb.shape[0])
         return self._gemm(L, ops.silu_quant_i8(emb, L.qp), emb.shape[0])
 
     def emb_tables(self, ts_all, steps):

@@ -82,11 +82,11 @@ def test_config5_sd_shaped_unet_stable_plms_calibration_and_sampling(golden):
         cmp("weight-quant graph", qnn(x8, t8, c8), g["out_wq"], 2e-3, 2e-4)
         qnn.set_quant_state(True, True)
         fq = qnn(x8, t8, c8)
-        cmp("fake-quant graph", fq, g["out_q"], 6e-2, 6e-3)
+        cmp("fake-quant graph", fq, g["out_q"], 8e-2, 1e-2)        # formula weights: a less contractive net than the seeded-init fixtures, a flip travels further
         eng = qnn.freeze()
         out = qnn(x8, t8, c8)
         assert qnn.engine is eng
-        cmp("int8 engine vs reference", out, g["out_q"], 6e-2, 6e-3)
+        cmp("int8 engine vs reference", out, g["out_q"], 8e-2, 1e-2)
         # PLMS on the engine: the loop (HIP graph, guidance pair) against the sampler class stepping the same engine
         S, B = int(g["args/custom_steps"]), 2
         xT = torch.randn(B, 4, 8, 8, generator=torch.Generator().manual_seed(5)).cuda()

@@ -1,0 +1,52 @@
+"""Diagnostic: the engine's attention core (quantise -> Q K^T -> softmax + quantise -> P V) stage by stage against torch on
+the same integer codes, for several (heads, head dim, queries, keys)."""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "eda-dm_amd"))
+import torch
+from types import SimpleNamespace
+from edadm import ops
+from edadm.engine import Engine
+dev = torch.device("cuda", 0)
+
+
+def q_(delta, zp, bits=8):
+    return SimpleNamespace(delta=torch.tensor(delta, device=dev), zero_point=torch.tensor(float(zp), device=dev), n_levels=2 ** bits)
+
+
+def case(B, heads, d, Nq, Nk, v_transposed=False):
+    g = torch.Generator().manual_seed(B * 1000 + heads * 100 + d)
+    hd = heads * d
+    q = torch.randn(B * Nq, hd, generator=g).to(dev)
+    k = torch.randn(B * Nk, hd, generator=g).to(dev)
+    v = torch.randn(B * Nk, hd, generator=g).to(dev)
+    aq, ak, av, aw = q_(0.03, 128), q_(0.031, 127), q_(0.029, 128), q_(1 / 255.0, 0)
+    eng = Engine.__new__(Engine)
+    eng.dev, eng._attn_cache = dev, {}
+    scale = d ** -0.5
+    out = eng.attention(q, k, v, B, Nq, Nk, heads, d, aq, ak, av, aw, scale)
+    # torch on the same codes
+    def codes(x, qz):
+        return torch.clamp(torch.round(x / qz.delta) + qz.zero_point, 0, 255) - qz.zero_point
+    cq, ck, cv = codes(q, aq), codes(k, ak), codes(v, av)
+    sp = lambda t, n: t.reshape(B, n, heads, d).permute(0, 2, 1, 3)
+    s = torch.einsum("bhid,bhjd->bhij", sp(cq, Nq).double(), sp(ck, Nk).double()) * float(aq.delta * ak.delta) * scale
+    p = torch.softmax(s.float(), -1)
+    cp = torch.clamp(torch.round(p / aw.delta) + aw.zero_point, 0, 255) - aw.zero_point
+    o = torch.einsum("bhij,bhjd->bhid", cp.double(), sp(cv, Nk).double()) * float(aw.delta * av.delta)
+    ref = o.permute(0, 2, 1, 3).reshape(B * Nq, hd).float()
+    err = (out - ref).abs().max().item() / ref.abs().max().item()
+    # stage 1 alone
+    qh, kh = ops.quant_f16(q, eng._aq(aq)[0]), ops.quant_f16(k, eng._aq(ak)[0])
+    e_codes = max((qh.float() - cq).abs().max().item(), (kh.float() - ck).abs().max().item())
+    s_e = ops.gemm_f16_nt(qh, hd, Nq * hd, kh, hd, Nk * hd, B, Nq, Nk, d, float(aq.delta * ak.delta) * scale, inner=heads,
+                          strideA_i=d, strideB_i=d)
+    e_s = (s_e.reshape(B, heads, Nq, Nk).double() - s).abs().max().item() / s.abs().max().item()
+    print("B=%d heads=%d d=%3d Nq=%4d Nk=%4d: codes err %.1f | scores rel err %.2e | output rel err %.2e %s" % (
+        B, heads, d, Nq, Nk, e_codes, e_s, err, "  <-- WRONG" if err > 1e-3 else ""))
+
+
+for args in ((2, 1, 32, 16, 16), (2, 2, 16, 16, 16), (2, 2, 16, 16, 7), (2, 8, 8, 16, 16), (2, 8, 8, 16, 77), (2, 8, 16, 64, 64),
+             (2, 8, 40, 64, 64), (2, 8, 40, 64, 77), (2, 8, 80, 16, 77), (2, 8, 160, 16, 77), (2, 4, 8, 16, 16), (2, 4, 24, 32, 32),
+             (1, 8, 40, 1024, 1024)):
+    case(*args)
