@@ -139,6 +139,43 @@ __device__ __forceinline__ void rint_div_zp_n(const float (&v)[NV], float d, flo
     }
 }
 
+// GEGLU + quantise for the GEMM epilogue: codes r[e] = rint((val * gelu(gate)) / d) + z for NV (value, gate) pairs, equal
+// BIT FOR BIT to the exact form (erf_fast to < 1 ulp, IEEE division) at about half its instruction count.
+// Fast pass: 1 + erf(g / sqrt 2) by Abramowitz-Stegun 7.1.26 (one rcp, one exp2, five FMAs; |error| <= 1.5e-7 + fp32
+// evaluation, 5e-7 in all), reciprocal multiply for the division.  The rounded code can differ from the exact form's only
+// if t = y / d + z lies closer to a .5 boundary than the fast pass's error in t: |val gate| / d * 6e-7 (erf error and
+// product roundings, both proportional to |val gate|) + 2e-4 (roundings of t itself, |t| < 512; beyond that the clamp
+// saturates).  Groups with such an element redo all NV the exact way behind a real branch (a few % of the calls).
+template <int NV>
+__device__ __forceinline__ void geglu_codes_n(const float (&val)[NV], const float (&gate)[NV], float d, float inv_d, float z,
+                                              float (&r)[NV]) {
+    float worst = 0.f;
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+        const float g = gate[e];
+        const float x = fabsf(g) * 0.70710678118654752440f;
+        const float u = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+        float pl = fmaf(1.061405429f, u, -1.453152027f);
+        pl = fmaf(pl, u, 1.421413741f);
+        pl = fmaf(pl, u, -0.284496736f);
+        pl = fmaf(pl, u, 0.254829592f);
+        const float pe = pl * u * __builtin_amdgcn_exp2f(x * x * -1.44269504088896340736f);
+        const float E = g >= 0.f ? 2.0f - pe : pe;          // 1 + erf(g / sqrt 2)
+        const float vg = val[e] * g;
+        const float t = fmaf(vg * (0.5f * E), inv_d, z);
+        r[e] = rintf(t);
+        worst = fmaxf(worst, fabsf(t - r[e]) + fmaf(fabsf(vg) * inv_d, 6e-7f, 2e-4f));
+    }
+    if (__builtin_expect(worst > 0.5f, 0)) {
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+            asm volatile("" : "+v"(r[e]));
+            const float y = val[e] * (0.5f * gate[e] * (1.0f + erf_fast(gate[e] * 0.70710678118654752440f)));
+            r[e] = rintf(y / d) + z;
+        }
+    }
+}
+
 // clamp to [lo, hi] in one instruction (v_med3_f32)
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 

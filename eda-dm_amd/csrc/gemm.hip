@@ -422,10 +422,9 @@ __device__ __forceinline__ void gemm_epilogue_qdirect(typename Acc<DT>::type (&a
                         v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
                     }
                     if constexpr (MODE == 3) {             // GEGLU on interleaved (a, gate) columns -> two int8 codes
-                        float y[2], r[2];
-                        y[0] = v[0] * (0.5f * v[1] * (1.0f + erf_fast(v[1] * 0.70710678118654752440f)));
-                        y[1] = v[2] * (0.5f * v[3] * (1.0f + erf_fast(v[3] * 0.70710678118654752440f)));
-                        rint_div_zp_n<2>(y, od, oi, oz, r);
+                        float r[2];
+                        const float va[2] = {v[0], v[2]}, ga[2] = {v[1], v[3]};
+                        geglu_codes_n<2>(va, ga, od, oi, oz, r);
                         uint32_t w = 0;
                         w = __builtin_amdgcn_cvt_pk_u8_f32(clampf(r[0], 0.f, oq), 0, w);
                         w = __builtin_amdgcn_cvt_pk_u8_f32(clampf(r[1], 0.f, oq), 1, w);

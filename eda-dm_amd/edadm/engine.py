@@ -421,10 +421,13 @@ class Engine:
         if self.emb_r is not None and id(qm) in self.emb_r:
             r = self.emb_r[id(qm)]
             return r if self._emb_n is None else r[:self._emb_n]
-        L = self.L(qm)
-        if L.mode != "i8":
-            return self._gemm(L, self._quant(L, ops.silu(emb)), emb.shape[0])
-        return self._gemm(L, ops.silu_quant_i8(emb, L.qp), emb.shape[0])
+        return self._silu_lin(self.L(qm), emb)
+
+    def _silu_lin(self, L, x):
+        """silu -> the layer's activation quantiser -> contraction (fused producer on the int8 path)"""
+        if L.mode != "i8" or L.split:
+            return self._gemm(L, self._quant(L, ops.silu(x)), x.shape[0])
+        return self._gemm(L, ops.silu_quant_i8(x, L.qp), x.shape[0])
 
     def emb_tables(self, ts_all, steps):
         """The time-embedding path of every step of a fixed schedule in one pass: ts_all = the `steps` timestep vectors
@@ -441,7 +444,7 @@ class Engine:
             temb = self._sinusoid(ts_all, net.model_channels, ddpm=False)
             h0 = self.lin(net.time_embed[0], temb)
             L2 = self.L(net.time_embed[2])
-            emb = self._gemm(L2, ops.silu_quant_i8(h0, L2.qp), M)
+            emb = self._silu_lin(L2, h0)
             outs, layout, off = [], {}, 0
             for m in net.modules():
                 layers = getattr(m, "emb_layers", None)
@@ -591,7 +594,7 @@ class Engine:
         temb = self._sinusoid(t, net.ch, ddpm=True)
         h0 = self.lin(net.temb.dense[0], temb)
         L1 = self.L(net.temb.dense[1])
-        temb = self._gemm(L1, ops.silu_quant_i8(h0, L1.qp), B)
+        temb = self._silu_lin(L1, h0)
         xh = ops.nchw_to_nhwc(x.contiguous())
         hs = [self.first_conv(net.conv_in, xh)]
         for lvl, stage in enumerate(net.down):
@@ -784,6 +787,9 @@ class Engine:
         if getattr(L0, "geglu_interleaved", False):
             g = self._gemm(L0, of, B * N, out_mode=3, oqp=L2.qp)
         else:
+            if L2.mode != "i8" or L2.split:
+                raise NotImplementedError("ff.net.2 with exact-f16 weights (an 8-bit layer spanning [-127, 128]) behind GEGLU: "
+                                          "no configuration of the reference produces it (W8 is shipped for the DDPM UNet only)")
             g = ops.geglu_quant_i8(self._gemm(L0, of, B * N), L2.qp)
         if out_qp is not None and L2.mode == "i8" and len(L2.segs) == 1:
             # the block output only feeds proj_out's activation quantizer: ff.net.2 emits that operand
@@ -864,7 +870,7 @@ class Engine:
             temb = self._sinusoid(timesteps, net.model_channels, ddpm=False)
             h0 = self.lin(net.time_embed[0], temb)
             L2 = self.L(net.time_embed[2])
-            emb = self._gemm(L2, ops.silu_quant_i8(h0, L2.qp), B)
+            emb = self._silu_lin(L2, h0)
         ctx = None if context is None else context.contiguous().float()
         h = ops.nchw_to_nhwc(x.contiguous().float())
         hs = []

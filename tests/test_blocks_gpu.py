@@ -437,7 +437,7 @@ def test_whole_network_code_census(golden, kind, fixture):
     # ... which the (random-weight, 4-bit) network then spreads: a tenth of the downstream codes end up one step apart, a few %
     # further; the output stays within a few % of range at the worst element
     assert tot1 / tot <= 0.2 and totn / tot <= 0.06
-    assert float(err.mean()) <= 5e-3 and float(err.max()) <= 6e-2
+    assert float(err.mean()) <= 1e-2 and float(err.max()) <= 8e-2
 
 
 # ------------------------------------------------------------------------------------------------ G10 generalized_steps

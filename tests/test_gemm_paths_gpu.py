@@ -88,7 +88,12 @@ def test_qgemm_quantised_outputs(ops, M, N, K):
     codes_close(h.float(), ops.quant_f16(f32, qp).float(), "f16")
     # the fused GEGLU reads interleaved (value, gate) columns; the stand-alone kernel takes [values | gates]
     split = torch.cat([f32[:, 0::2], f32[:, 1::2]], 1).contiguous()
-    codes_close(ops.qgemm_i8_q(Ad, Wd, M, N, K, sd, bd, 3, qp), ops.geglu_quant_i8(split, qp), "geglu")
+    fused, alone = ops.qgemm_i8_q(Ad, Wd, M, N, K, sd, bd, 3, qp), ops.geglu_quant_i8(split, qp)
+    codes_close(fused, alone, "geglu")
+    # the epilogue's fast GELU (Abramowitz-Stegun erf + reciprocal multiply) is accepted only outside a guard band around
+    # the rounding boundaries, inside it the exact form (erf to < 1 ulp, IEEE division) decides: the codes are those of
+    # the stand-alone kernel, which only knows the exact form -- every one of them
+    assert torch.equal(fused, alone), int((fused != alone).sum())
 
 
 @pytest.mark.parametrize("B,HW,N,K", [(14, 4096, 192, 1728), (56, 1024, 384, 1152), (512, 64, 192, 1216)])
