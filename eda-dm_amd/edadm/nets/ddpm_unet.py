@@ -11,6 +11,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from edadm import train_ops as T     # GroupNorm (+ SiLU), softmax, attention products on libedadm.so (forward and backward)
+
 
 def get_timestep_embedding(timesteps, embedding_dim):
     """sin | cos sinusoidal table (diffusion.py:6-24)."""
@@ -25,11 +27,18 @@ def get_timestep_embedding(timesteps, embedding_dim):
 
 
 def nonlinearity(x):
-    return x * torch.sigmoid(x)
+    return T.silu(x)                                # x * sigmoid(x) (diffusion.py:27-29)
+
+
+class _GroupNorm(nn.GroupNorm):
+    """nn.GroupNorm on the HIP forward / backward kernels (same parameters, same state_dict keys)."""
+
+    def forward(self, x, silu=False):
+        return T.group_norm(x, self, silu=silu)
 
 
 def Normalize(in_channels):
-    return nn.GroupNorm(num_groups=32, num_channels=in_channels, eps=1e-6, affine=True)
+    return _GroupNorm(num_groups=32, num_channels=in_channels, eps=1e-6, affine=True)
 
 
 class Upsample(nn.Module):
@@ -78,9 +87,9 @@ class ResnetBlock(nn.Module):
     def forward(self, x, temb=None, split=0):
         if temb is None:
             x, temb = x
-        h = self.conv1(nonlinearity(self.norm1(x)))
+        h = self.conv1(self.norm1(x, silu=True))
         h = h + self.temb_proj(nonlinearity(temb))[:, :, None, None]
-        h = self.conv2(self.dropout(nonlinearity(self.norm2(h))))
+        h = self.conv2(self.dropout(self.norm2(h, silu=True)))
         if self.in_channels != self.out_channels:
             if self.use_conv_shortcut:
                 x = self.conv_shortcut(x)
@@ -103,9 +112,9 @@ class AttnBlock(nn.Module):
         h_ = self.norm(x)
         q, k, v = self.q(h_), self.k(h_), self.v(h_)
         b, c, h, w = q.shape
-        w_ = torch.bmm(q.reshape(b, c, h * w).permute(0, 2, 1), k.reshape(b, c, h * w)) * (int(c) ** (-0.5))
-        w_ = F.softmax(w_, dim=2).permute(0, 2, 1)
-        h_ = torch.bmm(v.reshape(b, c, h * w), w_).reshape(b, c, h, w)
+        qt, kt = T.transpose12(q.reshape(b, c, h * w)), T.transpose12(k.reshape(b, c, h * w))      # [b, hw, c]
+        p = T.softmax(T.bmm_nt(qt, kt, int(c) ** (-0.5)))                  # softmax_j(q_i . k_j / sqrt(c))
+        h_ = T.bmm_nt(v.reshape(b, c, h * w), p).reshape(b, c, h, w)      # h[c, i] = sum_j v[c, j] p[i, j]
         return x + self.proj_out(h_)
 
 
@@ -197,4 +206,4 @@ class Model(nn.Module):
                     h = stage.attn[j](h)
             if lvl != 0:
                 h = stage.upsample(h)
-        return self.conv_out(nonlinearity(self.norm_out(h)))
+        return self.conv_out(self.norm_out(h, silu=True))

@@ -15,6 +15,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from edadm import train_ops as T     # GroupNorm (+ SiLU), LayerNorm, GEGLU, softmax, attention products on libedadm.so
+
 
 # ----------------------------------------------------------------------------- small helpers
 def checkpoint(func, inputs, params=None, flag=False):
@@ -41,7 +43,30 @@ def zero_module(module):
 
 class GroupNorm32(nn.GroupNorm):
     def forward(self, x):
-        return super().forward(x.float()).type(x.dtype)
+        return T.group_norm(x, self)
+
+
+class _GroupNorm(nn.GroupNorm):
+    """nn.GroupNorm on the HIP forward / backward kernels (same parameters, same state_dict keys)."""
+
+    def forward(self, x):
+        return T.group_norm(x, self)
+
+
+class _LayerNorm(nn.LayerNorm):
+    def forward(self, x):
+        return T.layer_norm(x, self)
+
+
+class _SiLU(nn.SiLU):
+    def forward(self, x):
+        return T.silu(x)
+
+
+def norm_silu(seq, x):
+    """(GroupNorm, SiLU) at the head of `seq` in ONE pass (the fused K5 of the training graph)."""
+    assert isinstance(seq[0], nn.GroupNorm) and isinstance(seq[1], nn.SiLU)
+    return T.group_norm(x, seq[0], silu=True)
 
 
 def normalization(channels):
@@ -49,7 +74,7 @@ def normalization(channels):
 
 
 def Normalize(in_channels):
-    return nn.GroupNorm(num_groups=32, num_channels=in_channels, eps=1e-6, affine=True)
+    return _GroupNorm(num_groups=32, num_channels=in_channels, eps=1e-6, affine=True)
 
 
 def timestep_embedding(timesteps, dim, max_period=10000, repeat_only=False):
@@ -80,8 +105,7 @@ class GEGLU(nn.Module):
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
     def forward(self, x):
-        a, gate = self.proj(x).chunk(2, dim=-1)
-        return a * F.gelu(gate)
+        return T.geglu(self.proj(x))                # a * gelu(gate), (a | gate) = proj(x).chunk(2, -1)
 
 
 class FeedForward(nn.Module):
@@ -101,12 +125,12 @@ class CrossQKMatMul(nn.Module):
         self.scale = scale
 
     def forward(self, q, k):
-        return torch.einsum("bid,bjd->bij", q, k) * self.scale
+        return T.bmm_nt(q, k, self.scale)           # einsum("bid,bjd->bij") * scale
 
 
 class CrossSMVMatMul(nn.Module):
     def forward(self, attn, v):
-        return torch.einsum("bij,bjd->bid", attn, v)
+        return T.bmm_nt(attn, T.transpose12(v))     # einsum("bij,bjd->bid")
 
 
 def split_heads(t, h):
@@ -139,7 +163,7 @@ class CrossAttention(nn.Module):
         if mask is not None:
             m = mask.reshape(mask.shape[0], -1)[:, None, :].repeat_interleave(self.heads, 0)
             sim.masked_fill_(~m, -torch.finfo(sim.dtype).max)
-        out = self.smv_matmul(sim.softmax(dim=-1), v)
+        out = self.smv_matmul(T.softmax(sim), v)
         return self.to_out(merge_heads(out, self.heads))
 
 
@@ -150,7 +174,7 @@ class BasicTransformerBlock(nn.Module):
         self.ff = FeedForward(dim, dropout=dropout, glu=gated_ff)
         self.attn2 = CrossAttention(query_dim=dim, context_dim=context_dim, heads=n_heads, dim_head=d_head,
                                     dropout=dropout)
-        self.norm1, self.norm2, self.norm3 = nn.LayerNorm(dim), nn.LayerNorm(dim), nn.LayerNorm(dim)
+        self.norm1, self.norm2, self.norm3 = _LayerNorm(dim), _LayerNorm(dim), _LayerNorm(dim)
         self.checkpoint = checkpoint
 
     def forward(self, x, context=None):
@@ -235,7 +259,7 @@ class ResBlock(TimestepBlock):
         self.out_channels = out_channels or channels
         self.use_conv, self.use_checkpoint = use_conv, use_checkpoint
         self.use_scale_shift_norm = use_scale_shift_norm
-        self.in_layers = nn.Sequential(normalization(channels), nn.SiLU(),
+        self.in_layers = nn.Sequential(normalization(channels), _SiLU(),
                                        conv_nd(dims, channels, self.out_channels, 3, padding=1))
         self.updown = up or down
         if up:
@@ -245,9 +269,9 @@ class ResBlock(TimestepBlock):
         else:
             self.h_upd = self.x_upd = nn.Identity()
         self.emb_layers = nn.Sequential(
-            nn.SiLU(), linear(emb_channels, 2 * self.out_channels if use_scale_shift_norm else self.out_channels))
+            _SiLU(), linear(emb_channels, 2 * self.out_channels if use_scale_shift_norm else self.out_channels))
         self.out_layers = nn.Sequential(
-            normalization(self.out_channels), nn.SiLU(), nn.Dropout(p=dropout),
+            normalization(self.out_channels), _SiLU(), nn.Dropout(p=dropout),
             zero_module(conv_nd(dims, self.out_channels, self.out_channels, 3, padding=1)))
         if self.out_channels == channels:
             self.skip_connection = nn.Identity()
@@ -263,11 +287,11 @@ class ResBlock(TimestepBlock):
 def resblock_forward(blk, x, emb, split=0):
     """Shared by ResBlock and qdiff.QuantResBlock (openaimodel.py:248-278, quant_block.py:86-116)."""
     if blk.updown:
-        h = blk.in_layers[:-1](x)
+        h = norm_silu(blk.in_layers, x)
         h, x = blk.h_upd(h), blk.x_upd(x)
         h = blk.in_layers[-1](h)
     else:
-        h = blk.in_layers(x)
+        h = blk.in_layers[-1](norm_silu(blk.in_layers, x))
     e = blk.emb_layers(emb).type(h.dtype)
     while e.dim() < h.dim():
         e = e[..., None]
@@ -275,7 +299,7 @@ def resblock_forward(blk, x, emb, split=0):
         scale, shift = torch.chunk(e, 2, dim=1)
         h = blk.out_layers[1:](blk.out_layers[0](h) * (1 + scale) + shift)
     else:
-        h = blk.out_layers(h + e)
+        h = blk.out_layers[2:](norm_silu(blk.out_layers, h + e))
     if split > 0:
         return blk.skip_connection(x, split=split) + h
     return blk.skip_connection(x) + h
@@ -287,12 +311,12 @@ class QKMatMul(nn.Module):
         self.scale = None
 
     def forward(self, q, k):
-        return torch.einsum("bct,bcs->bts", q * self.scale, k * self.scale)
+        return T.bmm_nt(T.transpose12(q * self.scale), T.transpose12(k * self.scale))     # einsum("bct,bcs->bts")
 
 
 class SMVMatMul(nn.Module):
     def forward(self, weight, v):
-        return torch.einsum("bts,bcs->bct", weight, v)
+        return T.bmm_nt(v, weight)                  # einsum("bts,bcs->bct")
 
 
 class QKVAttentionLegacy(nn.Module):
@@ -306,7 +330,7 @@ class QKVAttentionLegacy(nn.Module):
         ch = width // (3 * self.n_heads)
         q, k, v = qkv.reshape(bs * self.n_heads, ch * 3, length).split(ch, dim=1)
         self.qkv_matmul.scale = 1 / math.sqrt(math.sqrt(ch))
-        weight = torch.softmax(self.qkv_matmul(q, k).float(), dim=-1).type(qkv.dtype)
+        weight = T.softmax(self.qkv_matmul(q, k))
         return self.smv_matmul(weight, v).reshape(bs, -1, length)
 
 
@@ -371,7 +395,7 @@ class UNetModel(nn.Module):
         self.predict_codebook_ids = n_embed is not None
         self.split_shortcut = False
         mc, ted = model_channels, model_channels * 4
-        self.time_embed = nn.Sequential(linear(mc, ted), nn.SiLU(), linear(ted, ted))
+        self.time_embed = nn.Sequential(linear(mc, ted), _SiLU(), linear(ted, ted))
         if num_classes is not None:
             self.label_emb = nn.Embedding(num_classes, ted)
 
@@ -423,7 +447,7 @@ class UNetModel(nn.Module):
                                   else Upsample(ch, conv_resample, dims=dims, out_channels=ch))
                     ds //= 2
                 self.output_blocks.append(TimestepEmbedSequential(*layers))
-        self.out = nn.Sequential(normalization(ch), nn.SiLU(),
+        self.out = nn.Sequential(normalization(ch), _SiLU(),
                                  zero_module(conv_nd(dims, mc, out_channels, 3, padding=1)))
         if self.predict_codebook_ids:
             self.id_predictor = nn.Sequential(normalization(ch), conv_nd(dims, mc, n_embed, 1))
@@ -442,4 +466,4 @@ class UNetModel(nn.Module):
             split = h.shape[1] if self.split_shortcut else 0
             h = module(torch.cat([h, hs.pop()], dim=1), emb, context, split=split)
         h = h.type(x.dtype)
-        return self.id_predictor(h) if self.predict_codebook_ids else self.out(h)
+        return self.id_predictor(h) if self.predict_codebook_ids else self.out[2:](norm_silu(self.out, h))

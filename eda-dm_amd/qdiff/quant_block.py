@@ -13,6 +13,7 @@ from qdiff.quant_layer import QuantModule, UniformAffineQuantizer, StraightThrou
 from edadm.nets.ldm_unet import (AttentionBlock, ResBlock, TimestepBlock, QKMatMul, SMVMatMul,
                                  BasicTransformerBlock, resblock_forward, split_heads, merge_heads)
 from edadm.nets.ddpm_unet import ResnetBlock, AttnBlock, nonlinearity
+from edadm import train_ops as T
 
 logger = logging.getLogger(__name__)
 
@@ -70,9 +71,9 @@ class QuantQKMatMul(BaseQuantBlock):
         self.act_quantizer_k = UniformAffineQuantizer(**act_quant_params)
 
     def forward(self, q, k):
-        if self.use_act_quant:
-            return th.einsum("bct,bcs->bts", self.act_quantizer_q(q * self.scale), self.act_quantizer_k(k * self.scale))
-        return th.einsum("bct,bcs->bts", q * self.scale, k * self.scale)
+        if self.use_act_quant:                      # einsum("bct,bcs->bts")
+            return T.bmm_nt(T.transpose12(self.act_quantizer_q(q * self.scale)), T.transpose12(self.act_quantizer_k(k * self.scale)))
+        return T.bmm_nt(T.transpose12(q * self.scale), T.transpose12(k * self.scale))
 
     def set_quant_state(self, weight_quant: bool = False, act_quant: bool = False):
         self.use_act_quant = act_quant
@@ -88,9 +89,9 @@ class QuantSMVMatMul(BaseQuantBlock):
         self.act_quantizer_w = UniformAffineQuantizer(**pw)
 
     def forward(self, weight, v):
-        if self.use_act_quant:
-            return th.einsum("bts,bcs->bct", self.act_quantizer_w(weight), self.act_quantizer_v(v))
-        return th.einsum("bts,bcs->bct", weight, v)
+        if self.use_act_quant:                      # einsum("bts,bcs->bct")
+            return T.bmm_nt(self.act_quantizer_v(v), self.act_quantizer_w(weight))
+        return T.bmm_nt(v, weight)
 
     def set_quant_state(self, weight_quant: bool = False, act_quant: bool = False):
         self.use_act_quant = act_quant
@@ -121,18 +122,18 @@ def cross_attn_forward(self, x, context=None, mask=None):
     h = self.heads
     context = x if context is None else context
     q, k, v = (split_heads(t, h) for t in (self.to_q(x), self.to_k(context), self.to_v(context)))
-    if self.use_act_quant:
-        sim = th.einsum('bid,bjd->bij', self.act_quantizer_q(q), self.act_quantizer_k(k)) * self.scale
+    if self.use_act_quant:                          # einsum('bid,bjd->bij') * scale
+        sim = T.bmm_nt(self.act_quantizer_q(q), self.act_quantizer_k(k), self.scale)
     else:
-        sim = th.einsum('bid,bjd->bij', q, k) * self.scale
+        sim = T.bmm_nt(q, k, self.scale)
     if mask is not None:
         m = mask.reshape(mask.shape[0], -1)[:, None, :].repeat_interleave(h, 0)
         sim.masked_fill_(~m, -th.finfo(sim.dtype).max)
-    attn = sim.softmax(dim=-1)
-    if self.use_act_quant:
-        out = th.einsum('bij,bjd->bid', self.act_quantizer_w(attn), self.act_quantizer_v(v))
+    attn = T.softmax(sim)
+    if self.use_act_quant:                          # einsum('bij,bjd->bid')
+        out = T.bmm_nt(self.act_quantizer_w(attn), T.transpose12(self.act_quantizer_v(v)))
     else:
-        out = th.einsum('bij,bjd->bid', attn, v)
+        out = T.bmm_nt(attn, T.transpose12(v))
     return self.to_out(merge_heads(out, h))
 
 
@@ -190,9 +191,9 @@ class QuantResnetBlock(BaseQuantBlock):
     def forward(self, x, temb=None, split=0):
         if split != 0:
             self.split = split
-        h = self.conv1(nonlinearity(self.norm1(x)))
+        h = self.conv1(self.norm1(x, silu=True))
         h = h + self.temb_proj(nonlinearity(temb))[:, :, None, None]
-        h = self.conv2(self.dropout(nonlinearity(self.norm2(h))))
+        h = self.conv2(self.dropout(self.norm2(h, silu=True)))
         if self.in_channels != self.out_channels:
             x = self.conv_shortcut(x) if self.use_conv_shortcut else self.nin_shortcut(x, split=self.split)
         return x + h
@@ -216,16 +217,16 @@ class QuantAttnBlock(BaseQuantBlock):
         h_ = self.norm(x)
         q, k, v = self.q(h_), self.k(h_), self.v(h_)
         b, c, h, w = q.shape
-        q = q.reshape(b, c, h * w).permute(0, 2, 1)
+        q = T.transpose12(q.reshape(b, c, h * w))                  # [b, hw, c]
         k = k.reshape(b, c, h * w)
         if self.use_act_quant:
             q, k = self.act_quantizer_q(q), self.act_quantizer_k(k)
-        w_ = th.bmm(q, k) * (int(c) ** (-0.5))
-        w_ = nn.functional.softmax(w_, dim=2).permute(0, 2, 1)
+        p = T.softmax(T.bmm_nt(q, T.transpose12(k), int(c) ** (-0.5)))      # [b, i, j]: the reference's w_ before its permute
         v = v.reshape(b, c, h * w)
         if self.use_act_quant:
-            v, w_ = self.act_quantizer_v(v), self.act_quantizer_w(w_)
-        h_ = th.bmm(v, w_).reshape(b, c, h, w)
+            # the reference quantises w_.permute(0, 2, 1): a per-tensor quantiser, so the codes are those of p
+            v, p = self.act_quantizer_v(v), self.act_quantizer_w(p)
+        h_ = T.bmm_nt(v, p).reshape(b, c, h, w)                   # bmm(v, w_): h[c, i] = sum_j v[c, j] p[i, j]
         return x + self.proj_out(h_)
 
 

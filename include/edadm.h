@@ -324,6 +324,28 @@ int edadm_unpack_w4(const uint8_t* packed, const float* zp, int8_t* out, int64_t
                     void* stream);
 int edadm_pack_w4(const int8_t* w, const float* zp, uint8_t* packed, int64_t rows, int64_t cols, void* stream);
 
+/* ---- H1 training-graph ops: forward and input-gradient of the non-contraction ops of the calibration graph, fp32, on the
+ * reference's layouts (csrc/train_ops.hip).  GroupNorm (+ SiLU) over NCHW, `stats` = [B * G][2] (mean, rstd) written by the
+ * forward and read by the backward (ddim/models/diffusion.py:27-35, openaimodel.py:215-223, quant_block.py:86-116,321-348);
+ * LayerNorm over [rows][C], C <= 4096 (attention.py:201-203); GEGLU over [rows][2 inner] (attention.py:37-45); SiLU and
+ * softmax gradients (quant_block.py:204-235); a batched [Z][R][C] -> [Z][C][R] transpose for the K-major operands of the
+ * attention products' gradients.  The normalisation affines receive no gradient: the loop never trains them
+ * (block_recon.py:44-108). */
+int edadm_gn_fwd_nchw(const float* x, const float* gamma, const float* beta, float* y, float* stats, int64_t B, int64_t C,
+                      int64_t HW, int G, float eps, int silu, void* stream);
+int edadm_gn_bwd_nchw(const float* dy, const float* x, const float* gamma, const float* beta, const float* stats, float* dx,
+                      int64_t B, int64_t C, int64_t HW, int G, int silu, void* stream);
+int edadm_ln_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats, int64_t rows, int64_t C,
+                 float eps, void* stream);
+int edadm_ln_bwd(const float* dy, const float* x, const float* gamma, const float* stats, float* dx, int64_t rows, int64_t C,
+                 void* stream);
+int edadm_geglu_fwd(const float* h, float* out, int64_t rows, int64_t inner, void* stream);
+int edadm_geglu_bwd(const float* dy, const float* h, float* dh, int64_t rows, int64_t inner, void* stream);
+int edadm_silu_bwd(const float* dy, const float* x, float* dx, int64_t n, void* stream);
+int edadm_softmax_bwd(const float* dp, const float* p, float* dx, int64_t rows, int64_t cols, void* stream);
+int edadm_softmax_fwd_any(const float* s, float* out, int64_t rows, int64_t cols, void* stream);
+int edadm_transpose_batched_f32(const float* x, float* out, int64_t Z, int64_t R, int64_t C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
