@@ -135,7 +135,10 @@ def test_training_graph_has_no_stock_norm_or_blas_kernels(golden):
         torch.cuda.synchronize()
     names = [e.key for e in prof.key_averages() if getattr(e, "device_time_total", 0) > 0 or getattr(e, "cuda_time_total", 0) > 0]
     kernels = [n for n in names if not n.startswith("aten::") and not n.startswith("hip") and not n.startswith("Memcpy")]
-    bad = [n for n in kernels if any(k in n for k in ("Cijk_", "GroupNorm", "group_norm", "layer_norm", "LayerNorm", "silu",
-                                                       "Gelu", "gelu", "softmax", "Softmax", "rocblas", "hipblas"))]
+    stock = ("GroupNorm", "group_norm", "layer_norm", "LayerNorm", "RowwiseMoments", "silu", "Gelu", "gelu", "softmax", "Softmax")
+    bad = [n for n in kernels if "Cijk_" in n or "rocblas" in n or "hipblas" in n
+           or (("at::native" in n or "at_cuda" in n) and any(k in n for k in stock))]
+    ours = [n for n in kernels if n.startswith(("k_gn_", "k_ln_", "k_geglu_", "k_silu", "k_softmax", "k_transpose_batched"))]
+    assert len(ours) >= 6, ours
     print("device kernels of one forward+backward:", len(kernels))
     assert not bad, bad
