@@ -1505,6 +1505,225 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
 }
 
 #if EDADM_GEMM_DT == 0
+// ---- direct 3x3 convolution (stride 1, pad 1) for the long-K int8 layers.
+// The implicit-GEMM kernels above fetch every int8 activation nine times (once per tap) through L2 into LDS, and at
+// 256 x 192 tiles that intake (44 B/clk/CU), not the MFMA, sets their pace.  Here a workgroup owns 256 consecutive
+// output pixels (whole image rows, or whole images at the 8x8 level) and keeps the INPUT PATCH of one 64-channel
+// chunk -- the pixels plus a one-pixel halo, 64 bytes each -- resident in LDS: the nine taps of the chunk read their A
+// fragments straight from the patch at a shifted pixel index, so an activation byte crosses L2 -> LDS once per chunk
+// instead of nine times, and only the weights stream: a step is one filter row of a chunk (3 taps x 64 channels
+// = 36 MFMAs per wave between barriers), its 3 x BN x 64 B weight slab arrives by LDS-DMA into a two-slot ring while
+// the previous step computes, the next chunk's patch into the other of two patch buffers.
+//   LDS: patch pixel P, logical 16-byte chunk c at P * 64 + ((c ^ ((P >> 2) & 3)) << 4) -- the swizzle of the 64-byte-row
+//   kernels keyed by the PATCH pixel index, so 16 lanes on consecutive pixels hit 16 distinct 16-byte slots for every tap
+//   shift; the weight slab is stored pre-swizzled by the host (edadm_conv3_pack_w) and copied lane-linearly.
+//   vmcnt is hand-counted: every wave issues exactly 5 weight pieces per step and PPW (3 or 4) patch pieces per chunk
+//   (surplus pieces repeat the last one: same bytes to the same place), weights before patch, so the wait in front of a
+//   step is vmcnt(PPW) when only the next chunk's patch may stay in flight and vmcnt(0) otherwise.
+// Integer accumulation: the order of taps and chunks does not change a bit of the result.
+template <int TN>
+__global__ void __launch_bounds__(512)
+k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, int64_t M, int64_t N, int B, int H, int W,
+               int Cin, int padval, const float* __restrict__ scale, const float* __restrict__ bias,
+               const float* __restrict__ rowadd, int64_t rows_per_batch, const float* __restrict__ residual, int64_t ldr,
+               float* __restrict__ out, int64_t ldo) {
+    constexpr int TM = 2, BM = 256, BN = 64 * TN;
+    constexpr int PATCH_BYTES = 32 * 1024;                  // 8 waves x 4 pieces x 1 KiB >= 16 * ceil(NP / 16) * 64
+    constexpr int SLAB_BYTES = 3 * BN * 64;                 // one filter row of one 64-channel chunk
+    constexpr int RA = BM / 16 + 1;
+    constexpr int EC_BYTES = (2 + RA) * BN * 4 + 16;
+    constexpr int SMEM_BYTES = 2 * PATCH_BYTES + 2 * SLAB_BYTES + EC_BYTES;
+    __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM_BYTES];
+    float* ec = reinterpret_cast<float*>(smem + 2 * PATCH_BYTES + 2 * SLAB_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int64_t tile = blockIdx.y;
+    const int64_t m0 = tile * BM, n0 = (int64_t)blockIdx.x * BN;
+    const int HW = H * W;
+    // tile geometry: TR image rows of IMGS images starting at (b0, y0)
+    const int IMGS = HW >= BM ? 1 : BM / HW;
+    const int TR = HW >= BM ? BM / W : H;
+    const int tiles_per_img = HW >= BM ? HW / BM : 1;
+    const int b0 = (int)(HW >= BM ? tile / tiles_per_img : tile * IMGS);
+    const int y0 = HW >= BM ? (int)(tile % tiles_per_img) * TR : 0;
+    const int PR = TR + 2, PW = W + 2;
+    const int NP = IMGS * PR * PW;
+    const int pieces = (NP + 15) >> 4;
+    const int PPW = (pieces + 7) >> 3;                      // 3 or 4 (checked by the launcher)
+    const int NC = Cin >> 6;
+    const uint8_t* pad_row = g_pad_rows + (int)(uint8_t)padval * 64;
+
+    // ---- this lane's patch pieces: piece q covers patch pixels 16 q .. 16 q + 15, lane -> pixel 16 q + lane / 4,
+    // physical chunk lane % 4 (= logical chunk (lane % 4) ^ ((P >> 2) & 3) of the source pixel)
+    int psrc[4];                                            // byte offset of the source chunk at channel 0, -1 = padding
+    uint32_t pdst[4];                                       // LDS byte offset of the piece inside a patch buffer
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int q = wave + 8 * i;
+        if (q > pieces - 1) q = pieces - 1;
+        const int P = q * 16 + (lane >> 2);
+        const int sc = (lane & 3) ^ ((P >> 2) & 3);
+        pdst[i] = (uint32_t)q * 1024u;
+        psrc[i] = -1;
+        if (P < NP) {
+            const int img = P / (PR * PW), rem = P - img * (PR * PW);
+            const int py = rem / PW, px = rem - py * PW;
+            const int y = y0 + py - 1, x = px - 1;
+            if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+                psrc[i] = (((b0 + img) * H + y) * W + x) * Cin + sc * 16;
+        }
+    }
+    auto issue_patch = [&](int c) {
+        const uint32_t base = lds0 + (uint32_t)((c & 1) * PATCH_BYTES);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < PPW) {
+                const uint8_t* src = psrc[i] >= 0 ? A + (int64_t)psrc[i] + c * 64 : pad_row + (lane & 3) * 16;
+                glds16(src, base + pdst[i]);
+            }
+        }
+    };
+    // ---- weight slab of step s = 3 c + ky: 36 (TN = 3) pieces of 1 KiB, 5 per wave (the last ones repeat piece 35)
+    constexpr int WP = SLAB_BYTES / 1024, WPW = (WP + 7) / 8;
+    const uint8_t* wbase = Wdc + (int64_t)blockIdx.x * NC * 3 * SLAB_BYTES;
+    auto issue_w = [&](int s) {
+        const uint8_t* slab = wbase + (int64_t)s * SLAB_BYTES;
+        const uint32_t base = lds0 + (uint32_t)(2 * PATCH_BYTES + (s & 1) * SLAB_BYTES);
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) {
+            int q = wave + 8 * i;
+            if (q > WP - 1) q = WP - 1;
+            glds16(slab + q * 1024 + lane * 16, base + (uint32_t)q * 1024u);
+        }
+    };
+    // ---- this lane's output pixels -> patch pixel index of tap (0, 0)
+    int pp[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int p = wm * 64 + i * 32 + fr;                // pixel of the tile, NHWC order
+        const int img = p / (TR * W), rem = p - img * (TR * W);
+        const int yl = rem / W, x = rem - yl * W;
+        pp[i] = (img * PR + yl) * PW + x;
+    }
+
+    typename Acc<0>::type acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+
+    const int S = 3 * NC;
+    issue_w(0);
+    issue_patch(0);
+    stage_epilogue_consts<BN, RA>(ec, tid, (int)blockDim.x, m0, n0, M, N, scale, bias, rowadd, rows_per_batch, 1.0f, nullptr);
+    for (int s = 0; s < S; ++s) {
+        const int c = s / 3, ky = s - 3 * c;
+        // B(s) (and patch(c) when ky == 0) have landed once at most the next chunk's patch pieces are still in flight
+        if (ky == 1 && c + 1 < NC) {
+            if (PPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + 1 < S) issue_w(s + 1);
+        if (ky == 0 && c + 1 < NC) issue_patch(c + 1);
+        const uint8_t* Ps = smem + (c & 1) * PATCH_BYTES;
+        const uint8_t* Ws = smem + 2 * PATCH_BYTES + (s & 1) * SLAB_BYTES;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int toff = ky * PW + kx;
+            int pa[TM], sw[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int P = pp[i] + toff;
+                pa[i] = P * 64;
+                sw[i] = (P >> 2) & 3;
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int lc = 2 * ks + fh;
+                uint4 fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const uint4*>(Ps + pa[i] + ((lc ^ sw[i]) << 4));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = wn * (TN * 32) + j * 32 + fr;
+                    fb[j] = *reinterpret_cast<const uint4*>(Ws + kx * (BN * 64) + n * 64 + ((lc ^ ((n >> 2) & 3)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) mma_step<0>(fa[i], fb[j], acc[i][j]);
+            }
+        }
+    }
+    EpiRegs<TN> er;
+    load_epi_regs<TN, BN>(er, ec, lane, m0, m0 + wm * 64, wn * (TN * 32), rows_per_batch);
+    gemm_epilogue_direct<0, TM, TN>(acc, er, lane, m0 + wm * 64, n0 + wn * (TN * 32), rowadd != nullptr, residual, ldr, out, ldo);
+}
+
+// Weight layout of k_conv3_direct from the engine's [N][ky][kx][ci] int8 filter: [N / BN][Cin / 64][ky][kx][BN][64] with
+// the 16-byte chunks of a row at physical position chunk ^ ((n >> 2) & 3) (n = row inside the BN block).
+__global__ void k_conv3_pack_w(const int8_t* __restrict__ w, int8_t* __restrict__ out, int64_t N, int64_t Cin, int BN) {
+    const int64_t total = N * 9 * Cin / 16;                 // 16-byte chunks
+    const int64_t NC = Cin / 64;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        // destination coordinates
+        int64_t r = i;
+        const int pc = (int)(r & 3); r >>= 2;
+        const int n = (int)(r % BN); r /= BN;
+        const int kx = (int)(r % 3); r /= 3;
+        const int ky = (int)(r % 3); r /= 3;
+        const int64_t c = r % NC, nt = r / NC;
+        const int lc = pc ^ ((n >> 2) & 3);
+        const int64_t src = (((nt * BN + n) * 3 + ky) * 3 + kx) * Cin + c * 64 + lc * 16;
+        reinterpret_cast<uint4*>(out)[i] = *reinterpret_cast<const uint4*>(w + src);
+    }
+}
+extern "C" int edadm_conv3_pack_w(const int8_t* w, int8_t* out, int64_t N, int64_t Cin, void* stream) {
+    if (!w || !out || N <= 0 || Cin <= 0 || N % 192 || Cin % 64 || ((uintptr_t)w & 15) || ((uintptr_t)out & 15)) return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_conv3_pack_w, dim3(edadm_grid(N * 9 * Cin / 16, 256)), dim3(256), 0, (hipStream_t)stream, w, out, N, Cin, 192);
+    return edadm_launch_status();
+}
+extern "C" int edadm_conv3_direct_ok(int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t N) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin % 64 || N % 192 || Cin < 64) return 0;
+    if (W != 8 && W != 16 && W != 32 && W != 64) return 0;
+    const int64_t HW = H * W;
+    if (HW >= 256 ? (HW % 256 != 0) : (256 % HW != 0 || B % (256 / HW) != 0)) return 0;
+    if (B * HW * Cin >= (1ll << 31)) return 0;
+    const int64_t imgs = HW >= 256 ? 1 : 256 / HW, tr = HW >= 256 ? 256 / W : H;
+    const int64_t pieces = (imgs * (tr + 2) * (W + 2) + 15) / 16, ppw = (pieces + 7) / 8;
+    return ppw == 3 || ppw == 4;
+}
+extern "C" int edadm_qconv3_i8_direct(const int8_t* A, const int8_t* Wdc, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t N,
+                                      int padval, const float* scale, const float* bias, const float* rowadd,
+                                      int64_t rows_per_batch, const float* residual, int64_t ldr, float* out, int64_t ldo,
+                                      void* stream) {
+    if (!A || !Wdc || !out || !scale || !edadm_conv3_direct_ok(B, H, W, Cin, N)) return EDADM_EINVAL;
+    if (((uintptr_t)A & 15) || ((uintptr_t)Wdc & 15)) return EDADM_EINVAL;
+    if (rowadd && rows_per_batch < 64) return EDADM_EINVAL;
+    const int64_t M = B * H * W;
+    if (!rowadd) rows_per_batch = M;
+    static bool pad_ready = false;
+    if (!pad_ready) {
+        hipLaunchKernelGGL(k_init_pad_rows, dim3(1), dim3(256), 0, (hipStream_t)stream);
+        pad_ready = true;
+    }
+    hipLaunchKernelGGL((k_conv3_direct<3>), dim3((unsigned)(N / 192), (unsigned)(M / 256)), dim3(512), 0, (hipStream_t)stream,
+                       (const uint8_t*)A, (const uint8_t*)Wdc, M, N, (int)B, (int)H, (int)W, (int)Cin, padval, scale, bias, rowadd,
+                       rows_per_batch, residual, ldr, out, ldo);
+    return edadm_launch_status();
+}
+#endif
+
+#if EDADM_GEMM_DT == 0
 extern "C" int edadm_qgemm_i8_gn(const int8_t* A, int64_t lda, const int8_t* Wt, int64_t ldw, int64_t M, int64_t N,
                                  int64_t K, const int32_t* geom, const float* scale, const float* bias,
                                  const float* rowadd, int64_t rows_per_batch, const float* residual, int64_t ldr,

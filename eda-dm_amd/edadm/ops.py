@@ -430,6 +430,25 @@ def qgemm_i8(A, Wt, M, N, K, scale, bias, out, geom=None, lda=None, ldw=None, ro
     return out
 
 
+def conv3_direct_ok(B, H, W, Cin, N):
+    return bool(lib.load().edadm_conv3_direct_ok(int(B), int(H), int(W), int(Cin), int(N)))
+
+
+def conv3_pack_w(w_i8, N, Cin):
+    """[N][3][3][Cin] int8 filter -> the layout of edadm_qconv3_i8_direct ([N/192][Cin/64][3][3][192][64], chunks swizzled)."""
+    out = torch.empty(N * 9 * Cin, dtype=torch.int8, device=w_i8.device)
+    lib.call("edadm_conv3_pack_w", _p(w_i8, torch.int8), _p(out, torch.int8), int(N), int(Cin), _stream())
+    return out
+
+
+def qconv3_i8_direct(a_nhwc, wdc, B, H, W, Cin, N, padval, scale, bias, out, rowadd=None, rows_per_batch=1, residual=None):
+    """3x3 / stride 1 / pad 1 convolution of the int8 NHWC operand with the input patch resident in LDS (edadm.h)."""
+    lib.call("edadm_qconv3_i8_direct", _p(a_nhwc, torch.int8), _p(wdc, torch.int8), int(B), int(H), int(W), int(Cin), int(N),
+             int(padval), _pf(scale), _pf(bias), _pf(rowadd), int(rows_per_batch), _pf(residual), int(N), _pf(out), int(N),
+             _stream())
+    return out
+
+
 def gemm_f16_nt(A, lda, strideA, Bm, ldb, strideB, batch, M, N, K, alpha, out=None, inner=1, strideA_i=0,
                 strideB_i=0, ldc=None, strideC=None, strideC_i=0):
     """C[z] = alpha * A[z] . B[z]^T, z = outer*inner + head (two-level strides, in elements)."""

@@ -324,6 +324,18 @@ int edadm_unpack_w4(const uint8_t* packed, const float* zp, int8_t* out, int64_t
                     void* stream);
 int edadm_pack_w4(const int8_t* w, const float* zp, uint8_t* packed, int64_t rows, int64_t cols, void* stream);
 
+/* Direct 3x3 convolution (stride 1, pad 1) of the long-K int8 layers (quant_layer.py:406-437 at inference, F.conv2d): the
+ * input patch of a 256-pixel tile stays in LDS per 64-channel chunk, so an activation byte crosses L2 -> LDS once per
+ * chunk instead of once per tap.  Wdc = the filter in the kernel's own layout (edadm_conv3_pack_w from the [N][3][3][Cin]
+ * int8 filter of edadm_qgemm_i8); same epilogue contract as edadm_qgemm_i8 (scale, bias, per-image row-add, fp32 residual).
+ * edadm_conv3_direct_ok: 1 when (B, H, W, Cin, N) is a shape the kernel takes (W in {8,16,32,64}, Cin % 64 == 0,
+ * N % 192 == 0, whole 256-pixel tiles). */
+int edadm_conv3_pack_w(const int8_t* w, int8_t* out, int64_t N, int64_t Cin, void* stream);
+int edadm_conv3_direct_ok(int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t N);
+int edadm_qconv3_i8_direct(const int8_t* A, const int8_t* Wdc, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t N,
+                           int padval, const float* scale, const float* bias, const float* rowadd, int64_t rows_per_batch,
+                           const float* residual, int64_t ldr, float* out, int64_t ldo, void* stream);
+
 /* ---- H1 training-graph ops: forward and input-gradient of the non-contraction ops of the calibration graph, fp32, on the
  * reference's layouts (csrc/train_ops.hip).  GroupNorm (+ SiLU) over NCHW, `stats` = [B * G][2] (mean, rstd) written by the
  * forward and read by the backward (ddim/models/diffusion.py:27-35, openaimodel.py:215-223, quant_block.py:86-116,321-348);

@@ -138,3 +138,39 @@ def test_qgemm_transposed_f16_output(ops, B, Nk, N, K):
     tr = ops.qgemm_i8_q(*args, 4, qp, rows_per_batch=Nk)                   # [B][N][Nk]
     assert tr.shape == (B, N, Nk)
     assert torch.equal(tr, plain.reshape(B, Nk, N).transpose(1, 2))
+
+
+@pytest.mark.parametrize("B,H,W,Cin,N", [(3, 64, 64, 192, 192), (5, 32, 32, 384, 384), (6, 16, 16, 576, 192), (8, 8, 8, 960, 384),
+                                          (2, 64, 64, 64, 192), (4, 32, 32, 1152, 384), (2, 16, 16, 128, 576)])
+def test_direct_conv3_equals_the_implicit_gemm_bit_for_bit(ops, B, H, W, Cin, N):
+    """edadm_qconv3_i8_direct (input patch of a 256-pixel tile resident in LDS, weights streamed) against edadm_qgemm_i8's
+    implicit-GEMM gather on the same operands: integer accumulation, same epilogue arithmetic -> identical fp32 bits, with
+    and without the per-image row-add and the fp32 residual; and against an fp32 reference convolution."""
+    assert ops.conv3_direct_ok(B, H, W, Cin, N)
+    g = torch.Generator().manual_seed(B * H + Cin + N)
+    x = torch.randint(-128, 128, (B, H, W, Cin), generator=g, dtype=torch.int8).cuda()
+    w = torch.randint(-8, 9, (N, 3, 3, Cin), generator=g, dtype=torch.int8).cuda()
+    scale = (torch.rand(N, generator=g) * 1e-3 + 1e-4).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    M, K = B * H * W, 9 * Cin
+    padval = -17
+    rowadd = torch.randn(B, N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).cuda()
+    wdc = ops.conv3_pack_w(w.reshape(N, K), N, Cin)
+    geom = ops.make_geom(B, H, W, Cin, H, W, 3, 3, 1, 1, False, padval)
+    ones, zeros = torch.ones(N, device="cuda"), torch.zeros(N, device="cuda")
+    # exact integer sums first (scale 1, bias 0): against an fp32 convolution in 64-channel slices (every partial sum exact)
+    got = ops.qconv3_i8_direct(x, wdc, B, H, W, Cin, N, padval, ones, zeros, torch.empty(M, N, device="cuda"))
+    xp = F.pad(x.permute(0, 3, 1, 2).float(), (1, 1, 1, 1), value=padval)
+    ref = torch.zeros(B, N, H, W, device="cuda")
+    for c0 in range(0, Cin, 64):
+        ref += F.conv2d(xp[:, c0:c0 + 64].double(), w.permute(0, 3, 1, 2)[:, c0:c0 + 64].double()).float()
+    assert torch.equal(got, ref.permute(0, 2, 3, 1).reshape(M, N))
+    for ra, rs in ((None, None), (rowadd, None), (None, res), (rowadd, res)):
+        if ra is not None and H * W < 64:
+            continue
+        a = ops.qgemm_i8(x, w.reshape(N, K), M, N, K, scale, bias, torch.empty(M, N, device="cuda"), geom=geom, rowadd=ra,
+                         rows_per_batch=H * W, residual=rs)
+        b = ops.qconv3_i8_direct(x, wdc, B, H, W, Cin, N, padval, scale, bias, torch.empty(M, N, device="cuda"), rowadd=ra,
+                                 rows_per_batch=H * W, residual=rs)
+        assert torch.equal(a, b), (ra is not None, rs is not None, float((a - b).abs().max()))
