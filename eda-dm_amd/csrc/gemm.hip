@@ -1524,7 +1524,7 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
 template <int TN>
 __global__ void __launch_bounds__(512)
 k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, int64_t M, int64_t N, int B, int H, int W,
-               int Cin, int padval, const float* __restrict__ scale, const float* __restrict__ bias,
+               int Cin, int padval, int ups, const float* __restrict__ scale, const float* __restrict__ bias,
                const float* __restrict__ rowadd, int64_t rows_per_batch, const float* __restrict__ residual, int64_t ldr,
                float* __restrict__ out, int64_t ldo) {
     constexpr int TM = 2, BM = 256, BN = 64 * TN;
@@ -1572,8 +1572,11 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
             const int img = P / (PR * PW), rem = P - img * (PR * PW);
             const int py = rem / PW, px = rem - py * PW;
             const int y = y0 + py - 1, x = px - 1;
+            // ups: the convolution runs over the nearest-2x upsampled image (H x W are ITS dimensions); pixel (y, x) of
+            // it is pixel (y / 2, x / 2) of the stored tensor -- the upsampled tensor is never written
             if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
-                psrc[i] = (((b0 + img) * H + y) * W + x) * Cin + sc * 16;
+                psrc[i] = ups ? (((b0 + img) * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1)) * Cin + sc * 16
+                              : (((b0 + img) * H + y) * W + x) * Cin + sc * 16;
         }
     }
     auto issue_patch = [&](int c) {
@@ -1703,12 +1706,13 @@ extern "C" int edadm_conv3_direct_ok(int64_t B, int64_t H, int64_t W, int64_t Ci
     return ppw == 3 || ppw == 4;
 }
 extern "C" int edadm_qconv3_i8_direct(const int8_t* A, const int8_t* Wdc, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t N,
-                                      int padval, const float* scale, const float* bias, const float* rowadd,
+                                      int padval, int ups, const float* scale, const float* bias, const float* rowadd,
                                       int64_t rows_per_batch, const float* residual, int64_t ldr, float* out, int64_t ldo,
                                       void* stream) {
     if (!A || !Wdc || !out || !scale || !edadm_conv3_direct_ok(B, H, W, Cin, N)) return EDADM_EINVAL;
     if (((uintptr_t)A & 15) || ((uintptr_t)Wdc & 15)) return EDADM_EINVAL;
     if (rowadd && rows_per_batch < 64) return EDADM_EINVAL;
+    if (ups && ((H | W) & 1)) return EDADM_EINVAL;
     const int64_t M = B * H * W;
     if (!rowadd) rows_per_batch = M;
     static bool pad_ready = false;
@@ -1717,7 +1721,7 @@ extern "C" int edadm_qconv3_i8_direct(const int8_t* A, const int8_t* Wdc, int64_
         pad_ready = true;
     }
     hipLaunchKernelGGL((k_conv3_direct<3>), dim3((unsigned)(N / 192), (unsigned)(M / 256)), dim3(512), 0, (hipStream_t)stream,
-                       (const uint8_t*)A, (const uint8_t*)Wdc, M, N, (int)B, (int)H, (int)W, (int)Cin, padval, scale, bias, rowadd,
+                       (const uint8_t*)A, (const uint8_t*)Wdc, M, N, (int)B, (int)H, (int)W, (int)Cin, padval, ups ? 1 : 0, scale, bias, rowadd,
                        rows_per_batch, residual, ldr, out, ldo);
     return edadm_launch_status();
 }

@@ -347,27 +347,27 @@ class Engine:
             Ho, Wo, pad0 = Hl // 2, Wl // 2, L.pad          # pad 0: DDPM (0,1,0,1) form; pad 1: LDM form
         assert L.mode in ("i8", "f16") and L.cin % 16 == 0, "implicit-GEMM gather needs Cin % 16 == 0"
         padval = (L.zx[0] - 128) if L.mode == "i8" else 0
-        if self.direct_conv and L.mode == "i8" and L.kh == 3 and L.stride == 1 and L.pad == 1 and not ups and \
-                len(L.segs) == 1 and L.K >= self.direct_conv_min_k and ops.conv3_direct_ok(B, H, W, L.cin, L.N) and \
-                (rowadd is None or H * W >= 64):
+        if self.direct_conv and L.mode == "i8" and L.kh == 3 and L.stride == 1 and L.pad == 1 and \
+                len(L.segs) == 1 and L.K >= self.direct_conv_min_k and ops.conv3_direct_ok(B, Hl, Wl, L.cin, L.N) and \
+                (rowadd is None or Hl * Wl >= 64):
             # long-K 3x3 convolution: input patch resident in LDS, each activation byte fetched once per 64-channel chunk
             if not hasattr(L, "wdc"):
                 L.wdc = ops.conv3_pack_w(L.segs[0]["w"], L.N, L.cin)
-            M = B * H * W
+            M = B * Hl * Wl
             out = torch.empty(M, L.N, dtype=torch.float32, device=self.dev)
             res2 = None if residual is None else residual.reshape(M, -1)
             s0 = L.segs[0]
 
             def run():
-                ops.qconv3_i8_direct(a, L.wdc, B, H, W, L.cin, L.N, padval, s0["scale"], L.bias, out, rowadd=rowadd,
-                                     rows_per_batch=H * W, residual=res2)
+                ops.qconv3_i8_direct(a, L.wdc, B, Hl, Wl, L.cin, L.N, padval, s0["scale"], L.bias, out, rowadd=rowadd,
+                                     rows_per_batch=Hl * Wl, residual=res2, ups=ups)
             if self.tap is not None:
                 self.tap.setdefault(L.name, []).append(a.detach().clone())
             if self.prof is not None:
                 self.prof.append((L.mode, L.name, M, L.N, L.K, 2.0 * M * L.N * L.K, run,
                                   self._alg_bytes(L, a, M, 4.0 * M * L.N, residual, "conv3")))
             run()
-            return out.reshape(B, H, W, L.N)
+            return out.reshape(B, Hl, Wl, L.N)
         geom = ops.make_geom(B, H, W, L.cin, Ho, Wo, L.kh, L.kh, L.stride, pad0, ups, padval)
         M = B * Ho * Wo
         out = self._gemm(L, a, M, geom=geom, rowadd=rowadd, rpb=Ho * Wo,

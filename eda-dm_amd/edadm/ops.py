@@ -441,11 +441,12 @@ def conv3_pack_w(w_i8, N, Cin):
     return out
 
 
-def qconv3_i8_direct(a_nhwc, wdc, B, H, W, Cin, N, padval, scale, bias, out, rowadd=None, rows_per_batch=1, residual=None):
+def qconv3_i8_direct(a_nhwc, wdc, B, H, W, Cin, N, padval, scale, bias, out, rowadd=None, rows_per_batch=1, residual=None,
+                     ups=False):
     """3x3 / stride 1 / pad 1 convolution of the int8 NHWC operand with the input patch resident in LDS (edadm.h)."""
     lib.call("edadm_qconv3_i8_direct", _p(a_nhwc, torch.int8), _p(wdc, torch.int8), int(B), int(H), int(W), int(Cin), int(N),
-             int(padval), _pf(scale), _pf(bias), _pf(rowadd), int(rows_per_batch), _pf(residual), int(N), _pf(out), int(N),
-             _stream())
+             int(padval), 1 if ups else 0, _pf(scale), _pf(bias), _pf(rowadd), int(rows_per_batch), _pf(residual), int(N), _pf(out),
+             int(N), _stream())
     return out
 
 

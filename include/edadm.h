@@ -329,11 +329,12 @@ int edadm_pack_w4(const int8_t* w, const float* zp, uint8_t* packed, int64_t row
  * chunk instead of once per tap.  Wdc = the filter in the kernel's own layout (edadm_conv3_pack_w from the [N][3][3][Cin]
  * int8 filter of edadm_qgemm_i8); same epilogue contract as edadm_qgemm_i8 (scale, bias, per-image row-add, fp32 residual).
  * edadm_conv3_direct_ok: 1 when (B, H, W, Cin, N) is a shape the kernel takes (W in {8,16,32,64}, Cin % 64 == 0,
- * N % 192 == 0, whole 256-pixel tiles). */
+ * N % 192 == 0, whole 256-pixel tiles).  H, W are the dimensions the convolution runs over; with ups = 1 the stored
+ * tensor is [B][H/2][W/2][Cin] and its nearest-2x upsample (openaimodel.py:110-118, diffusion.py:41-45) is read in place. */
 int edadm_conv3_pack_w(const int8_t* w, int8_t* out, int64_t N, int64_t Cin, void* stream);
 int edadm_conv3_direct_ok(int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t N);
 int edadm_qconv3_i8_direct(const int8_t* A, const int8_t* Wdc, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t N,
-                           int padval, const float* scale, const float* bias, const float* rowadd, int64_t rows_per_batch,
+                           int padval, int ups, const float* scale, const float* bias, const float* rowadd, int64_t rows_per_batch,
                            const float* residual, int64_t ldr, float* out, int64_t ldo, void* stream);
 
 /* ---- H1 training-graph ops: forward and input-gradient of the non-contraction ops of the calibration graph, fp32, on the

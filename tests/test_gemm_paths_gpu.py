@@ -174,3 +174,26 @@ def test_direct_conv3_equals_the_implicit_gemm_bit_for_bit(ops, B, H, W, Cin, N)
         b = ops.qconv3_i8_direct(x, wdc, B, H, W, Cin, N, padval, scale, bias, torch.empty(M, N, device="cuda"), rowadd=ra,
                                  rows_per_batch=H * W, residual=rs)
         assert torch.equal(a, b), (ra is not None, rs is not None, float((a - b).abs().max()))
+
+
+@pytest.mark.parametrize("B,Hin,Cin,N", [(3, 32, 384, 384), (5, 16, 576, 192), (8, 4, 960, 192), (2, 8, 128, 384)])
+def test_direct_conv3_over_the_folded_upsample(ops, B, Hin, Cin, N):
+    """The Upsample convolution (openaimodel.py:110-118): 3x3 over the nearest-2x upsampled tensor, which neither kernel
+    writes -- the direct kernel's patch loader and the implicit GEMM's gather both read pixel (y / 2, x / 2); same bits."""
+    H = 2 * Hin
+    assert ops.conv3_direct_ok(B, H, H, Cin, N)
+    g = torch.Generator().manual_seed(B + Hin + Cin)
+    x = torch.randint(-128, 128, (B, Hin, Hin, Cin), generator=g, dtype=torch.int8).cuda()
+    w = torch.randint(-8, 9, (N, 3, 3, Cin), generator=g, dtype=torch.int8).cuda()
+    scale, bias = (torch.rand(N, generator=g) * 1e-3 + 1e-4).cuda(), torch.randn(N, generator=g).cuda()
+    M, K, padval = B * H * H, 9 * Cin, 9
+    geom = ops.make_geom(B, Hin, Hin, Cin, H, H, 3, 3, 1, 1, True, padval)
+    a = ops.qgemm_i8(x, w.reshape(N, K), M, N, K, scale, bias, torch.empty(M, N, device="cuda"), geom=geom)
+    b = ops.qconv3_i8_direct(x, ops.conv3_pack_w(w.reshape(N, K), N, Cin), B, H, H, Cin, N, padval, scale, bias,
+                             torch.empty(M, N, device="cuda"), ups=True)
+    assert torch.equal(a, b), float((a - b).abs().max())
+    xu = x.permute(0, 3, 1, 2).float().repeat_interleave(2, 2).repeat_interleave(2, 3)
+    ref = F.conv2d(F.pad(xu, (1, 1, 1, 1), value=padval).double(), w.permute(0, 3, 1, 2).double()).permute(0, 2, 3, 1).reshape(M, N)
+    got = ops.qconv3_i8_direct(x, ops.conv3_pack_w(w.reshape(N, K), N, Cin), B, H, H, Cin, N, padval, torch.ones(N, device="cuda"),
+                               torch.zeros(N, device="cuda"), torch.empty(M, N, device="cuda"), ups=True)
+    assert torch.equal(got.double(), ref)
