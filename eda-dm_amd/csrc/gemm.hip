@@ -274,7 +274,7 @@ __device__ __forceinline__ int64_t uniform_i64(int64_t v) {  // pin a wave-unifo
     return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
-template <int DT, int TM, int TN, bool HAS_RA, bool HAS_RES>
+template <int DT, int TM, int TN, bool HAS_RA, bool HAS_RES, bool GNREG = false>
 __device__ __forceinline__ void epilogue_direct_body(typename Acc<DT>::type (&acc)[TM][TN], const EpiRegs<TN>& er, int lane,
                                                      int64_t row0, int64_t col0, const float* __restrict__ residual,
                                                      int64_t ldr, float* __restrict__ out, int64_t ldo,
@@ -285,7 +285,12 @@ __device__ __forceinline__ void epilogue_direct_body(typename Acc<DT>::type (&ac
     // per row group the four values of a column are summed in registers and added to the wave's own LDS slots
     // (sum, sum of squares per column) -- no accumulator lives across the store loop (the kernel is at its
     // register limit), the LDS pipe is idle during this epilogue.
-    if (gn_ws && lane < 32) {
+    // GNREG (kernels with registers to spare, k_conv3_direct): the per-column sums of the wave's TM x 32 rows stay in
+    // 2 TN registers across the store loop, the two lanes that share a column add up at the end: no LDS, no atomics
+    float gs[TN], gq[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) gs[j] = gq[j] = 0.f;
+    if (!GNREG && gn_ws && lane < 32) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) *reinterpret_cast<float2*>(gacc + (j * 32 + fr) * 2) = make_float2(0.f, 0.f);
     }
@@ -339,7 +344,10 @@ __device__ __forceinline__ void epilogue_direct_body(typename Acc<DT>::type (&ac
                 pq[j] += v * v;
             }
         }
-        if (gn_ws) {
+        if constexpr (GNREG) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) { gs[j] += ps[j]; gq[j] += pq[j]; }
+        } else if (gn_ws) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 atomicAdd(gacc + (j * 32 + fr) * 2, ps[j]);
@@ -347,6 +355,17 @@ __device__ __forceinline__ void epilogue_direct_body(typename Acc<DT>::type (&ac
             }
         }
         asm volatile("" ::: "memory");
+    }
+    if constexpr (GNREG) {
+        if (gn_ws) {
+            const int64_t slab = row0 / (TM * 32);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float a0 = gs[j] + __shfl_xor(gs[j], 32, 64), a1 = gq[j] + __shfl_xor(gq[j], 32, 64);
+                if (lane < 32) *reinterpret_cast<float2*>(gn_ws + (slab * N + col0 + j * 32 + fr) * 2) = make_float2(a0, a1);
+            }
+        }
+        return;
     }
     if (gn_ws) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -357,6 +376,21 @@ __device__ __forceinline__ void epilogue_direct_body(typename Acc<DT>::type (&ac
                 *reinterpret_cast<float2*>(gn_ws + (slab * N + col0 + j * 32 + fr) * 2) =
                     *reinterpret_cast<const float2*>(gacc + (j * 32 + fr) * 2);
         }
+    }
+}
+
+template <int DT, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_direct_gnreg(typename Acc<DT>::type (&acc)[TM][TN], const EpiRegs<TN>& er, int lane,
+                                                           int64_t row0, int64_t col0, bool has_rowadd,
+                                                           const float* __restrict__ residual, int64_t ldr,
+                                                           float* __restrict__ out, int64_t ldo, float* __restrict__ gn_ws,
+                                                           int64_t N) {
+    if (residual) {
+        if (has_rowadd) epilogue_direct_body<DT, TM, TN, true, true, true>(acc, er, lane, row0, col0, residual, ldr, out, ldo, nullptr, gn_ws, N);
+        else epilogue_direct_body<DT, TM, TN, false, true, true>(acc, er, lane, row0, col0, residual, ldr, out, ldo, nullptr, gn_ws, N);
+    } else {
+        if (has_rowadd) epilogue_direct_body<DT, TM, TN, true, false, true>(acc, er, lane, row0, col0, residual, ldr, out, ldo, nullptr, gn_ws, N);
+        else epilogue_direct_body<DT, TM, TN, false, false, true>(acc, er, lane, row0, col0, residual, ldr, out, ldo, nullptr, gn_ws, N);
     }
 }
 
@@ -1526,7 +1560,7 @@ __global__ void __launch_bounds__(512)
 k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, int64_t M, int64_t N, int B, int H, int W,
                int Cin, int padval, int ups, const float* __restrict__ scale, const float* __restrict__ bias,
                const float* __restrict__ rowadd, int64_t rows_per_batch, const float* __restrict__ residual, int64_t ldr,
-               float* __restrict__ out, int64_t ldo) {
+               float* __restrict__ out, int64_t ldo, float* __restrict__ gn_ws) {
     constexpr int TM = 2, BM = 256, BN = 64 * TN;
     constexpr int PATCH_BYTES = 32 * 1024;                  // 8 waves x 4 pieces x 1 KiB >= 16 * ceil(NP / 16) * 64
     constexpr int SLAB_BYTES = 3 * BN * 64;                 // one filter row of one 64-channel chunk
@@ -1669,7 +1703,10 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
     }
     EpiRegs<TN> er;
     load_epi_regs<TN, BN>(er, ec, lane, m0, m0 + wm * 64, wn * (TN * 32), rows_per_batch);
-    gemm_epilogue_direct<0, TM, TN>(acc, er, lane, m0 + wm * 64, n0 + wn * (TN * 32), rowadd != nullptr, residual, ldr, out, ldo);
+    // gn_ws [M / 64][N][2]: per-channel (sum, sum of squares) of each 64-row slab of this output, for the GroupNorm that
+    // normalises it next (its statistics pass then only reduces these partials: no second read of the tensor)
+    gemm_epilogue_direct_gnreg<0, TM, TN>(acc, er, lane, m0 + wm * 64, n0 + wn * (TN * 32), rowadd != nullptr, residual, ldr, out,
+                                          ldo, gn_ws, N);
 }
 
 // Weight layout of k_conv3_direct from the engine's [N][ky][kx][ci] int8 filter: [N / BN][Cin / 64][ky][kx][BN][64] with
@@ -1708,8 +1745,9 @@ extern "C" int edadm_conv3_direct_ok(int64_t B, int64_t H, int64_t W, int64_t Ci
 extern "C" int edadm_qconv3_i8_direct(const int8_t* A, const int8_t* Wdc, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t N,
                                       int padval, int ups, const float* scale, const float* bias, const float* rowadd,
                                       int64_t rows_per_batch, const float* residual, int64_t ldr, float* out, int64_t ldo,
-                                      void* stream) {
+                                      float* gn_ws, void* stream) {
     if (!A || !Wdc || !out || !scale || !edadm_conv3_direct_ok(B, H, W, Cin, N)) return EDADM_EINVAL;
+    if (gn_ws && (H * W) % 64) return EDADM_EINVAL;         // a 64-row slab must not straddle two images
     if (((uintptr_t)A & 15) || ((uintptr_t)Wdc & 15)) return EDADM_EINVAL;
     if (rowadd && rows_per_batch < 64) return EDADM_EINVAL;
     if (ups && ((H | W) & 1)) return EDADM_EINVAL;
@@ -1722,7 +1760,7 @@ extern "C" int edadm_qconv3_i8_direct(const int8_t* A, const int8_t* Wdc, int64_
     }
     hipLaunchKernelGGL((k_conv3_direct<3>), dim3((unsigned)(N / 192), (unsigned)(M / 256)), dim3(512), 0, (hipStream_t)stream,
                        (const uint8_t*)A, (const uint8_t*)Wdc, M, N, (int)B, (int)H, (int)W, (int)Cin, padval, ups ? 1 : 0, scale, bias, rowadd,
-                       rows_per_batch, residual, ldr, out, ldo);
+                       rows_per_batch, residual, ldr, out, ldo, gn_ws);
     return edadm_launch_status();
 }
 #endif

@@ -219,15 +219,16 @@ __global__ void __launch_bounds__(256) k_gn_partial(const float* __restrict__ x,
 // ws2 != nullptr: channels [C1, C) come from a second partials buffer (the other half of a skip concatenation)
 __global__ void __launch_bounds__(64) k_gn_final(const float* __restrict__ ws, const float* __restrict__ ws2, int64_t C1,
                                                  float* __restrict__ stats,
-                                                 int64_t HW, int64_t C, int64_t G, int nchunk, float eps) {
+                                                 int64_t HW, int64_t C, int64_t G, int nchunk, float eps, int64_t B2 = 0) {
     const int64_t b = blockIdx.y, g = blockIdx.x;
+    const int64_t b2 = B2 > 0 ? b % B2 : b;               // the second buffer may hold a whole fraction of the batch (guidance pair)
     const int cpg = (int)(C / G);
     double s = 0.0, ss = 0.0;
     const int items = nchunk * cpg;
     for (int i = threadIdx.x; i < items; i += 64) {
         const int ch = i / cpg, c = (int)(g * cpg) + i % cpg;
         const float* p = (!ws2 || c < C1) ? ws + ((b * nchunk + ch) * (ws2 ? C1 : C) + c) * 2
-                                          : ws2 + ((b * nchunk + ch) * (C - C1) + (c - C1)) * 2;
+                                          : ws2 + ((b2 * nchunk + ch) * (C - C1) + (c - C1)) * 2;
         s += (double)p[0];
         ss += (double)p[1];
     }
@@ -264,13 +265,19 @@ extern "C" int edadm_groupnorm_stats_cat(const float* x1, int64_t C1, const floa
     return edadm_groupnorm_stats_cat_rep(x1, C1, x2, C2, stats, ws, B, HW, G, eps, 0, stream);
 }
 // pass 2 alone, over per-channel partials [B][nchunk][C][2] that a producer already wrote (edadm_qgemm_i8_gn)
+extern "C" int edadm_groupnorm_final_cat_rep(const float* ws1, int64_t C1, const float* ws2, int64_t C2, float* stats, int64_t B,
+                                             int64_t HW, int64_t G, int64_t nchunk, float eps, int64_t B2, void* stream) {
+    const int64_t C = C1 + (ws2 ? C2 : 0);
+    if (!ws1 || !stats || B <= 0 || HW <= 0 || C1 <= 0 || (ws2 && C2 <= 0) || G <= 0 || (C % G) || nchunk <= 0 || B2 < 0 ||
+        (B2 > 0 && (!ws2 || B % B2)))
+        return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_gn_final, dim3((unsigned)G, (unsigned)B), dim3(64), 0, (hipStream_t)stream, ws1, ws2, C1, stats, HW, C,
+                       G, (int)nchunk, eps, B2);
+    return edadm_launch_status();
+}
 extern "C" int edadm_groupnorm_final_cat(const float* ws1, int64_t C1, const float* ws2, int64_t C2, float* stats, int64_t B,
                                          int64_t HW, int64_t G, int64_t nchunk, float eps, void* stream) {
-    const int64_t C = C1 + (ws2 ? C2 : 0);
-    if (!ws1 || !stats || B <= 0 || HW <= 0 || C1 <= 0 || (ws2 && C2 <= 0) || G <= 0 || (C % G) || nchunk <= 0) return EDADM_EINVAL;
-    hipLaunchKernelGGL(k_gn_final, dim3((unsigned)G, (unsigned)B), dim3(64), 0, (hipStream_t)stream, ws1, ws2, C1, stats, HW, C,
-                       G, (int)nchunk, eps);
-    return edadm_launch_status();
+    return edadm_groupnorm_final_cat_rep(ws1, C1, ws2, C2, stats, B, HW, G, nchunk, eps, 0, stream);
 }
 extern "C" int edadm_groupnorm_stats(const float* x, float* stats, float* ws, int64_t B, int64_t HW, int64_t C,
                                      int64_t G, float eps, void* stream) {

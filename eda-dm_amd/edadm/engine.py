@@ -131,6 +131,7 @@ class Engine:
         self.gn_from_producer = os.environ.get("EDADM_GN_FROM_PRODUCER", "0") == "1"   # measured slower (58.4 vs 61.7 img/s): off
         self.direct_conv = os.environ.get("EDADM_DIRECT_CONV", "1") != "0"        # LDS-resident-patch 3x3 convolution
         self.direct_conv_min_k = int(os.environ.get("EDADM_DIRECT_CONV_MIN_K", "1152"))
+        self.gn_partials = os.environ.get("EDADM_GN_PARTIALS", "1") != "0"       # ... which also writes the next GroupNorm's partial sums
         self.graph = None
         self.prof = None
         self.tap = None              # {layer name: [operands]}: diagnostics (per-layer code census), off on the hot path
@@ -358,16 +359,23 @@ class Engine:
             res2 = None if residual is None else residual.reshape(M, -1)
             s0 = L.segs[0]
 
+            # GroupNorm partials of this output from the epilogue's registers (no atomics): the layer that normalises it next
+            # skips its statistics pass over the tensor
+            ws = torch.empty(M // 64, L.N, 2, dtype=torch.float32, device=self.dev) if (self.gn_partials and (Hl * Wl) % 64 == 0) else None
+
             def run():
                 ops.qconv3_i8_direct(a, L.wdc, B, Hl, Wl, L.cin, L.N, padval, s0["scale"], L.bias, out, rowadd=rowadd,
-                                     rows_per_batch=Hl * Wl, residual=res2, ups=ups)
+                                     rows_per_batch=Hl * Wl, residual=res2, ups=ups, gn_ws=ws)
             if self.tap is not None:
                 self.tap.setdefault(L.name, []).append(a.detach().clone())
             if self.prof is not None:
                 self.prof.append((L.mode, L.name, M, L.N, L.K, 2.0 * M * L.N * L.K, run,
                                   self._alg_bytes(L, a, M, 4.0 * M * L.N, residual, "conv3")))
             run()
-            return out.reshape(B, Hl, Wl, L.N)
+            o4 = out.reshape(B, Hl, Wl, L.N)
+            if ws is not None:
+                o4._gn = (ws, Hl * Wl)
+            return o4
         geom = ops.make_geom(B, H, W, L.cin, Ho, Wo, L.kh, L.kh, L.stride, pad0, ups, padval)
         M = B * Ho * Wo
         out = self._gemm(L, a, M, geom=geom, rowadd=rowadd, rpb=Ho * Wo,
@@ -385,12 +393,14 @@ class Engine:
     def _gn_stats(self, norm, x):
         """statistics pass: from the producers' partials when every half of x has them, else the two-pass kernels"""
         parts = (x.a, x.b) if isinstance(x, ops.Cat) else (x,)
-        gs = [getattr(p, "_gn", None) for p in parts] if not (isinstance(x, ops.Cat) and x.rep > 1) else [None]
+        gs = [getattr(p, "_gn", None) for p in parts]
         B = parts[0].shape[0]
         HW = parts[0].numel() // (B * parts[0].shape[-1])
         if all(g is not None and g[1] == HW for g in gs):
             ws2 = gs[1][0] if len(gs) == 2 else None
-            return ops.groupnorm_final(gs[0][0], parts[0].shape[-1], ws2, parts[-1].shape[-1], B, HW, norm.num_groups, norm.eps)
+            rep = x.rep if isinstance(x, ops.Cat) else 1
+            return ops.groupnorm_final(gs[0][0], parts[0].shape[-1], ws2, parts[-1].shape[-1], B, HW, norm.num_groups, norm.eps,
+                                       B2=parts[-1].shape[0] if rep > 1 else 0)
         return ops.groupnorm_stats(x, norm.num_groups, norm.eps)
 
     def gn(self, norm, x, silu, qms=(), want_f32=False, scale_shift=None, raw=None):

@@ -405,11 +405,12 @@ def gn_partials_ok(M, N, hw, rowadd_rpb=None):
         (rowadd_rpb is None or rowadd_rpb >= 64)
 
 
-def groupnorm_final(ws1, C1, ws2, C2, B, HW, G, eps):
-    """stats[B][G][2] from producer-written partials [B][HW/64][C][2] (ws2: second half of a concatenation)."""
+def groupnorm_final(ws1, C1, ws2, C2, B, HW, G, eps, B2=0):
+    """stats[B][G][2] from producer-written partials [B][HW/64][C][2] (ws2: second half of a concatenation, B2 > 0: of
+    B2 images read periodically)."""
     stats = torch.empty(B, G, 2, dtype=torch.float32, device=ws1.device)
-    lib.call("edadm_groupnorm_final_cat", _pf(ws1), C1, _pf(ws2), C2 if ws2 is not None else 0, _pf(stats), B, HW, G,
-             HW // 64, float(eps), _stream())
+    lib.call("edadm_groupnorm_final_cat_rep", _pf(ws1), C1, _pf(ws2), C2 if ws2 is not None else 0, _pf(stats), B, HW, G,
+             HW // 64, float(eps), int(B2), _stream())
     return stats
 
 
@@ -442,11 +443,11 @@ def conv3_pack_w(w_i8, N, Cin):
 
 
 def qconv3_i8_direct(a_nhwc, wdc, B, H, W, Cin, N, padval, scale, bias, out, rowadd=None, rows_per_batch=1, residual=None,
-                     ups=False):
+                     ups=False, gn_ws=None):
     """3x3 / stride 1 / pad 1 convolution of the int8 NHWC operand with the input patch resident in LDS (edadm.h)."""
     lib.call("edadm_qconv3_i8_direct", _p(a_nhwc, torch.int8), _p(wdc, torch.int8), int(B), int(H), int(W), int(Cin), int(N),
              int(padval), 1 if ups else 0, _pf(scale), _pf(bias), _pf(rowadd), int(rows_per_batch), _pf(residual), int(N), _pf(out),
-             int(N), _stream())
+             int(N), _pf(gn_ws), _stream())
     return out
 
 

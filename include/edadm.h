@@ -171,6 +171,10 @@ int edadm_quant_i8_cat_rep(const float* x1, int64_t C1, const float* x2, int64_t
  * (edadm_qgemm_i8_gn) -> stats; ws2 (may be NULL) holds the second half of a channel concatenation */
 int edadm_groupnorm_final_cat(const float* ws1, int64_t C1, const float* ws2, int64_t C2, float* stats, int64_t B,
                               int64_t HW, int64_t G, int64_t nchunk, float eps, void* stream);
+/* the same with the second partials buffer holding B2 < B images, read periodically (image b takes b % B2): the shared
+ * half of a classifier-free-guidance pair; B2 = 0: same batch */
+int edadm_groupnorm_final_cat_rep(const float* ws1, int64_t C1, const float* ws2, int64_t C2, float* stats, int64_t B,
+                                  int64_t HW, int64_t G, int64_t nchunk, float eps, int64_t B2, void* stream);
 /* LayerNorm over the last dim, same output options (ldm/modules/attention.py:222-242). */
 int edadm_layernorm_quant(const float* x, const float* gamma, const float* beta, int64_t rows, int64_t C,
                           float eps, float* out_f32, int8_t* q0, int8_t* q1, int8_t* q2, const float* qp,
@@ -330,12 +334,14 @@ int edadm_pack_w4(const int8_t* w, const float* zp, uint8_t* packed, int64_t row
  * int8 filter of edadm_qgemm_i8); same epilogue contract as edadm_qgemm_i8 (scale, bias, per-image row-add, fp32 residual).
  * edadm_conv3_direct_ok: 1 when (B, H, W, Cin, N) is a shape the kernel takes (W in {8,16,32,64}, Cin % 64 == 0,
  * N % 192 == 0, whole 256-pixel tiles).  H, W are the dimensions the convolution runs over; with ups = 1 the stored
- * tensor is [B][H/2][W/2][Cin] and its nearest-2x upsample (openaimodel.py:110-118, diffusion.py:41-45) is read in place. */
+ * tensor is [B][H/2][W/2][Cin] and its nearest-2x upsample (openaimodel.py:110-118, diffusion.py:41-45) is read in place.
+ * gn_ws (or NULL): [M / 64][N][2] per-channel (sum, sum of squares) of every 64-row slab of the output, written from the
+ * epilogue's registers -- the partials edadm_groupnorm_final_cat reduces (H * W % 64 == 0). */
 int edadm_conv3_pack_w(const int8_t* w, int8_t* out, int64_t N, int64_t Cin, void* stream);
 int edadm_conv3_direct_ok(int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t N);
 int edadm_qconv3_i8_direct(const int8_t* A, const int8_t* Wdc, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t N,
                            int padval, int ups, const float* scale, const float* bias, const float* rowadd, int64_t rows_per_batch,
-                           const float* residual, int64_t ldr, float* out, int64_t ldo, void* stream);
+                           const float* residual, int64_t ldr, float* out, int64_t ldo, float* gn_ws, void* stream);
 
 /* ---- H1 training-graph ops: forward and input-gradient of the non-contraction ops of the calibration graph, fp32, on the
  * reference's layouts (csrc/train_ops.hip).  GroupNorm (+ SiLU) over NCHW, `stats` = [B * G][2] (mean, rstd) written by the

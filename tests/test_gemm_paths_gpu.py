@@ -197,3 +197,37 @@ def test_direct_conv3_over_the_folded_upsample(ops, B, Hin, Cin, N):
     got = ops.qconv3_i8_direct(x, ops.conv3_pack_w(w.reshape(N, K), N, Cin), B, H, H, Cin, N, padval, torch.ones(N, device="cuda"),
                                torch.zeros(N, device="cuda"), torch.empty(M, N, device="cuda"), ups=True)
     assert torch.equal(got.double(), ref)
+
+
+@pytest.mark.parametrize("B,H,Cin,N", [(4, 64, 192, 192), (6, 16, 576, 576), (8, 8, 960, 384)])
+def test_direct_conv3_groupnorm_partials(ops, B, H, Cin, N):
+    """edadm_qconv3_i8_direct with gn_ws: per-channel (sum, sum of squares) of every 64-row slab of the output, summed in
+    the epilogue's registers; reduced by edadm_groupnorm_final_cat[_rep] they give the statistics of the two-pass kernels on
+    the same output to 2e-5 (fp32 partial sums in another order, combined in fp64) -- alone, as the second half of a skip
+    concatenation, and as the half-batch part of a guidance pair read periodically.  The output itself does not change."""
+    g = torch.Generator().manual_seed(B + H + N)
+    x = torch.randint(-128, 128, (B, H, H, Cin), generator=g, dtype=torch.int8).cuda()
+    w = torch.randint(-8, 9, (N, 9 * Cin), generator=g, dtype=torch.int8).cuda()
+    scale, bias = (torch.rand(N, generator=g) * 1e-2 + 1e-3).cuda(), torch.randn(N, generator=g).cuda()
+    M, HW = B * H * H, H * H
+    wdc = ops.conv3_pack_w(w, N, Cin)
+    res = torch.randn(M, N, generator=g).cuda()
+    out0 = ops.qconv3_i8_direct(x, wdc, B, H, H, Cin, N, 3, scale, bias, torch.empty(M, N, device="cuda"), residual=res)
+    ws = torch.full((M // 64, N, 2), float("nan"), device="cuda")
+    out = ops.qconv3_i8_direct(x, wdc, B, H, H, Cin, N, 3, scale, bias, torch.empty(M, N, device="cuda"), residual=res, gn_ws=ws)
+    assert torch.equal(out, out0) and torch.isfinite(ws).all()
+    G = 32
+    xo = out.reshape(B, HW, N)
+    tol = lambda got, want: ((got - want).abs() <= 2e-5 * want.abs().clamp_min(1.0)).all()
+    assert tol(ops.groupnorm_final(ws, N, None, 0, B, HW, G, 1e-5), ops.groupnorm_stats(xo, G, 1e-5))
+    other = torch.randn(B, HW, 64, generator=g).cuda() * 3
+    ws_o = torch.empty(M // 64, 64, 2, device="cuda")
+    o3 = other.reshape(M // 64, 64, 64)
+    ws_o[..., 0], ws_o[..., 1] = o3.sum(1), (o3 * o3).sum(1)
+    assert tol(ops.groupnorm_final(ws_o, 64, ws, N, B, HW, G, 1e-5), ops.groupnorm_stats(ops.Cat(other, xo), G, 1e-5))
+    # guidance pair: the second part holds half the images and is read periodically
+    big = torch.cat([other, other * 0.5])
+    ws_b = torch.cat([ws_o, ws_o * torch.tensor([0.5, 0.25], device="cuda")])
+    got = ops.groupnorm_final(ws_b, 64, ws, N, 2 * B, HW, G, 1e-5, B2=B)
+    want = ops.groupnorm_stats(ops.Cat(big, xo), G, 1e-5)
+    assert tol(got, want)
