@@ -152,7 +152,7 @@ __device__ __forceinline__ void gemm_epilogue(typename Acc<DT>::type (&acc)[TM][
                     float4 v = *reinterpret_cast<const float4*>(ep + rl * EST + c4 * 4);
                     const float4 sc4 = *reinterpret_cast<const float4*>(ec + ecol);
                     const float4 b4 = *reinterpret_cast<const float4*>(ec + BN + ecol);
-                    v.x = v.x * sc4.x + b4.x; v.y = v.y * sc4.y + b4.y; v.z = v.z * sc4.z + b4.z; v.w = v.w * sc4.w + b4.w;
+                    v.x = fmaf(v.x, sc4.x, b4.x); v.y = fmaf(v.y, sc4.y, b4.y); v.z = fmaf(v.z, sc4.z, b4.z); v.w = fmaf(v.w, sc4.w, b4.w);
                     if (has_rowadd) {
                         const int bj = (int)(row / rows_per_batch - b0);
                         const float4 a4 = *reinterpret_cast<const float4*>(ec + (2 + bj) * BN + ecol);
@@ -210,7 +210,7 @@ __device__ __forceinline__ void gemm_epilogue(typename Acc<DT>::type (&acc)[TM][
             for (int r = 0; r < 16; ++r) {
                 const int64_t row = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 if (row >= M) continue;
-                float v = (float)acc[i][j][r] * s + bs;
+                float v = fmaf((float)acc[i][j][r], s, bs);
                 if (has_rowadd) v += ec[(2 + (int)(row / rows_per_batch - b0)) * BN + ecol];
                 if (residual) v += residual[row * ldr + col];
                 if (out_mode == 0) {
@@ -336,7 +336,7 @@ __device__ __forceinline__ void epilogue_direct_body(typename Acc<DT>::type (&ac
             for (int j = 0; j < TN; ++j) {
                 auto a = acc[i][j][4 * g + e];
                 asm volatile("" : "+v"(a));                // read the accumulator here, not hoisted above the dispatch
-                float v = (float)a * er.s[j] + er.b[j];
+                float v = fmaf((float)a, er.s[j], er.b[j]);       // explicit: every instantiation rounds the same way
                 if constexpr (HAS_RA) v += late ? er.ra1[j] : er.ra0[j];
                 if constexpr (HAS_RES) v += rr[gi][e][j];
                 EDADM_NT_STORE(v, reinterpret_cast<float*>(op + ooff + j * 128));
@@ -449,7 +449,7 @@ __device__ __forceinline__ void gemm_epilogue_qdirect(typename Acc<DT>::type (&a
                         asm volatile("" : "+v"(acc[i][j][4 * g + e]));     // read here (in place: no copy), not hoisted
                         v[e] = (float)acc[i][j][4 * g + e];
                     }
-                    v[0] = v[0] * s4.x + b4.x; v[1] = v[1] * s4.y + b4.y; v[2] = v[2] * s4.z + b4.z; v[3] = v[3] * s4.w + b4.w;
+                    v[0] = fmaf(v[0], s4.x, b4.x); v[1] = fmaf(v[1], s4.y, b4.y); v[2] = fmaf(v[2], s4.z, b4.z); v[3] = fmaf(v[3], s4.w, b4.w);
                     if (residual) {                        // the lane's four columns are one 16-byte piece of its row
                         const int64_t col = col0 + j * 32 + 8 * g + fh4;
                         const float4 r4 = *reinterpret_cast<const float4*>(residual + (row0 + i * 32 + fr) * ldr + col);
