@@ -1007,12 +1007,93 @@ def g16_layer_recon():
     save("g16_layer_recon", d)
 
 
+def g17_tdac_imagenet():
+    """G17: the reference's TDAC_imagenet_calib_data_generator (scripts/calibration.py:371-500) end to end on the fixture
+    LDM of g13_ldm_imagenet (its weights, FP state): DDIMSampler_control trajectories with classifier-free guidance, the
+    mid-block features, density / variety scores, the allocation, the shuffled step assignment and the assembled
+    calibration tuple.  Randomness is captured, not re-drawn: the start noise of every trajectory batch (x_inter[0]) and
+    the permutation of torch.randperm are stored so that a test can inject them."""
+    import scripts.calibration as refcal
+    from qdiff.utils import AttentionMap  # noqa: F401
+    base = np.load(os.path.join(HERE, "g13_ldm_imagenet.npz"))
+    kw = {k[4:]: (base[k].tolist() if base[k].ndim else base[k].item()) for k in base.files if k.startswith("cfg/")}
+    model = UNetModel(**kw).eval()
+    model.load_state_dict({k[3:]: torch.as_tensor(base[k]) for k in base.files if k.startswith("sd/")})
+    qnn = QuantModel(model, WQ4, AQ8, sm_abit=8, act_quant_mode="qdiff")
+    qnn.eval()
+    qnn.set_quant_state(False, False)
+    b = make_beta_schedule("linear", 1000, linear_start=0.0015, linear_end=0.0195)
+    ac = np.cumprod(1.0 - b, axis=0)
+    g = torch.Generator().manual_seed(1717)
+    emb = torch.randn(1001, 16, generator=g) * 0.7
+
+    class Wrap(nn.Module):
+        def __init__(self, net):
+            super().__init__()
+            self.diffusion_model = net
+
+    class FakeLD(nn.Module):
+        def __init__(self, net):
+            super().__init__()
+            self.model = Wrap(net)
+            self.num_timesteps = 1000
+            self.cond_stage_key = "class_label"
+            self.betas = torch.tensor(b, dtype=torch.float32)
+            self.alphas_cumprod = torch.tensor(ac, dtype=torch.float32)
+            self.alphas_cumprod_prev = torch.tensor(np.append(1.0, ac[:-1]), dtype=torch.float32)
+            self.device = torch.device("cpu")
+
+        def apply_model(self, x_, t_, c_):
+            return self.model.diffusion_model(x_, t_, context=c_)
+
+        def get_learned_conditioning(self, batch):
+            return emb[batch[self.cond_stage_key]][:, None, :]          # ClassEmbedder (encoders/modules.py:21-33)
+
+    ld = FakeLD(qnn)
+    N, nb, S = 32, 8, 10
+    labels = torch.randint(0, 1000, (N,), generator=g)
+    args = SimpleNamespace(scale=3.0, data=labels, custom_steps=S, ddim_eta=0.0, lamda=1.2)
+    perms = []
+    orig_perm, orig_shape = torch.randperm, None
+    torch.randperm = lambda n, **k: (perms.append(orig_perm(n, **k)) or perms[-1])
+    draws = []
+    orig_randn = torch.randn
+
+    def rec_randn(*a, **k):
+        r = orig_randn(*a, **k)
+        draws.append(r.clone())
+        return r
+
+    torch.randn = rec_randn
+    # the generator hard-codes the LDM-4 latent shape [3, 64, 64] (:380); the fixture UNet takes any H, W
+    cwd = os.getcwd()
+    os.chdir("/tmp")                                          # it also saves a plot into the working directory
+    try:
+        torch.manual_seed(1717)
+        src = open(refcal.__file__).read()
+        assert "shape = [3, 64, 64]" in src
+        ns = dict(refcal.__dict__)
+        exec(compile(src.replace("shape = [3, 64, 64]", "shape = [3, 8, 8]"), refcal.__file__, "exec"), ns)
+        calib_data, t, index, cond, uncond = ns["TDAC_imagenet_calib_data_generator"](ld, args, N, nb, "cpu", S)
+    finally:
+        torch.randperm = orig_perm
+        torch.randn = orig_randn
+        os.chdir(cwd)
+    d = {"emb": emb, "labels": labels, "N": N, "nb": nb, "S": S, "scale": 3.0, "lamda": 1.2, "perm": perms[-1],
+         "calib_data": calib_data, "t": t, "index": index, "cond": cond, "uncond": uncond}
+    # the start noise of each trajectory batch: the first torch.randn of every sampler.sample() call (each of the S steps
+    # then draws one more through noise_like, multiplied by sigma = 0)
+    assert len(draws) == (N // nb) * (S + 1), len(draws)
+    d["x_T"] = torch.stack([draws[i * (S + 1)] for i in range(N // nb)])
+    save("g17_tdac_imagenet", d)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     jobs = dict(g1=g1_weight_init, g2=g2_act_init, g3=g3_uaq_forward, g4=g4_adaround, g5=g5_loss,
                 g6=g6_quant_module, g7=g7_blocks, g8=g8_g12_recon, g9=g9_tdac, g10=g10_steps,
                 g13c=g13_cifar_unet, g13i=lambda: g13_ldm_unet("imagenet"), g13h=lambda: g13_ldm_unet("church"), g14=g14_plms, g15=g15_decoder,
-                g7b=g7b_blocks, g13w8=lambda: g13_cifar_unet(8, "g13_cifar_w8", 1301), g13sd=g13_ldm_sd, g16=g16_layer_recon)
+                g17=g17_tdac_imagenet, g7b=g7b_blocks, g13w8=lambda: g13_cifar_unet(8, "g13_cifar_w8", 1301), g13sd=g13_ldm_sd, g16=g16_layer_recon)
     for k, fn in jobs.items():
         if not only or k in only:
             print("==", k)

@@ -271,3 +271,40 @@ def test_layer_recon_walk_with_attention_step_sizes(golden):
         out = qnn(x[:8], t[:8]).cpu().numpy()
     ref = g["final/out_q"]
     assert np.abs(out - ref).max() < 0.08 * np.abs(ref).max()
+
+
+def test_tdac_imagenet_generator_values(golden):
+    """scripts.calibration.TDAC_imagenet_calib_data_generator (scripts/calibration.py:371-500 of the reference)
+    against the reference generator's own output (G17) on the fixture LDM, with the reference's random draws injected
+    (start noise of every trajectory batch, the final permutation): the step allocation, the per-sample timesteps and
+    indices exactly, the assembled calibration latents to fp32 trajectory accuracy."""
+    from scripts.calibration import TDAC_imagenet_calib_data_generator
+    from edadm.latent import LatentDiffusionLite, ClassEmbedder
+    from qdiff import QuantModel
+    from helpers import build_ldm
+    g, base = golden("g17_tdac_imagenet"), golden("g13_ldm_imagenet")
+    qnn = QuantModel(build_ldm(base), WQ4, AQ8, sm_abit=8, act_quant_mode="qdiff").cuda().eval()
+    qnn.set_quant_state(False, False)
+    ce = ClassEmbedder(16, n_classes=1001)
+    with torch.no_grad():
+        ce.embedding.weight.copy_(T(g["emb"]))
+    ld = LatentDiffusionLite(qnn, timesteps=1000, linear_start=0.0015, linear_end=0.0195, conditioning_key="crossattn",
+                             cond_stage_model=ce, cond_stage_key="class_label").cuda()
+    N, nb, S = int(g["N"]), int(g["nb"]), int(g["S"])
+    args = SimpleNamespace(scale=float(g["scale"]), data=T(g["labels"]), custom_steps=S, ddim_eta=0.0, lamda=float(g["lamda"]),
+                           latent_shape=[3, 8, 8])
+    xT = iter(T(g["x_T"]))
+    orig_randn, orig_perm = torch.randn, torch.randperm
+    torch.randn = lambda *a, **k: next(xT).cuda()
+    torch.randperm = lambda n, **k: T(g["perm"])
+    try:
+        calib, t, index, cond, uncond = TDAC_imagenet_calib_data_generator(ld, args, N, nb, torch.device("cuda"), S)
+    finally:
+        torch.randn, torch.randperm = orig_randn, orig_perm
+    np.testing.assert_array_equal(t.cpu().numpy(), g["t"])
+    np.testing.assert_array_equal(index.cpu().numpy(), g["index"])
+    np.testing.assert_allclose(cond.cpu().numpy(), g["cond"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(uncond.cpu().numpy(), g["uncond"], rtol=1e-6, atol=1e-7)
+    err = np.abs(calib.cpu().numpy() - g["calib_data"]).max() / np.abs(g["calib_data"]).max()
+    print("TDAC calibration latents vs the reference generator: max %.2e of range" % err)
+    assert err <= 1e-4
