@@ -308,3 +308,42 @@ def test_tdac_imagenet_generator_values(golden):
     err = np.abs(calib.cpu().numpy() - g["calib_data"]).max() / np.abs(g["calib_data"]).max()
     print("TDAC calibration latents vs the reference generator: max %.2e of range" % err)
     assert err <= 1e-4
+
+
+def test_task_harness_calibrate_save_load_sample(golden, tmp_path, capsys):
+    """scripts/sample_diffusion_ldm_imagenet.py (the flow of the reference's script of that name, :142-249) as
+    two jobs on a fixture-sized UNet: calibrate (TDAC set, Conditional scale init, the conditional reconstruction walk,
+    quantiser state + W4-packed frozen model written) and sample (state loaded into a fresh process image, batches from
+    (seed, batch index), DDIM + CFG on the int8 executor).  Sampling twice gives the same latents; a run restricted to
+    the batches of rank 1 of 2 reproduces exactly those batches."""
+    import json
+    from scripts import sample_diffusion_ldm_imagenet as H
+    base = golden("g13_ldm_imagenet")
+    kw = {k[4:]: (base[k].tolist() if base[k].ndim else base[k].item()) for k in base.files if k.startswith("cfg/")}
+    out = str(tmp_path / "calib")
+    common = ["--unet", json.dumps(kw), "--latent", "3", "8", "8", "--custom_steps", "10"]
+    H.main(["calibrate", "--out", out, "--calib_num_samples", "32", "--batch_samples", "8", "--iters", "2"] + common)
+    line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert line["job"] == "calibrate" and line["units"] > 10 and line["frozen_bytes"] > 0
+    save_a, save_b = str(tmp_path / "a"), str(tmp_path / "b")
+    for save in (save_a, save_b):
+        H.main(["sample", "--state", out, "--n_samples", "16", "--n_batch", "4", "--no_decode", "--save", save] + common)
+        line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+        assert line["images"] == 16 and line["ranks"] == 1
+    for i in range(4):
+        a, b = np.load("%s/batch_%06d.npy" % (save_a, i)), np.load("%s/batch_%06d.npy" % (save_b, i))
+        assert np.isfinite(a).all() and np.array_equal(a, b), i
+    assert not np.array_equal(np.load(save_a + "/batch_000000.npy"), np.load(save_a + "/batch_000001.npy"))
+    # the shard of rank 1 of 2 = batches 1 and 3 of the same global sequence
+    from edadm import dist as edist
+    orig = edist.world
+    edist.world = lambda: (1, 2)
+    try:
+        save_c = str(tmp_path / "c")
+        H.main(["sample", "--state", out, "--n_samples", "16", "--n_batch", "4", "--no_decode", "--save", save_c] + common)
+    finally:
+        edist.world = orig
+    import os
+    assert sorted(os.listdir(save_c)) == ["batch_000001.npy", "batch_000003.npy"]
+    for i in (1, 3):
+        assert np.array_equal(np.load("%s/batch_%06d.npy" % (save_c, i)), np.load("%s/batch_%06d.npy" % (save_a, i)))
