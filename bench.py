@@ -99,6 +99,47 @@ def time_decoder(dev, B):
                       "expansions (fp32-grade, DESIGN.md section 4), the rest on the exact-fp32 MFMA; random-init weights"}
 
 
+def end_to_end(loop, noise, cond, uncond, args, dev, B):
+    """Latents -> images as the reference's loop delivers them (sample_diffusion_ldm_imagenet.py:215-249 decodes every
+    batch): the VQ-f4 decode of batch k runs on a second HIP stream while batch k + 1 samples on the first."""
+    from edadm.nets.vq_decoder import Decoder
+    from edadm.decoder import DecoderEngine
+    torch.manual_seed(4321)
+    dec = DecoderEngine(Decoder(**VQF4).to(dev).eval(), torch.nn.Conv2d(3, 3, 1).to(dev), codebook=torch.randn(8192, 3, device=dev))
+    side = torch.cuda.Stream(device=dev)
+    n = max(args.steps, 2)
+    lat = loop.sample(noise[0], cond, uncond)
+    with torch.cuda.stream(side):
+        dec(lat)                                      # warm the side stream's buffers
+    torch.cuda.synchronize()
+    out = {}
+    for mode in ("serial", "overlapped"):
+        torch.cuda.synchronize()
+        t0 = time.time()
+        prev, imgs = None, 0
+        for i in range(n):
+            if mode == "overlapped" and prev is not None:
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    prev.record_stream(side)
+                    imgs += dec(prev).shape[0]
+                prev = None
+            lat = loop.sample(noise[i % len(noise)], cond, uncond)
+            if mode == "serial":
+                imgs += dec(lat).shape[0]
+            else:
+                prev = lat
+        if prev is not None:
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                prev.record_stream(side)
+                imgs += dec(prev).shape[0]
+        torch.cuda.synchronize()
+        out[mode] = imgs / (time.time() - t0)
+    return {"metric": "images/sec, latents sampled AND decoded to 256x256 pixels", "value": max(out.values()), "unit": "images/sec",
+            "serial": out["serial"], "decode_on_second_stream": out["overlapped"], "batches": n}
+
+
 def time_calibration(qnn, dev, n_calib=256, iters=20):
     """The calibration hot loop (H1) on the same full-size UNet: the conditional reconstruction walk
     (qdiff_control.recon_block_Qmodel, every unit of the model) with `n_calib` synthetic calibration samples
@@ -420,13 +461,29 @@ def main():
             try:
                 line["calibration"]["reconstruction"] = time_calibration(qnn, dev)
                 line["calibration"]["h1_contraction"] = time_h1_contraction(dev)
+                try:        # the MEASURED full run (python bench.py --full-calib, committed) next to this run's extrapolation
+                    with open(os.path.join(ROOT, "profiles", "r02a_full_calibration.json")) as fh:
+                        full = json.load(fh)["calibration"]
+                    ext = line["calibration"]["reconstruction"]["extrapolated_full_s"]["total"]
+                    line["calibration"]["measured_full_s"] = {
+                        "wall_s": full["wall_s"], "caching_s": full["caching_s"], "loop_s": full["loop_s"],
+                        "source": "profiles/r02a_full_calibration.json: 1024 samples x 1000 iterations x 80 units on one MI355X "
+                                  "(build of that commit; later builds are faster per iteration)",
+                        "this_run_extrapolation_s": ext, "extrapolation_over_measured": ext / full["wall_s"]}
+                except Exception:
+                    pass
             except Exception as e:
                 line["calibration"]["reconstruction"] = {"error": repr(e)}
         if world == 1 and not args.no_decode:
             try:
                 d = time_decoder(dev, B)
                 d["images_per_sec_unet_plus_decode"] = 1.0 / (elapsed / (B * args.steps) + d["wall_s"] / B)
+                d["roofline"] = {"bound": "mfma", "achieved": 3 * d["tflops_fp32"], "peak": 2516.0, "unit": "TFLOP/s",
+                                 "frac": 3 * d["tflops_fp32"] / 2516.0,
+                                 "note": "three f16 MFMA products per fp32 product (fp32-grade result): fp32-equivalent rate x 3 "
+                                         "against the dense f16 MFMA peak"}
                 line["first_stage_decode"] = d
+                line["end_to_end"] = end_to_end(loop, noise, cond, uncond, args, dev, B)
             except Exception as e:
                 line["first_stage_decode"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:

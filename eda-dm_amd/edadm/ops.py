@@ -33,7 +33,9 @@ def _pf(t):
 
 def workspace(device, floats=None):
     n = int(lib.load().edadm_reduce_ws_floats()) if floats is None else int(floats)
-    key = (device.index, "r" if floats is None else "x")
+    # one buffer per (device, stream): launches on different streams may run concurrently (a decoder on a side stream next to
+    # the sampling graph), and a graph captured on its capture stream keeps the buffer of that stream to itself
+    key = (device.index, "r" if floats is None else "x", torch.cuda.current_stream(device).cuda_stream)
     w = _ws.get(key)
     if w is None or w.numel() < n:
         if w is not None:
