@@ -294,6 +294,9 @@ def main():
     ap.add_argument("--no-decode", action="store_true", help="skip the first-stage decoder timing")
     ap.add_argument("--full-calib", action="store_true",
                     help="run ONLY the full calibration (1024 samples x 1000 iterations x every unit, ~10 min) and print its line")
+    ap.add_argument("--calib-ranks", action="store_true",
+                    help="with --gpus N > 1: also time a bounded reconstruction walk with the activation caching sharded over the "
+                         "ranks (all_gather_into_tensor of the cached slabs + broadcast of the learned parameters per unit)")
     ap.add_argument("--calib-samples", type=int, default=None)
     ap.add_argument("--calib-iters", type=int, default=None)
     args = ap.parse_args()
@@ -424,6 +427,16 @@ def main():
             traffic = tj["hbm_bytes_per_launch"] * tj["launches"] / tj.get("unet_calls", 4) / max(len(i8), 1)
     except Exception:
         pass
+    calib_mr = None
+    if world > 1 and args.calib_ranks:
+        # every rank runs the walk (the loop is replicated); the caching batches are sharded and all-gathered
+        from edadm import dist as edist
+        edist.GATHER_STATS.update(bytes=0, calls=0)
+        r = time_calibration(qnn, dev, n_calib=32 * world * 2, iters=3)
+        calib_mr = {"ranks": world, "units": r["units"], "calib_samples": r["calib_samples"], "caching_s": r["caching_s"],
+                    "caching_s_per_unit": r["caching_s"] / max(r["units"], 1), "gathered_bytes": edist.GATHER_STATS["bytes"],
+                    "gather_calls": edist.GATHER_STATS["calls"], "loop_s": r["loop_s"],
+                    "transport": "all_gather_into_tensor over RCCL (one slab per cached tensor, in place) + broadcast of alphas / step sizes from rank 0"}
     if rank == 0:
         images = B * args.steps * world
         achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12
@@ -457,6 +470,8 @@ def main():
                          "unet_algorithmic_tflops": 2 * B * UNET_GFLOP_PER_ROW / unet_ms},
             "calibration": calib,
         }
+        if calib_mr is not None:
+            line["calibration"]["multi_rank"] = calib_mr
         if world == 1 and not args.no_calib:
             try:
                 line["calibration"]["reconstruction"] = time_calibration(qnn, dev)
