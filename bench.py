@@ -211,6 +211,7 @@ def time_calibration(qnn, dev, n_calib=256, iters=20):
     setup = max(loop - timing["iter_s"] - feat, 0.0)
     return dict(units=units, calib_samples=n_calib, iters_per_unit=iters, wall_s=total, caching_s=t_cache[0],
                 loop_s=loop, unit_setup_s=setup, s_per_iteration_all_units=per_iter_all_units,
+                per_unit_ms=[{"unit": u, "weights": n, "ms_per_iteration": ms} for u, n, ms in timing.get("per_unit", [])],
                 fp_features={"s": feat, "units_cached": timing.get("feat_units", 0), "budget_gb_at_1024_samples": feat_gb},
                 fp_trace={"budget_gb_at_1024_samples": full_gb, "fp_prefix_sweeps": du.STATS["fp_captures"],
                           "units_served": du.STATS["units_served"], "memo_budget_gb_at_1024_samples": memo_gb,

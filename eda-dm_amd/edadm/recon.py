@@ -278,6 +278,8 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
         torch.cuda.synchronize()
         TIMING["iter_s"] += time.time() - _t_steady
         TIMING["iters"] += iters - 1
+        TIMING.setdefault("per_unit", []).append((type(unit).__name__, sum(p.numel() for p in w_para),
+                                                  1e3 * (time.time() - _t_steady) / (iters - 1)))
     for module in modules:
         if isinstance(module, QuantModule):
             module.weight_quantizer.soft_targets = False
