@@ -14,11 +14,24 @@ __device__ __forceinline__ float fq_one(float x, float d, float z, float qmax, f
     return (c - z) * d;
 }
 
+// Mask-RNG epoch: a device word folded into every mask seed.  A reconstruction iteration captured into a HIP graph bakes
+// its kernels' seed ARGUMENTS into the graph; the epoch, bumped by a one-thread kernel at the head of the graph, is what
+// makes replay k draw masks different from replay k - 1 (forward and backward of one replay read the same value).
+// 0 (the initial value) leaves every seed as passed.
+static __device__ uint64_t g_rng_epoch = 0;
+__device__ __forceinline__ uint64_t epoch_seed(uint64_t seed) { return seed + g_rng_epoch * 0xD1B54A32D192ED03ull; }
+static __global__ void k_rng_epoch(uint64_t v, int add) { g_rng_epoch = add ? g_rng_epoch + v : v; }
+extern "C" int edadm_rng_epoch(uint64_t value, int add, void* stream) {
+    hipLaunchKernelGGL(k_rng_epoch, dim3(1), dim3(1), 0, (hipStream_t)stream, value, add);
+    return edadm_launch_status();
+}
+
 __global__ void __launch_bounds__(256) k_fq_fwd(const float* __restrict__ x, float* __restrict__ out,
                                                 float* __restrict__ codes, int64_t n,
                                                 const float* __restrict__ delta, const float* __restrict__ zp,
                                                 int64_t nq, int64_t inner, float qmax,
-                                                const float* __restrict__ u, float prob, uint64_t seed) {
+                                                const float* __restrict__ u, float prob, uint64_t seed_arg) {
+    const uint64_t seed = epoch_seed(seed_arg);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const bool vec = ((n & 3) == 0) && (nq == 1 || (inner & 3) == 0);
     const bool mix = prob < 1.0f;
@@ -96,7 +109,8 @@ __global__ void __launch_bounds__(256) k_fq_bwd(const float* __restrict__ gy, co
                                                 float* __restrict__ gx, float* __restrict__ part, int64_t n,
                                                 const float* __restrict__ delta, const float* __restrict__ zp,
                                                 float qmax, const float* __restrict__ u, float prob,
-                                                uint64_t seed) {
+                                                uint64_t seed_arg) {
+    const uint64_t seed = epoch_seed(seed_arg);
     __shared__ float sm[4];
     const float d = delta[0], z = zp[0];
     const bool mix = prob < 1.0f;
@@ -428,7 +442,8 @@ extern "C" int edadm_adam_step(float* p, const float* g, float* m, float* v, int
 // ------------------------------------------------------------------------------------------ K10
 __global__ void __launch_bounds__(256) k_mix(const float* __restrict__ a, const float* __restrict__ b,
                                              float* __restrict__ out, int64_t n, const float* __restrict__ u,
-                                             float prob, uint64_t seed) {
+                                             float prob, uint64_t seed_arg) {
+    const uint64_t seed = epoch_seed(seed_arg);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const float r = u ? u[i] : rng_uniform(seed, (uint64_t)i);

@@ -172,6 +172,12 @@ def adam_step(p, g, m, v, hyper):
     lib.call("edadm_adam_step", _pf(p), _pf(g), _pf(m), _pf(v), p.numel(), _pf(hyper), _stream())
 
 
+def rng_epoch(value, add=False):
+    """Set (add=False) or increment the device-side mask-RNG epoch that edadm_fake_quant_* / edadm_mix_where fold into their
+    seed arguments (edadm.h): one launch on the current stream, capturable."""
+    lib.call("edadm_rng_epoch", ctypes.c_uint64(int(value)), 1 if add else 0, _stream())
+
+
 def mix_where(a, b, prob, u=None, seed=0):
     out = torch.empty_like(a)
     lib.call("edadm_mix_where", _pf(a), _pf(b), _pf(out), a.numel(), _pf(u), float(prob), int(seed), _stream())

@@ -108,12 +108,20 @@ class FusedAdam:
                 p.grad = self.grad[o:o + k].view(p.shape)
             o += k
 
-    def step(self):
+    def prepare(self):
+        """host half of a step: the step's learning rate and bias corrections into the device-side hyper vector"""
         lr = self.lr0 * (1 + math.cos(math.pi * self.t / self.t_max)) / 2
         self.t += 1
         b1, b2 = self.betas
         self.hyper.copy_(torch.tensor([lr / (1 - b1 ** self.t), math.sqrt(1 - b2 ** self.t), b1, b2]))
+
+    def launch(self):
+        """device half: one kernel over the flat slab (capturable: reads the hyper vector from device memory)"""
         ops.adam_step(self.flat, self.grad, self.m, self.v, self.hyper)
+
+    def step(self):
+        self.prepare()
+        self.launch()
 
 
 def _as_param(q):
@@ -138,6 +146,10 @@ def _attention_quantizers(module, control=True):
 
 # bench.py sets TIMING = {"iter_s": 0.0, "iters": 0}: wall time of every iteration after the first of each unit
 TIMING = None
+# iterations from which a unit's loop replays a HIP graph of one iteration (0 / huge = always eager), and the eager iterations
+# in front of the capture (lazy initialisation, allocator warm-up)
+GRAPH_MIN_ITERS = int(os.environ.get("EDADM_RECON_GRAPH_MIN_ITERS", "64"))
+GRAPH_WARMUP = 2
 
 
 def fp_features(unit, hooks, cached_inps, resblock, sz, chunk, budget_bytes):
@@ -233,12 +245,18 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
             torch.cuda.synchronize()
             TIMING["feat_s"] = TIMING.get("feat_s", 0.0) + time.time() - _t_feat
             TIMING["feat_units"] = TIMING.get("feat_units", 0) + (feats is not None)
-    for it in range(iters):
-        if TIMING is not None and it == 1:                 # steady-state iterations only (bench.py): the first one
-            torch.cuda.synchronize()                       # carries allocator warm-up and lazy initialisation
-            _t_steady = time.time()
-        idx = random.sample(range(sz), batch_size)
-        idx_t = torch.tensor(idx, device=cached_outs.device)
+    # One iteration is ~400-2000 kernel launches; at the 16x16 and 8x8 levels they are so short that the loop is bound by
+    # the host's launch rate (5 us per launch through Python + autograd), not by the GPU.  From the third iteration on the
+    # whole iteration -- gathers of the drawn minibatch, the three forwards, autograd's backward, both Adam launches -- is
+    # therefore ONE HIP-graph replay: the minibatch indices go through a static device buffer, the learning-rate vector is
+    # written before the replay, and the stochastic masks (kernel seed ARGUMENTS are frozen in a graph) come from a device-side
+    # epoch word bumped at the head of every replay (edadm_rng_epoch).  Same kernels, same order, same bits as eager.
+    use_graph = iters >= GRAPH_MIN_ITERS and cached_outs.is_cuda
+    idx_buf = torch.zeros(batch_size, dtype=torch.long, device=cached_outs.device)
+    graph = None
+
+    def body():
+        idx_t = idx_buf
         cur_out = cached_outs[idx_t]
         if resblock:
             cur_inp, cur_sym = cached_inps[0][0][idx_t], cached_inps[1][0][idx_t]
@@ -273,7 +291,29 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
         loss.backward()
         for o in (w_opt, a_opt):
             if o:
-                o.step()
+                o.launch()
+
+    for it in range(iters):
+        if TIMING is not None and it == 1:                 # steady-state iterations only (bench.py): the first one
+            torch.cuda.synchronize()                       # carries allocator warm-up and lazy initialisation
+            _t_steady = time.time()
+        idx = random.sample(range(sz), batch_size)
+        idx_buf.copy_(torch.tensor(idx))
+        for o in (w_opt, a_opt):
+            if o:
+                o.prepare()
+        if graph is not None:
+            graph.replay()
+            continue
+        if use_graph and it >= GRAPH_WARMUP:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                ops.rng_epoch(1, add=True)
+                body()
+            graph.replay()                                 # capture does not execute: this runs iteration `it`
+            continue
+        body()
+    del graph
     if TIMING is not None and iters > 1:
         torch.cuda.synchronize()
         TIMING["iter_s"] += time.time() - _t_steady

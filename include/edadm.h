@@ -328,6 +328,12 @@ int edadm_unpack_w4(const uint8_t* packed, const float* zp, int8_t* out, int64_t
                     void* stream);
 int edadm_pack_w4(const int8_t* w, const float* zp, uint8_t* packed, int64_t rows, int64_t cols, void* stream);
 
+/* Mask-RNG epoch (a device word added, times an odd constant, to the seed argument of edadm_fake_quant_fwd/_bwd and
+ * edadm_mix_where): add = 0 sets it, add = 1 increments it by `value`.  A reconstruction iteration replayed from a HIP graph
+ * (block_recon.py:136-210 as one graph launch) keeps its captured seed arguments and bumps the epoch at the head of every
+ * replay, so each iteration draws fresh masks (the `torch.rand_like` of quant_layer.py:271-272, block_recon.py:141-143). */
+int edadm_rng_epoch(uint64_t value, int add, void* stream);
+
 /* Direct 3x3 convolution (stride 1, pad 1) of the long-K int8 layers (quant_layer.py:406-437 at inference, F.conv2d): the
  * input patch of a 256-pixel tile stays in LDS per 64-channel chunk, so an activation byte crosses L2 -> LDS once per
  * chunk instead of once per tap.  Wdc = the filter in the kernel's own layout (edadm_conv3_pack_w from the [N][3][3][Cin]

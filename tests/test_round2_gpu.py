@@ -201,7 +201,7 @@ def test_layer_recon_walk_with_attention_step_sizes(golden):
                   recon_w=True, recon_a=True, keep_gpu=True)
     names = {m: n for n, m in qnn.named_modules()}
     traj, order, cur = {}, [], {"name": None}
-    orig_step = recon.FusedAdam.step
+    orig_step = recon.FusedAdam.launch
     ol, oa = rl.layer_reconstruction, rl.AttnBlock_layer_reconstruction
 
     def step(self):
@@ -216,13 +216,13 @@ def test_layer_recon_walk_with_attention_step_sizes(golden):
             return fn(model, unit, **kw)
         return run
 
-    recon.FusedAdam.step = step
+    recon.FusedAdam.launch = step
     rl.layer_reconstruction, rl.AttnBlock_layer_reconstruction = wrap("layer", ol), wrap("attn", oa)
     try:
         random.seed(1616)
         rl.recon_layer_Qmodel(None, qnn, cali, kwargs).recon()
     finally:
-        recon.FusedAdam.step = orig_step
+        recon.FusedAdam.launch = orig_step
         rl.layer_reconstruction, rl.AttnBlock_layer_reconstruction = ol, oa
     assert order == [str(u) for u in g["order"]] == [u[0] for u in G16_UNITS]
     assert qnn.block_count == int(g["block_count"])
