@@ -255,6 +255,8 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
     idx_buf = torch.zeros(batch_size, dtype=torch.long, device=cached_outs.device)
     graph = None
 
+    dbg = os.environ.get("EDADM_GRAPH_DEBUG", "")          # diagnostics only (tools/graph_bisect.py)
+
     def body():
         idx_t = idx_buf
         cur_out = cached_outs[idx_t]
@@ -268,12 +270,12 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
         elif is_block:
             cur_inp = cur_sym                 # block_recon.py:144-145 (the layer loop keeps cur_inp)
         for o in (w_opt, a_opt):
-            if o:
+            if o and "nozero" not in dbg:
                 o.zero_grad()
         args_q = (cur_inp, temb_inp) if resblock else (cur_inp,)
         out_quant = unit(*args_q)
         m_loss = 0.0
-        if is_block and hooks:
+        if is_block and hooks and "nosecond" not in dbg:
             if feats is not None:
                 module_r = [f[idx_t] for f in feats] + [None]
             else:
@@ -288,9 +290,11 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
             for j in range(len(module_r) - 1):
                 m_loss = m_loss + lp_loss(module_q[j], module_r[j], p=2)
         loss = loss_func(out_quant, cur_out) + add_loss * m_loss
+        if "nobwd" in dbg:
+            return
         loss.backward()
         for o in (w_opt, a_opt):
-            if o:
+            if o and "noadam" not in dbg:
                 o.launch()
 
     for it in range(iters):
