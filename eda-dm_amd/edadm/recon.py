@@ -191,7 +191,7 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
     modules = list(unit.modules()) if is_block else [unit]
     for module in modules:
         if isinstance(module, QuantModule):
-            if is_block:
+            if is_block and "nohooks" not in os.environ.get("EDADM_GRAPH_DEBUG", ""):
                 hooks.append(AttentionMap(module))
             if module.split == 0 or (control and not is_block):
                 module.weight_quantizer = AdaRoundQuantizer(uaq=module.weight_quantizer, round_mode=round_mode,
@@ -311,7 +311,7 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
             continue
         if use_graph and it >= GRAPH_WARMUP:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, **({"capture_error_mode": "thread_local"} if "threadlocal" in dbg else {})):
                 ops.rng_epoch(1, add=True)
                 body()
             graph.replay()                                 # capture does not execute: this runs iteration `it`

@@ -1,7 +1,7 @@
 """Diagnostic: which units' reconstruction iteration survives HIP-graph capture (each case in its own process)."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CASES = ["block:rb", "block:rb:dbg=nosecond", "block:rb:dbg=nobwd", "block:rb:dbg=noadam", "block:rb:dbg=nozero", "block:rb:dbg=nosecond,nozero", "block:rb:recon_a0", "block:rb:recon_w0", "block:rb:iters200"]
+CASES = ["asblock:conv_in", "asblock:temb_lin", "block:rb:noactq", "block:rb:f16x3off", "block:rb:threadlocal", "block:rb:fp", "block:rb:nohooks"]
 if len(sys.argv) == 1:
     for c in CASES:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), c], capture_output=True, text=True)
@@ -15,6 +15,12 @@ import numpy as np, torch, random
 case = sys.argv[1].split(":")
 if "nofeat" in case:
     os.environ["EDADM_FP_FEAT_GB"] = "0"
+if "f16x3off" in case:
+    os.environ["EDADM_F16X3"] = "0"
+if "threadlocal" in case:
+    os.environ["EDADM_GRAPH_DEBUG"] = "threadlocal"
+if "nohooks" in case:
+    os.environ["EDADM_GRAPH_DEBUG"] = "nohooks"
 for c in case:
     if c.startswith("dbg="):
         os.environ["EDADM_GRAPH_DEBUG"] = c[4:]
@@ -34,7 +40,9 @@ kw = dict(cali_data=(x, t), iters=10, act_quant=True, asym=True, opt_mode="mse",
 if "iters200" in case:
     kw["iters"] = 200
 recon.GRAPH_MIN_ITERS = 4
-fn = {"layer": layer_reconstruction, "block": block_reconstruction, "attn": AttnBlock_layer_reconstruction}[case[0]]
+if "noactq" in case:
+    kw["act_quant"] = False
+fn = {"layer": layer_reconstruction, "block": block_reconstruction, "asblock": block_reconstruction, "attn": AttnBlock_layer_reconstruction}[case[0]]
 fn(qnn, getattr(qnn.model, case[1]), **kw)
 torch.cuda.synchronize()
 print("ok", case)
