@@ -296,6 +296,8 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
         for o in (w_opt, a_opt):
             if o and "noadam" not in dbg:
                 o.launch()
+        for h in hooks:                       # tensors of this iteration must not outlive it (they would pin the autograd
+            h.out = h.feature = None          # graph of a captured iteration past the end of the capture)
 
     for it in range(iters):
         if TIMING is not None and it == 1:                 # steady-state iterations only (bench.py): the first one

@@ -1,7 +1,7 @@
 """Diagnostic: which units' reconstruction iteration survives HIP-graph capture (each case in its own process)."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CASES = ["asblock:conv_in", "asblock:temb_lin", "block:rb:noactq", "block:rb:f16x3off", "block:rb:threadlocal", "block:rb:fp", "block:rb:nohooks"]
+CASES = ["asblock:conv_in", "block:rb", "block:rb:nofeat", "block:at"]
 if len(sys.argv) == 1:
     for c in CASES:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), c], capture_output=True, text=True)
