@@ -140,12 +140,12 @@ def end_to_end(loop, noise, cond, uncond, args, dev, B):
             "serial": out["serial"], "decode_on_second_stream": out["overlapped"], "batches": n}
 
 
-def time_calibration(qnn, dev, n_calib=256, iters=20):
+def time_calibration(qnn, dev, n_calib=256, iters=40):
     """The calibration hot loop (H1) on the same full-size UNet: the conditional reconstruction walk
     (qdiff_control.recon_block_Qmodel, every unit of the model) with `n_calib` synthetic calibration samples
     (CFG-doubled rows) and `iters` iterations per unit.  The shipped setting is 1024 samples x 1000 iterations
     (sample_diffusion_ldm_imagenet.py:165-196): `--full-calib` runs exactly that and reports the measured wall-clock;
-    the default bench line runs a bounded 256 x 20 and extrapolates linearly, next to the committed measurement."""
+    the default bench line runs a bounded 256 x 40 (iterations replayed from a HIP graph, as in the full run) and extrapolates linearly, next to the committed measurement."""
     import qdiff_control.block_recon as cb
     import qdiff_control.layer_recon as cl
     from qdiff_control import recon_block_Qmodel
@@ -212,6 +212,7 @@ def time_calibration(qnn, dev, n_calib=256, iters=20):
     return dict(units=units, calib_samples=n_calib, iters_per_unit=iters, wall_s=total, caching_s=t_cache[0],
                 loop_s=loop, unit_setup_s=setup, s_per_iteration_all_units=per_iter_all_units,
                 per_unit_ms=[{"unit": u, "weights": n, "ms_per_iteration": ms} for u, n, ms in timing.get("per_unit", [])],
+                graphed_units=timing.get("graphed_units", 0),
                 fp_features={"s": feat, "units_cached": timing.get("feat_units", 0), "budget_gb_at_1024_samples": feat_gb},
                 fp_trace={"budget_gb_at_1024_samples": full_gb, "fp_prefix_sweeps": du.STATS["fp_captures"],
                           "units_served": du.STATS["units_served"], "memo_budget_gb_at_1024_samples": memo_gb,

@@ -148,7 +148,7 @@ def _attention_quantizers(module, control=True):
 TIMING = None
 # iterations from which a unit's loop replays a HIP graph of one iteration (0 / huge = always eager), and the eager iterations
 # in front of the capture (lazy initialisation, allocator warm-up)
-GRAPH_MIN_ITERS = int(os.environ.get("EDADM_RECON_GRAPH_MIN_ITERS", "64"))
+GRAPH_MIN_ITERS = int(os.environ.get("EDADM_RECON_GRAPH_MIN_ITERS", "32"))
 GRAPH_WARMUP = 2
 
 
@@ -254,6 +254,7 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
     use_graph = iters >= GRAPH_MIN_ITERS and cached_outs.is_cuda
     idx_buf = torch.zeros(batch_size, dtype=torch.long, device=cached_outs.device)
     graph = None
+    t_first = GRAPH_WARMUP + 1 if use_graph else 1
 
     dbg = os.environ.get("EDADM_GRAPH_DEBUG", "")          # diagnostics only (tools/graph_bisect.py)
 
@@ -300,8 +301,8 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
             h.out = h.feature = None          # graph of a captured iteration past the end of the capture)
 
     for it in range(iters):
-        if TIMING is not None and it == 1:                 # steady-state iterations only (bench.py): the first one
-            torch.cuda.synchronize()                       # carries allocator warm-up and lazy initialisation
+        if TIMING is not None and it == t_first:           # steady-state iterations only (bench.py): the first ones carry
+            torch.cuda.synchronize()                       # allocator warm-up, lazy initialisation and the graph capture
             _t_steady = time.time()
         idx = random.sample(range(sz), batch_size)
         idx_buf.copy_(torch.tensor(idx))
@@ -320,12 +321,13 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
             continue
         body()
     del graph
-    if TIMING is not None and iters > 1:
+    if TIMING is not None and iters > t_first:
         torch.cuda.synchronize()
         TIMING["iter_s"] += time.time() - _t_steady
-        TIMING["iters"] += iters - 1
+        TIMING["iters"] += iters - t_first
+        TIMING["graphed_units"] = TIMING.get("graphed_units", 0) + int(use_graph)
         TIMING.setdefault("per_unit", []).append((type(unit).__name__, sum(p.numel() for p in w_para),
-                                                  1e3 * (time.time() - _t_steady) / (iters - 1)))
+                                                  1e3 * (time.time() - _t_steady) / (iters - t_first)))
     for module in modules:
         if isinstance(module, QuantModule):
             module.weight_quantizer.soft_targets = False
