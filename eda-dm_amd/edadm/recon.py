@@ -191,7 +191,7 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
     modules = list(unit.modules()) if is_block else [unit]
     for module in modules:
         if isinstance(module, QuantModule):
-            if is_block and "nohooks" not in os.environ.get("EDADM_GRAPH_DEBUG", ""):
+            if is_block:
                 hooks.append(AttentionMap(module))
             if module.split == 0 or (control and not is_block):
                 module.weight_quantizer = AdaRoundQuantizer(uaq=module.weight_quantizer, round_mode=round_mode,
@@ -256,8 +256,6 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
     graph = None
     t_first = GRAPH_WARMUP + 1 if use_graph else 1
 
-    dbg = os.environ.get("EDADM_GRAPH_DEBUG", "")          # diagnostics only (tools/graph_bisect.py)
-
     def body():
         idx_t = idx_buf
         cur_out = cached_outs[idx_t]
@@ -271,12 +269,12 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
         elif is_block:
             cur_inp = cur_sym                 # block_recon.py:144-145 (the layer loop keeps cur_inp)
         for o in (w_opt, a_opt):
-            if o and "nozero" not in dbg:
+            if o:
                 o.zero_grad()
         args_q = (cur_inp, temb_inp) if resblock else (cur_inp,)
         out_quant = unit(*args_q)
         m_loss = 0.0
-        if is_block and hooks and "nosecond" not in dbg:
+        if is_block and hooks:
             if feats is not None:
                 module_r = [f[idx_t] for f in feats] + [None]
             else:
@@ -291,11 +289,9 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
             for j in range(len(module_r) - 1):
                 m_loss = m_loss + lp_loss(module_q[j], module_r[j], p=2)
         loss = loss_func(out_quant, cur_out) + add_loss * m_loss
-        if "nobwd" in dbg:
-            return
         loss.backward()
         for o in (w_opt, a_opt):
-            if o and "noadam" not in dbg:
+            if o:
                 o.launch()
         for h in hooks:                       # tensors of this iteration must not outlive it (they would pin the autograd
             h.out = h.feature = None          # graph of a captured iteration past the end of the capture)
@@ -314,7 +310,7 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
             continue
         if use_graph and it >= GRAPH_WARMUP:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, **({"capture_error_mode": "thread_local"} if "threadlocal" in dbg else {})):
+            with torch.cuda.graph(graph):
                 ops.rng_epoch(1, add=True)
                 body()
             graph.replay()                                 # capture does not execute: this runs iteration `it`
