@@ -3,6 +3,7 @@
 // (K6), layout changes.  All HBM-bound: each input element is read once (GroupNorm: twice — one
 // statistics pass, one apply pass) and each operand byte written once; 16-byte accesses.
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/edadm.h"
 #include <hip/hip_fp16.h>
 
@@ -345,6 +346,66 @@ __global__ void __launch_bounds__(256) k_gn_apply(const float* __restrict__ x, c
         if (Q <= 256) break;
     }
 }
+// The common sampling form -- ONE int8 operand out (+ optionally the raw-input operand), no fp32 output, no scale-shift,
+// channel counts in multiples of 16 -- with 16 channels per thread: four 16-byte loads in flight per lane and one 16-byte
+// store per operand (k_gn_apply moves 16 B in / 4 B out per lane and iteration).  Same arithmetic per 4-channel group as
+// k_gn_apply (same `quant4`, same boundary test granularity): identical bits.
+__global__ void __launch_bounds__(256) k_gn_apply16(const float* __restrict__ x, const float* __restrict__ x2, int64_t C1,
+                                                    const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, int64_t HW, int64_t C, int64_t G, int silu,
+                                                    int8_t* __restrict__ q0, const QP* __restrict__ qp, int rows_per_block,
+                                                    int8_t* __restrict__ qraw, const QP* __restrict__ qpr, int64_t raw_split,
+                                                    int64_t B2) {
+    const int64_t b = blockIdx.y;
+    const int64_t b2 = B2 > 0 ? b % B2 : b;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < HW ? r0 + rows_per_block : HW;
+    const int G16 = (int)(C >> 4), RS = 256 / G16;
+    const int tid = threadIdx.x;
+    const int grp = tid % G16, rs = tid / G16;
+    if (rs >= RS) return;
+    const int cpg = (int)(C / G);
+    const QP qa = qp_load(qp, 0);
+    float a[16], bb[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int c = grp * 16 + j;
+        const int g = c / cpg;
+        const float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
+        a[j] = rstd * gamma[c];
+        bb[j] = beta[c] - mean * a[j];
+    }
+    const bool first = grp * 16 < C1;
+    const int64_t Ca = first ? C1 : C - C1;
+    const float* src = first ? x + grp * 16 : x2 + (grp * 16 - C1);
+    const int64_t bs = first ? b : b2;
+    QP qr = qa;
+    if (qraw) qr = qp_load(qpr, (raw_split > 0 && grp * 16 >= raw_split) ? 1 : 0);
+    for (int64_t r = r0 + rs; r < r1; r += RS) {
+        const float4* p = reinterpret_cast<const float4*>(src + (bs * HW + r) * Ca);
+        const float4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
+        const float4 vv[4] = {v0, v1, v2, v3};
+        uint4 w, wr;
+        uint32_t* wp = reinterpret_cast<uint32_t*>(&w);
+        uint32_t* wrp = reinterpret_cast<uint32_t*>(&wr);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4 v = vv[k];
+            float y[4] = {v.x * a[4 * k] + bb[4 * k], v.y * a[4 * k + 1] + bb[4 * k + 1], v.z * a[4 * k + 2] + bb[4 * k + 2],
+                          v.w * a[4 * k + 3] + bb[4 * k + 3]};
+            if (silu) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) y[j] = silu_rcp(y[j]);
+            }
+            wp[k] = quant4(make_float4(y[0], y[1], y[2], y[3]), qa);
+            if (qraw) wrp[k] = quant4(v, qr);
+        }
+        const int64_t o = (b * HW + r) * C + grp * 16;
+        *reinterpret_cast<uint4*>(q0 + o) = w;
+        if (qraw) *reinterpret_cast<uint4*>(qraw + o) = wr;
+    }
+}
+
 extern "C" int edadm_groupnorm_apply_cat_raw(const float* x1, int64_t C1, const float* x2, int64_t C2, const float* stats,
                                              const float* gamma, const float* beta, const float* scale_shift, int64_t B,
                                              int64_t HW, int64_t G, int silu, float* out_f32, int8_t* q0, int8_t* q1,
@@ -356,6 +417,18 @@ extern "C" int edadm_groupnorm_apply_cat_raw(const float* x1, int64_t C1, const 
     if ((q0 || q1 || q2) && !qp) return EDADM_EINVAL;
     if (qraw && (!qp_raw || raw_split < 0 || raw_split >= C || (raw_split & 3))) return EDADM_EINVAL;
     if (B2 < 0 || (B2 > 0 && (!x2 || B % B2))) return EDADM_EINVAL;
+    static const bool wide = !getenv("EDADM_GN_APPLY16") || atoi(getenv("EDADM_GN_APPLY16")) != 0;
+    if (wide && !out_f32 && !scale_shift && nq == 1 && q0 && !q1 && !q2 && (C & 15) == 0 && (C1 & 15) == 0 && C <= 4096 &&
+        (!qraw || (raw_split & 15) == 0) && !((uintptr_t)q0 & 15) && !((uintptr_t)qraw & 15) && !((uintptr_t)x1 & 15) &&
+        !((uintptr_t)x2 & 15)) {
+        const int G16 = (int)(C >> 4), RS = 256 / G16;
+        int rpb16 = (int)(16384 / C);
+        rpb16 = rpb16 < RS ? RS : (rpb16 / RS) * RS;
+        const unsigned gx16 = (unsigned)((HW + rpb16 - 1) / rpb16);
+        hipLaunchKernelGGL(k_gn_apply16, dim3(gx16, (unsigned)B), dim3(256), 0, (hipStream_t)stream, x1, x2, C1, stats, gamma, beta,
+                           HW, C, G, silu, q0, (const QP*)qp, rpb16, qraw, (const QP*)qp_raw, raw_split, B2);
+        return edadm_launch_status();
+    }
     // rows per block: a multiple of what keeps (quad) fixed per thread when Q | 256, ~16 KB of input per block
     int rpb = (int)(16384 / C);   // ~64 KB of fp32 input per block
     if (rpb < 1) rpb = 1;

@@ -447,6 +447,34 @@ def test_cat_consumers_match_materialised_concat(ops):
             exact(ops.quant_i8(cat.reshape(-1, C), qp, split=split), ops.quant_i8(ops.Cat(a, b), qp, split=split))
 
 
+def test_groupnorm_apply_wide_equals_narrow(ops):
+    """k_gn_apply16 (one int8 operand, 16 channels per thread: the sampling form) gives the bits of k_gn_apply (taken when
+    an fp32 output is also asked for): plain, concatenated, CFG-pair-periodic second half, raw operand with split."""
+    g = torch.Generator().manual_seed(16)
+    for B, H, Ca, Cb, rep in ((2, 8, 192, 0, 1), (3, 16, 384, 192, 1), (4, 8, 960, 960, 2), (2, 4, 64, 0, 1),
+                              (2, 9, 576, 384, 1), (2, 8, 200, 0, 1)):
+        a = (torch.randn(B, H, H, Ca, generator=g) * 1.5).cuda()
+        x = a
+        if Cb:
+            b = (torch.randn(B // rep, H, H, Cb, generator=g) * 2 + 0.5).cuda()
+            x = ops.Cat(a, b)
+        C = Ca + Cb
+        G = 32 if C % 32 == 0 else 8
+        gamma, beta = torch.randn(C, generator=g).cuda(), torch.randn(C, generator=g).cuda()
+        qp = ops.qp_tensor([(0.03, 120.0, 255.0)], "cuda")
+        rqp = ops.qp_tensor([(0.04, 128.0, 255.0), (0.07, 125.0, 255.0)], "cuda")
+        st = ops.groupnorm_stats(x, G, 1e-5)
+        for silu in (True, False):
+            for split in ((0, Ca) if Cb else (0,)):
+                _, qn, rn = ops.groupnorm_apply(x, st, gamma, beta, G, silu, qp=qp, nq=1, want_f32=True, raw_qp=rqp, raw_split=split)
+                _, qw, rw = ops.groupnorm_apply(x, st, gamma, beta, G, silu, qp=qp, nq=1, raw_qp=rqp, raw_split=split)
+                exact(qn[0], qw[0]), exact(rn, rw)
+            if rep == 1:
+                _, qn = ops.groupnorm_apply(x, st, gamma, beta, G, silu, qp=qp, nq=1, want_f32=True)
+                _, qw = ops.groupnorm_apply(x, st, gamma, beta, G, silu, qp=qp, nq=1)
+                exact(qn[0], qw[0])
+
+
 def test_plms_loop_golden(ops, golden):
     """K9b + PLMSLoop (edadm/sampling.py) against the reference's PLMSSampler run (G14): every intermediate x and
     pred_x0 of the 8 steps, classifier-free guidance 7.5; fp32 elementwise chains: 3e-5."""
