@@ -542,6 +542,9 @@ static __device__ uint8_t g_pad_rows[256 * 64];
 #ifdef EDADM_STAMPS
 // diagnostic build only (make stamps): per-wave cycle stamps summed over all waves of a launch
 static __device__ unsigned long long g_stamps[8];
+#ifndef EDADM_STAMP_WAVE
+#define EDADM_STAMP_WAVE 0                                  // k_conv3_direct: the wave whose stamps are summed
+#endif
 #define STAMP(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
 #define STAMP_ADD(slot, d) do { if (lane == 0) atomicAdd(&g_stamps[slot], (unsigned long long)(d)); } while (0)
 #else
@@ -1548,9 +1551,13 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
 // instead of nine times, and only the weights stream: a step is one filter row of a chunk (3 taps x 64 channels
 // = 36 MFMAs per wave between barriers), its 3 x BN x 64 B weight slab arrives by LDS-DMA into a two-slot ring while
 // the previous step computes, the next chunk's patch into the other of two patch buffers.
-//   LDS: patch pixel P, logical 16-byte chunk c at P * 64 + ((c ^ ((P >> 2) & 3)) << 4) -- the swizzle of the 64-byte-row
-//   kernels keyed by the PATCH pixel index, so 16 lanes on consecutive pixels hit 16 distinct 16-byte slots for every tap
-//   shift; the weight slab is stored pre-swizzled by the host (edadm_conv3_pack_w) and copied lane-linearly.
+//   LDS: patch pixel P = (row, col) of the patch, logical 16-byte chunk c at P * 64 + ((c ^ key) << 4) with
+//   key = (col >> KSH) & 3, KSH = 2 for W >= 32 and 1 for W <= 16: a ds_read_b128 is served in four groups of 16 lanes
+//   ({0-3, 12-15, 20-27}, ...), 32 lanes are 32 consecutive tile pixels = one stretch of a patch row (W >= 32) or two / four
+//   rows 2 halo pixels apart (W = 16 / 8), and with this key the 16 lanes of a group hit 16 distinct 16-byte slots for
+//   every tap shift in all four cases (enumerated; SQ_LDS_BANK_CONFLICT = 0).  The key (P >> 2) & 3 of the 64-byte-row
+//   GEMM kernels is conflict-free only while the lanes' patch pixels are consecutive: 2-way at W = 16, 3-way at W = 8.
+//   The weight slab is stored pre-swizzled by the host (edadm_conv3_pack_w) and copied lane-linearly.
 //   vmcnt is hand-counted: every wave issues exactly 5 weight pieces per step and PPW (3 or 4) patch pieces per chunk
 //   (surplus pieces repeat the last one: same bytes to the same place), weights before patch, so the wait in front of a
 //   step is vmcnt(PPW) when only the next chunk's patch may stay in flight and vmcnt(0) otherwise.
@@ -1588,6 +1595,7 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
     const int pieces = (NP + 15) >> 4;
     const int PPW = (pieces + 7) >> 3;                      // 3 or 4 (checked by the launcher)
     const int NC = Cin >> 6;
+    const int KSH = W >= 32 ? 2 : 1;
     const uint8_t* pad_row = g_pad_rows + (int)(uint8_t)padval * 64;
 
     // ---- this lane's patch pieces: piece q covers patch pixels 16 q .. 16 q + 15, lane -> pixel 16 q + lane / 4,
@@ -1599,12 +1607,12 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
         int q = wave + 8 * i;
         if (q > pieces - 1) q = pieces - 1;
         const int P = q * 16 + (lane >> 2);
-        const int sc = (lane & 3) ^ ((P >> 2) & 3);
         pdst[i] = (uint32_t)q * 1024u;
         psrc[i] = -1;
         if (P < NP) {
             const int img = P / (PR * PW), rem = P - img * (PR * PW);
             const int py = rem / PW, px = rem - py * PW;
+            const int sc = (lane & 3) ^ ((px >> KSH) & 3);
             const int y = y0 + py - 1, x = px - 1;
             // ups: the convolution runs over the nearest-2x upsampled image (H x W are ITS dimensions); pixel (y, x) of
             // it is pixel (y / 2, x / 2) of the stored tensor -- the upsampled tensor is never written
@@ -1637,13 +1645,14 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
         }
     };
     // ---- this lane's output pixels -> patch pixel index of tap (0, 0)
-    int pp[TM];
+    int pp[TM], pcol[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int p = wm * 64 + i * 32 + fr;                // pixel of the tile, NHWC order
         const int img = p / (TR * W), rem = p - img * (TR * W);
         const int yl = rem / W, x = rem - yl * W;
         pp[i] = (img * PR + yl) * PW + x;
+        pcol[i] = x;
     }
 
     typename Acc<0>::type acc[TM][TN];
@@ -1655,11 +1664,16 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
 
     const int S = 3 * NC;
+    STAMP(t_entry);
+#ifdef EDADM_STAMPS
+    unsigned long long d_wait = 0, d_first = 0, d_vm = 0;
+#endif
     issue_w(0);
     issue_patch(0);
     stage_epilogue_consts<BN, RA>(ec, tid, (int)blockDim.x, m0, n0, M, N, scale, bias, rowadd, rows_per_batch, 1.0f, nullptr);
     for (int s = 0; s < S; ++s) {
         const int c = s / 3, ky = s - 3 * c;
+        STAMP(ts0);
         // B(s) (and patch(c) when ky == 0) have landed once at most the next chunk's patch pieces are still in flight
         if (ky == 1 && c + 1 < NC) {
             if (PPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -1667,8 +1681,12 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        STAMP(tsv);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+#ifdef EDADM_STAMPS
+        { STAMP(ts1); if (s == 0) d_first = ts1 - t_entry; else { d_wait += ts1 - ts0; d_vm += tsv - ts0; } }
+#endif
         if (s + 1 < S) issue_w(s + 1);
         if (ky == 0 && c + 1 < NC) issue_patch(c + 1);
         const uint8_t* Ps = smem + (c & 1) * PATCH_BYTES;
@@ -1681,7 +1699,7 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
             for (int i = 0; i < TM; ++i) {
                 const int P = pp[i] + toff;
                 pa[i] = P * 64;
-                sw[i] = (P >> 2) & 3;
+                sw[i] = ((pcol[i] + kx) >> KSH) & 3;
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -1705,8 +1723,20 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
     load_epi_regs<TN, BN>(er, ec, lane, m0, m0 + wm * 64, wn * (TN * 32), rows_per_batch);
     // gn_ws [M / 64][N][2]: per-channel (sum, sum of squares) of each 64-row slab of this output, for the GroupNorm that
     // normalises it next (its statistics pass then only reduces these partials: no second read of the tensor)
+    STAMP(t_main);
     gemm_epilogue_direct_gnreg<0, TM, TN>(acc, er, lane, m0 + wm * 64, n0 + wn * (TN * 32), rowadd != nullptr, residual, ldr, out,
                                           ldo, gn_ws, N);
+#ifdef EDADM_STAMPS
+    // slots: 0 prologue (entry -> first barrier passed), 1 waits in front of the other steps (6: their vmcnt part), 2 the rest of
+    // the main loop, 3 epilogue incl. draining its stores, 4 samples, 5 total.  ONE wave of every eighth workgroup: the atomics
+    // of every wave would dominate the launch.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(t_end);
+    if (wave == EDADM_STAMP_WAVE && ((blockIdx.x + blockIdx.y) & 7) == 0) {
+        STAMP_ADD(0, d_first); STAMP_ADD(1, d_wait); STAMP_ADD(2, t_main - t_entry - d_first - d_wait); STAMP_ADD(3, t_end - t_main);
+        STAMP_ADD(4, 1); STAMP_ADD(5, t_end - t_entry); STAMP_ADD(6, d_vm);
+    }
+#endif
 }
 
 // Weight layout of k_conv3_direct from the engine's [N][ky][kx][ci] int8 filter: [N / BN][Cin / 64][ky][kx][BN][64] with

@@ -14,8 +14,12 @@ cali = (torch.randn(N, 3, 64, 64, generator=g).to(dev), torch.randint(1, 1000, (
         torch.randn(N, 1, 512, generator=g).to(dev))
 qnn.set_quant_state(True, True)
 iters = int(os.environ.get("ITERS", "30"))
-for name, unit in (("res 192@64", qnn.model.input_blocks[1][0]), ("tf 384@32", qnn.model.input_blocks[4][1].transformer_blocks[0]),
-                   ("res 960@8", qnn.model.middle_block[0])):
+units = (("res 192@64", qnn.model.input_blocks[1][0]), ("tf 384@32", qnn.model.input_blocks[4][1].transformer_blocks[0]),
+         ("res 960@8", qnn.model.middle_block[0]), ("tf 960@8", qnn.model.middle_block[1].transformer_blocks[0]),
+         ("tf 576@16", qnn.model.input_blocks[7][1].transformer_blocks[0]))
+sel = os.environ.get("UNITS")            # comma-separated substrings of the names; default: the first three
+units = [u for u in units if any(k in u[0] for k in sel.split(","))] if sel else units[:3]
+for name, unit in units:
     kw = dict(cali_data=cali, iters=iters, act_quant=True, asym=True, opt_mode='mse', lr_a=1e-4, lr_w=5e-1, p=2.0,
               weight=0.0001, b_range=(20, 2), warmup=0.2, batch_size=32, input_prob=0.5, add_loss=0.8, recon_w=True,
               recon_a=True, keep_gpu=True)
