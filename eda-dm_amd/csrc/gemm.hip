@@ -46,6 +46,15 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_addr) {
                  : "memory");
 }
 
+// the same with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset: no vector address arithmetic per piece
+__device__ __forceinline__ void glds16_s(const void* sbase, uint32_t voff, uint32_t lds_addr) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_addr)
+                 : "memory");
+}
+
 struct ConvGeom {
     int mode, B, H, W, Cin, Ho, Wo, KH, KW, stride, pad0, ups, padval, r0, r1, r2;
 };
@@ -1600,15 +1609,18 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
 
     // ---- this lane's patch pieces: piece q covers patch pixels 16 q .. 16 q + 15, lane -> pixel 16 q + lane / 4,
     // physical chunk lane % 4 (= logical chunk (lane % 4) ^ ((P >> 2) & 3) of the source pixel)
-    int psrc[4];                                            // byte offset of the source chunk at channel 0, -1 = padding
-    uint32_t pdst[4];                                       // LDS byte offset of the piece inside a patch buffer
+    // source pointer of each piece for the chunk to be requested next (padding lanes point into g_pad_rows and do not advance)
+    const uint8_t* pptr[4];
+    int pinc[4];
+    uint32_t pdst[4];                                       // LDS byte offset of the piece inside a patch buffer (wave-uniform)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int q = wave + 8 * i;
         if (q > pieces - 1) q = pieces - 1;
         const int P = q * 16 + (lane >> 2);
-        pdst[i] = (uint32_t)q * 1024u;
-        psrc[i] = -1;
+        pdst[i] = (uint32_t)__builtin_amdgcn_readfirstlane(q * 1024);
+        pptr[i] = pad_row + (lane & 3) * 16;
+        pinc[i] = 0;
         if (P < NP) {
             const int img = P / (PR * PW), rem = P - img * (PR * PW);
             const int py = rem / PW, px = rem - py * PW;
@@ -1616,24 +1628,31 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
             const int y = y0 + py - 1, x = px - 1;
             // ups: the convolution runs over the nearest-2x upsampled image (H x W are ITS dimensions); pixel (y, x) of
             // it is pixel (y / 2, x / 2) of the stored tensor -- the upsampled tensor is never written
-            if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
-                psrc[i] = ups ? (((b0 + img) * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1)) * Cin + sc * 16
-                              : (((b0 + img) * H + y) * W + x) * Cin + sc * 16;
+            if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+                const int off = ups ? (((b0 + img) * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1)) * Cin + sc * 16
+                                    : (((b0 + img) * H + y) * W + x) * Cin + sc * 16;
+                pptr[i] = A + off;
+                pinc[i] = 64;
+            }
         }
     }
-    auto issue_patch = [&](int c) {
-        const uint32_t base = lds0 + (uint32_t)((c & 1) * PATCH_BYTES);
+    int pnext = 0;                                          // patch buffer the next request goes to
+    auto issue_patch = [&]() {                              // chunks are requested in order: each call advances the pointers
+        const uint32_t base = lds0 + (uint32_t)(pnext * PATCH_BYTES);
+        pnext ^= 1;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (i < PPW) {
-                const uint8_t* src = psrc[i] >= 0 ? A + (int64_t)psrc[i] + c * 64 : pad_row + (lane & 3) * 16;
-                glds16(src, base + pdst[i]);
+                glds16(pptr[i], base + pdst[i]);
+                pptr[i] += pinc[i];
             }
         }
     };
-    // ---- weight slab of step s = 3 c + ky: 36 (TN = 3) pieces of 1 KiB, 5 per wave (the last ones repeat piece 35)
+    // ---- weight slab of step s = 3 c + ky: 36 (TN = 3) pieces of 1 KiB, 5 per wave (the last ones repeat piece 35); the
+    // source is a scalar base + lane * 16: no vector arithmetic per piece
     constexpr int WP = SLAB_BYTES / 1024, WPW = (WP + 7) / 8;
     const uint8_t* wbase = Wdc + (int64_t)blockIdx.x * NC * 3 * SLAB_BYTES;
+    const uint32_t wlane = (uint32_t)lane * 16u;
     auto issue_w = [&](int s) {
         const uint8_t* slab = wbase + (int64_t)s * SLAB_BYTES;
         const uint32_t base = lds0 + (uint32_t)(2 * PATCH_BYTES + (s & 1) * SLAB_BYTES);
@@ -1641,7 +1660,7 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
         for (int i = 0; i < WPW; ++i) {
             int q = wave + 8 * i;
             if (q > WP - 1) q = WP - 1;
-            glds16(slab + q * 1024 + lane * 16, base + (uint32_t)q * 1024u);
+            glds16_s(slab + q * 1024, wlane, base + (uint32_t)q * 1024u);
         }
     };
     // ---- this lane's output pixels -> patch pixel index of tap (0, 0)
@@ -1653,6 +1672,23 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
         const int yl = rem / W, x = rem - yl * W;
         pp[i] = (img * PR + yl) * PW + x;
         pcol[i] = x;
+    }
+    // LDS byte offsets of this lane's fragments, fixed for the whole tile: A inside a patch buffer for filter row 0 (a step adds
+    // the buffer and ky * PW * 64, both wave-uniform), B inside a slab (a tap adds a compile-time kx * BN * 64)
+    uint32_t aoff[TM][3][2], boff[TN][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int key = ((pcol[i] + kx) >> KSH) & 3;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) aoff[i][kx][ks] = (uint32_t)((pp[i] + kx) * 64 + (((2 * ks + fh) ^ key) << 4));
+        }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = wn * (TN * 32) + j * 32 + fr;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) boff[j][ks] = (uint32_t)(n * 64 + (((2 * ks + fh) ^ ((n >> 2) & 3)) << 4));
     }
 
     typename Acc<0>::type acc[TM][TN];
@@ -1669,7 +1705,7 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
     unsigned long long d_wait = 0, d_first = 0, d_vm = 0;
 #endif
     issue_w(0);
-    issue_patch(0);
+    issue_patch();
     stage_epilogue_consts<BN, RA>(ec, tid, (int)blockDim.x, m0, n0, M, N, scale, bias, rowadd, rows_per_batch, 1.0f, nullptr);
     for (int s = 0; s < S; ++s) {
         const int c = s / 3, ky = s - 3 * c;
@@ -1688,30 +1724,18 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
         { STAMP(ts1); if (s == 0) d_first = ts1 - t_entry; else { d_wait += ts1 - ts0; d_vm += tsv - ts0; } }
 #endif
         if (s + 1 < S) issue_w(s + 1);
-        if (ky == 0 && c + 1 < NC) issue_patch(c + 1);
-        const uint8_t* Ps = smem + (c & 1) * PATCH_BYTES;
+        if (ky == 0 && c + 1 < NC) issue_patch();
+        const uint8_t* Ps = smem + (uint32_t)__builtin_amdgcn_readfirstlane((c & 1) * PATCH_BYTES + ky * PW * 64);
         const uint8_t* Ws = smem + 2 * PATCH_BYTES + (s & 1) * SLAB_BYTES;
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-            const int toff = ky * PW + kx;
-            int pa[TM], sw[TM];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int P = pp[i] + toff;
-                pa[i] = P * 64;
-                sw[i] = ((pcol[i] + kx) >> KSH) & 3;
-            }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const int lc = 2 * ks + fh;
                 uint4 fa[TM], fb[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const uint4*>(Ps + pa[i] + ((lc ^ sw[i]) << 4));
+                for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const uint4*>(Ps + aoff[i][kx][ks]);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int n = wn * (TN * 32) + j * 32 + fr;
-                    fb[j] = *reinterpret_cast<const uint4*>(Ws + kx * (BN * 64) + n * 64 + ((lc ^ ((n >> 2) & 3)) << 4));
-                }
+                for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const uint4*>(Ws + kx * (BN * 64) + boff[j][ks]);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
