@@ -462,7 +462,7 @@ def main():
                          "algorithmic_bytes_note": "per GEMM call, like `traffic`: int8 activation tensor + integer weights + output in "
                                                    "its stored type + fp32 residual, each element once (a convolution's input counted "
                                                    "once, not 9x); traffic / algorithmic_bytes = re-read factor",
-                         "kernel": "int8 GEMM (edadm_qgemm_i8/_q: k_gemm_nt8, k_gemm_p, k_gemm_nt): %d launches per UNet call of a DDIM step, %.1f GFLOP, %.2f ms summed"
+                         "kernel": "int8 GEMM (edadm_qgemm_i8/_q and edadm_qconv3_i8_direct: k_conv3_direct, k_gemm_nt, k_gemm_p, k_gemm_nt8): %d launches per UNet call of a DDIM step, %.1f GFLOP, %.2f ms summed"
                                    % (len(i8), gemm_flop / 1e9, gemm_ms),
                          "hbm": {"note": "same launches against the HBM roof: PMC bytes per launch x launches / summed time",
                                  "achieved_GBps": (traffic * len(i8) / (gemm_ms * 1e-3) / 1e9) if traffic else None,
