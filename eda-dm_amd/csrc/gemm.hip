@@ -349,8 +349,17 @@ __device__ __forceinline__ void epilogue_direct_body(typename Acc<DT>::type (&ac
                 if constexpr (HAS_RA) v += late ? er.ra1[j] : er.ra0[j];
                 if constexpr (HAS_RES) v += rr[gi][e][j];
                 EDADM_NT_STORE(v, reinterpret_cast<float*>(op + ooff + j * 128));
-                ps[j] += v;
-                pq[j] += v * v;
+                if constexpr (GNREG) {
+                    // finished here, value by value: left free, the compiler pairs values of different rows for packed f32
+                    // adds / multiplies, keeps them alive across the row groups and spills them (k_conv3_direct: 190
+                    // scratch accesses per wave, most of this epilogue's time with a row add or a residual)
+                    ps[j] += v;
+                    pq[j] += v * v;
+                    asm volatile("" : "+v"(ps[j]), "+v"(pq[j]));
+                } else {
+                    ps[j] += v;
+                    pq[j] += v * v;
+                }
             }
         }
         if constexpr (GNREG) {
