@@ -111,6 +111,47 @@ __device__ __forceinline__ void stage_epilogue_consts(float* ec, int tid, int nt
     }
 }
 
+// The same in two halves for kernels that request the constants at entry and park them in registers until the main loop is
+// over (k_gemm_nt, BN <= blockDim: one column per thread): loads the compiler can see are waited for with vmcnt(0), which also
+// waits for every LDS-DMA piece issued before them -- staged in front of the main loop, the constants made the first MFMA wait
+// for all STAGES - 1 prefetched tiles instead of the first one.
+template <int RA>
+struct EpiConsts {
+    float s, b, ra[RA], oq;
+};
+template <int BN, int RA>
+__device__ __forceinline__ void load_epilogue_consts(EpiConsts<RA>& k, int tid, int64_t m0, int64_t n0, int64_t M, int64_t N,
+                                                     const float* __restrict__ scale, const float* __restrict__ bias,
+                                                     const float* __restrict__ rowadd, int64_t rows_per_batch, float alpha,
+                                                     const float* __restrict__ oqp) {
+    k.oq = (tid < 3 && oqp) ? oqp[tid] : 0.f;
+    k.s = k.b = 0.f;
+#pragma unroll
+    for (int j = 0; j < RA; ++j) k.ra[j] = 0.f;
+    if (tid < BN) {
+        const int64_t col = n0 + tid;
+        const bool in = col < N;
+        k.s = in ? (scale ? scale[col] : alpha) : 0.f;
+        k.b = (in && bias) ? bias[col] : 0.f;
+        const int64_t b0 = m0 / rows_per_batch;
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            const int64_t b = b0 + j;
+            k.ra[j] = (in && rowadd && b * rows_per_batch < M) ? rowadd[b * N + col] : 0.f;
+        }
+    }
+}
+template <int BN, int RA>
+__device__ __forceinline__ void store_epilogue_consts(float* ec, const EpiConsts<RA>& k, int tid) {
+    if (tid < 3) ec[(2 + RA) * BN + tid] = k.oq;
+    if (tid < BN) {
+        ec[tid] = k.s;
+        ec[BN + tid] = k.b;
+#pragma unroll
+        for (int j = 0; j < RA; ++j) ec[(2 + j) * BN + tid] = k.ra[j];
+    }
+}
+
 template <int DT, int TM, int TN, int BN, int RA, int HG>
 __device__ __forceinline__ void gemm_epilogue(typename Acc<DT>::type (&acc)[TM][TN], uint8_t* smem, const float* ec,
                                               int wave, int lane, int64_t m0, int64_t row0, int64_t col0, int ecol0,
@@ -601,6 +642,10 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
     const int wm = wave >> 1, wn = wave & 1;
+    STAMP(t_entry);
+#ifdef EDADM_STAMPS
+    unsigned long long d_wait = 0;
+#endif
     const int64_t m0 = (int64_t)blockIdx.y * BM + g.r0, n0 = (int64_t)blockIdx.x * BN;   // g.r0: first row of a tail launch
     {   // batch index z = outer * inner + head: (batch, head) views of [B][N][heads*d] tensors
         const int64_t zo = blockIdx.z / inner, zi = blockIdx.z % inner;
@@ -719,14 +764,20 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
 
     const int64_t nk = (Kb + 63) / 64;
     const int fr = lane & 31, fh = lane >> 5;
+    STAMP(t_addr);
+    // the epilogue constants are requested ahead of the first tiles (older in the in-order vmcnt queue than every LDS-DMA
+    // piece, so the counted waits of the main loop never see them) and go to LDS after the main loop
+    static_assert(BN <= 256, "one column per thread");
+    EpiConsts<RA> ek;
+    load_epilogue_consts<BN, RA>(ek, tid, m0, n0, M, N, scale, bias, rowadd, rows_per_batch, alpha, oqp);
 #pragma unroll
     for (int p = 0; p < STAGES - 1; ++p)
         if (p < nk) issue_tile(p, (int64_t)p * 64);
-    // epilogue constants go to LDS behind the first tiles' DMA, so their load latency hides under it
-    stage_epilogue_consts<BN, RA>(ec, tid, (int)blockDim.x, m0, n0, M, N, scale, bias, rowadd, rows_per_batch, alpha, oqp);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // keep the pipeline's vmcnt bookkeeping to LDS-DMA only
+    STAMP(t_issued);
+    STAMP(t_setup);
     auto main_loop = [&](auto swp) {
     for (int64_t kt = 0; kt < nk; ++kt) {
+        STAMP(ts0);
         // tile kt has landed once at most the newer tile's LPT loads are still in flight
         // tiles kt+1 .. kt+STAGES-2 may still be in flight
         const int64_t ahead = nk - 1 - kt < STAGES - 2 ? nk - 1 - kt : STAGES - 2;
@@ -736,6 +787,9 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+#ifdef EDADM_STAMPS
+        { STAMP(ts1); d_wait += ts1 - ts0; }
+#endif
         if (kt + STAGES - 1 < nk) issue_tile((int)((kt + STAGES - 1) % STAGES), (kt + STAGES - 1) * 64);
         const uint8_t* As = smem + (int)(kt % STAGES) * TILE;
         const uint8_t* Bs = As + BM * 64;
@@ -807,10 +861,31 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
     };
     if (qdirect) main_loop(std::true_type{});
     else main_loop(std::false_type{});
+    store_epilogue_consts<BN, RA>(ec, ek, tid);
+    __syncthreads();
+    STAMP(t_main);
+#ifdef EDADM_STAMPS
+    // slots: 0 setup (entry -> first tiles requested, epilogue constants staged), 1 vmcnt + barrier waits of the K-steps, 2 the
+    // rest of the main loop, 3 epilogue incl. draining its stores, 4 samples, 5 total (wave 0 of every eighth workgroup)
+    auto stamp_out = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(t_end);
+        if (wave == 0 && ((blockIdx.x + blockIdx.y) & 7) == 0) {
+            STAMP_ADD(0, t_setup - t_entry); STAMP_ADD(1, d_wait); STAMP_ADD(2, t_main - t_setup - d_wait); STAMP_ADD(3, t_end - t_main);
+            STAMP_ADD(4, 1); STAMP_ADD(5, t_end - t_entry);
+            // 6: entry -> addresses ready (low 20 bits x samples fit), 7: addresses ready -> first tiles issued; the rest of slot 0
+            // is staging the epilogue constants + the wait for all of it
+            STAMP_ADD(6, t_addr - t_entry); STAMP_ADD(7, t_issued - t_addr);
+        }
+    };
+#else
+    auto stamp_out = [&]() {};
+#endif
 
     if (qdirect) {
         gemm_epilogue_qdirect<DT, TM, TN, BN, RA>(acc, ec, lane, m0 + wm * (TM * 32), n0 + wn * (TN * 32), wn * (TN * 32), out, ldo,
                                                   out_mode, residual, ldr, rows_per_batch, N);
+        stamp_out();
         return;
     }
     if (direct) {
@@ -818,10 +893,12 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
         load_epi_regs<TN, BN>(er, ec, lane, m0, m0 + wm * (TM * 32), wn * (TN * 32), rows_per_batch);
         gemm_epilogue_direct<DT, TM, TN>(acc, er, lane, m0 + wm * (TM * 32), n0 + wn * (TN * 32), rowadd != nullptr, residual,
                                          ldr, out, ldo, gacc_all + (wm * BN + wn * (TN * 32)) * 2, gn_ws, N);
+        stamp_out();
         return;
     }
     gemm_epilogue<DT, TM, TN, BN, RA, (TN % 2 == 0 || TN == 3) ? 4 : 2>(acc, smem, ec, wave, lane, m0, m0 + wm * (TM * 32), n0 + wn * (TN * 32),
                                       wn * (TN * 32), M, N, rows_per_batch, rowadd != nullptr, residual, ldr, out, ldo, out_mode);
+    stamp_out();
 }
 
 // ---- 8-wave variant for the large-M layers: 256 x (64*TN) tile, 128-byte K rows (full cache lines per
