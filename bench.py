@@ -479,12 +479,12 @@ def main():
                 line["calibration"]["reconstruction"] = time_calibration(qnn, dev)
                 line["calibration"]["h1_contraction"] = time_h1_contraction(dev)
                 try:        # the MEASURED full run (python bench.py --full-calib, committed) next to this run's extrapolation
-                    with open(os.path.join(ROOT, "profiles", "r02r_full_calibration.json")) as fh:
+                    with open(os.path.join(ROOT, "profiles", "r02z_full_calibration.json")) as fh:
                         full = json.load(fh)["calibration"]
                     ext = line["calibration"]["reconstruction"]["extrapolated_full_s"]["total"]
                     line["calibration"]["measured_full_s"] = {
                         "wall_s": full["wall_s"], "caching_s": full["caching_s"], "loop_s": full["loop_s"],
-                        "source": "profiles/r02r_full_calibration.json: 1024 samples x 1000 iterations x 80 units on one MI355X, "
+                        "source": "profiles/r02z_full_calibration.json: 1024 samples x 1000 iterations x 80 units on one MI355X, "
                                   "iterations replayed as HIP graphs (the first measured run of the round, "
                                   "profiles/r02a_full_calibration.json, took 529.6 s)",
                         "this_run_extrapolation_s": ext, "extrapolation_over_measured": ext / full["wall_s"]}
