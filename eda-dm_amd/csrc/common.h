@@ -153,16 +153,17 @@ __device__ __forceinline__ void geglu_codes_n(const float (&val)[NV], const floa
 #pragma unroll
     for (int e = 0; e < NV; ++e) {
         const float g = gate[e];
-        const float x = fabsf(g) * 0.70710678118654752440f;
-        const float u = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+        // x = |g| / sqrt 2 never materialises: 1 + p x = fma(|g|, p / sqrt 2, 1), and exp(-x^2) = exp2(-(|g| sqrt(log2(e) / 2))^2)
+        const float u = __builtin_amdgcn_rcpf(fmaf(fabsf(g), 0.3275911f * 0.70710678118654752440f, 1.0f));
+        const float xe = fabsf(g) * 0.84932180028801904272f;
         float pl = fmaf(1.061405429f, u, -1.453152027f);
         pl = fmaf(pl, u, 1.421413741f);
         pl = fmaf(pl, u, -0.284496736f);
         pl = fmaf(pl, u, 0.254829592f);
-        const float pe = pl * u * __builtin_amdgcn_exp2f(x * x * -1.44269504088896340736f);
+        const float pe = pl * u * __builtin_amdgcn_exp2f(-(xe * xe));
         const float E = g >= 0.f ? 2.0f - pe : pe;          // 1 + erf(g / sqrt 2)
         const float vg = val[e] * g;
-        const float t = fmaf(vg * (0.5f * E), inv_d, z);
+        const float t = fmaf(vg * E, 0.5f * inv_d, z);      // 0.5 inv_d: exact scaling, hoisted out of the loop by the compiler
         r[e] = rintf(t);
         worst = fmaxf(worst, fabsf(t - r[e]) + fmaf(fabsf(vg) * inv_d, 6e-7f, 2e-4f));
     }
