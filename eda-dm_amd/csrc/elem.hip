@@ -109,28 +109,45 @@ __global__ void __launch_bounds__(256) k_fq_bwd(const float* __restrict__ gy, co
                                                 float* __restrict__ gx, float* __restrict__ part, int64_t n,
                                                 const float* __restrict__ delta, const float* __restrict__ zp,
                                                 float qmax, const float* __restrict__ u, float prob,
-                                                uint64_t seed_arg) {
+                                                uint64_t seed_arg, int vec) {
     const uint64_t seed = epoch_seed(seed_arg);
     __shared__ float sm[4];
     const float d = delta[0], z = zp[0];
     const bool mix = prob < 1.0f;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     float acc = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const float g = gy[i], v = x[i];
+    // one element: the autograd chain of (clamp(round(x / d) + z, 0, qmax) - z) * d, operation by operation
+    auto one = [&](float g, float v, int64_t i, float& gxi) -> float {
         const float xs = v / d;
         const float xi = rintf(xs) + z;
         const float inr = (xi >= 0.f && xi <= qmax) ? 1.f : 0.f;
         const float c = fminf(fmaxf(xi, 0.f), qmax);
         const float gq = g * d * inr;
         float gd = g * (c - z) - gq * (xs / d);
-        float gxi = gq / d;
+        gxi = gq / d;
         if (mix) {
             const float r = u ? u[i] : rng_uniform(seed, (uint64_t)i);
             if (!(r < prob)) { gxi = g; gd = 0.f; }
         }
-        if (gx) gx[i] = gxi;
-        acc += gd;
+        return gd;
+    };
+    if (vec) {                                              // 16-byte accesses (n % 4 == 0, aligned operands)
+        const int64_t n4 = n >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+            const float4 g4 = reinterpret_cast<const float4*>(gy)[i], v4 = reinterpret_cast<const float4*>(x)[i];
+            float4 o;
+            acc += one(g4.x, v4.x, 4 * i, o.x);
+            acc += one(g4.y, v4.y, 4 * i + 1, o.y);
+            acc += one(g4.z, v4.z, 4 * i + 2, o.z);
+            acc += one(g4.w, v4.w, 4 * i + 3, o.w);
+            if (gx) reinterpret_cast<float4*>(gx)[i] = o;
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+            float gxi;
+            acc += one(gy[i], x[i], i, gxi);
+            if (gx) gx[i] = gxi;
+        }
     }
     const float s = block_sum_256(acc, sm);
     if (threadIdx.x == 0) part[blockIdx.x] = s;
@@ -140,10 +157,11 @@ extern "C" int edadm_fake_quant_bwd(const float* gy, const float* x, float* gx, 
                                     const float* delta, const float* zp, float qmax, const float* u, float prob,
                                     uint64_t seed, float* ws, void* stream) {
     if (!gy || !x || !gdelta || !delta || !zp || !ws || n <= 0) return EDADM_EINVAL;
-    int g = edadm_grid(n, 256);
+    const int vec = (n & 3) == 0 && !(((uintptr_t)gy | (uintptr_t)x | (uintptr_t)gx | (uintptr_t)u) & 15);
+    int g = edadm_grid(vec ? n >> 2 : n, 256);
     if (g > EDADM_RED_BLOCKS) g = EDADM_RED_BLOCKS;
     hipLaunchKernelGGL(k_fq_bwd, dim3(g), dim3(256), 0, (hipStream_t)stream, gy, x, gx, ws, n, delta, zp, qmax, u,
-                       prob, seed);
+                       prob, seed, vec);
     hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, (hipStream_t)stream, ws, g, 1, gdelta, 1.0f);
     return edadm_launch_status();
 }
@@ -397,6 +415,14 @@ __global__ void __launch_bounds__(256) k_lp_bwd(const float* __restrict__ p, con
                                                 float* __restrict__ gp) {
     const float k = 2.0f * inv_denom * gscale[0];
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if ((n & 3) == 0 && !(((uintptr_t)p | (uintptr_t)t | (uintptr_t)gp) & 15)) {
+        const int64_t n4 = n >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+            const float4 a = reinterpret_cast<const float4*>(p)[i], b = reinterpret_cast<const float4*>(t)[i];
+            reinterpret_cast<float4*>(gp)[i] = make_float4(k * (a.x - b.x), k * (a.y - b.y), k * (a.z - b.z), k * (a.w - b.w));
+        }
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) gp[i] = k * (p[i] - t[i]);
 }
 extern "C" int edadm_lp_loss_fwd(const float* pred, const float* tgt, int64_t n, float inv_denom, float* loss,
