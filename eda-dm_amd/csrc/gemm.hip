@@ -1664,6 +1664,7 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
                const float* __restrict__ rowadd, int64_t rows_per_batch, const float* __restrict__ residual, int64_t ldr,
                float* __restrict__ out, int64_t ldo, float* __restrict__ gn_ws) {
     constexpr int TM = 2, BM = 256, BN = 64 * TN;
+    STAMP(t_kernel);
     constexpr int PATCH_BYTES = 32 * 1024;                  // 8 waves x 4 pieces x 1 KiB >= 16 * ceil(NP / 16) * 64
     constexpr int SLAB_BYTES = 3 * BN * 64;                 // one filter row of one 64-channel chunk
     constexpr int RA = BM / 16 + 1;
@@ -1679,13 +1680,19 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
     const int64_t tile = blockIdx.y;
     const int64_t m0 = tile * BM, n0 = (int64_t)blockIdx.x * BN;
     const int HW = H * W;
-    // tile geometry: TR image rows of IMGS images starting at (b0, y0)
-    const int IMGS = HW >= BM ? 1 : BM / HW;
-    const int TR = HW >= BM ? BM / W : H;
-    const int tiles_per_img = HW >= BM ? HW / BM : 1;
-    const int b0 = (int)(HW >= BM ? tile / tiles_per_img : tile * IMGS);
-    const int y0 = HW >= BM ? (int)(tile % tiles_per_img) * TR : 0;
+    // tile geometry: TR image rows of IMGS images starting at (b0, y0).  W is 8 .. 64 and H * W divides or is a multiple of
+    // 256 (edadm_conv3_direct_ok): both are powers of two, every division of the set-up is a shift, and the two by the patch
+    // width / patch size (W + 2 is no power of two) go through an exact float reciprocal (indices < 512) -- the set-up was
+    // 3.0 k cycles per tile, most of it integer division sequences
+    const int lw = 31 - __builtin_clz((unsigned)W), lhw = 31 - __builtin_clz((unsigned)HW);
+    const int IMGS = HW >= BM ? 1 : BM >> lhw;
+    const int TR = HW >= BM ? BM >> lw : H;
+    const int ltpi = HW >= BM ? lhw - 8 : 0;                // log2(tiles per image)
+    const int b0 = (int)(HW >= BM ? tile >> ltpi : tile * IMGS);
+    const int y0 = HW >= BM ? (int)(tile & ((1 << ltpi) - 1)) * TR : 0;
     const int PR = TR + 2, PW = W + 2;
+    const float rPW = 1.0f / (float)PW, rPP = 1.0f / (float)(PR * PW);
+    auto div_small = [](int a, float r) { return (int)(((float)a + 0.5f) * r); };   // a / b for 0 <= a < 2^16, r = 1 / b
     const int NP = IMGS * PR * PW;
     const int pieces = (NP + 15) >> 4;
     const int PPW = (pieces + 7) >> 3;                      // 3 or 4 (checked by the launcher)
@@ -1708,8 +1715,8 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
         pptr[i] = pad_row + (lane & 3) * 16;
         pinc[i] = 0;
         if (P < NP) {
-            const int img = P / (PR * PW), rem = P - img * (PR * PW);
-            const int py = rem / PW, px = rem - py * PW;
+            const int img = div_small(P, rPP), rem = P - img * (PR * PW);
+            const int py = div_small(rem, rPW), px = rem - py * PW;
             const int sc = (lane & 3) ^ ((px >> KSH) & 3);
             const int y = y0 + py - 1, x = px - 1;
             // ups: the convolution runs over the nearest-2x upsampled image (H x W are ITS dimensions); pixel (y, x) of
@@ -1754,8 +1761,9 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int p = wm * 64 + i * 32 + fr;                // pixel of the tile, NHWC order
-        const int img = p / (TR * W), rem = p - img * (TR * W);
-        const int yl = rem / W, x = rem - yl * W;
+        const int ltw = HW >= BM ? 8 : lhw;                 // TR * W = 256 or H * W
+        const int img = p >> ltw, rem = p & ((1 << ltw) - 1);
+        const int yl = rem >> lw, x = rem & (W - 1);
         pp[i] = (img * PR + yl) * PW + x;
         pcol[i] = x;
     }
@@ -1787,6 +1795,9 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
 
     const int S = 3 * NC;
     STAMP(t_entry);
+#ifdef EDADM_STAMPS
+    if (wave == EDADM_STAMP_WAVE && ((blockIdx.x + blockIdx.y) & 7) == 0) STAMP_ADD(7, t_entry - t_kernel);
+#endif
 #ifdef EDADM_STAMPS
     unsigned long long d_wait = 0, d_first = 0, d_vm = 0;
 #endif

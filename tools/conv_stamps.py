@@ -29,8 +29,8 @@ def case(B, H, Cin, N, residual):
     M, K = B * H * W, 9 * Cin
     us = e0.elapsed_time(e1) * 1e3
     mfma = (Cin // 64) * 3 * 36 * 32 * 2            # cycles per wave at the MFMA's rate (two waves share a SIMD)
-    print("M=%6d N=%4d K=%5d res=%d | %6.1f us %6.0f TOP/s | per wave ticks: prologue=%5.0f waits=%6.0f (vmcnt %6.0f) compute=%6.0f epilogue=%6.0f "
-          "total=%6.0f | MFMA-rate cycles %d" % (M, N, K, residual, us, 2.0 * M * N * K / us / 1e6, buf[0] / n, buf[1] / n, buf[6] / n,
+    print("M=%6d N=%4d K=%5d res=%d | %6.1f us %6.0f TOP/s | per wave ticks: setup=%5.0f prologue=%5.0f waits=%6.0f (vmcnt %6.0f) compute=%6.0f epilogue=%6.0f "
+          "total=%6.0f | MFMA-rate cycles %d" % (M, N, K, residual, us, 2.0 * M * N * K / us / 1e6, buf[7] / n, buf[0] / n, buf[1] / n, buf[6] / n,
                                                   buf[2] / n, buf[3] / n, buf[5] / n, mfma))
 
 
