@@ -1700,6 +1700,23 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
     const int KSH = W >= 32 ? 2 : 1;
     const uint8_t* pad_row = g_pad_rows + (int)(uint8_t)padval * 64;
 
+    // ---- weight slab of step s = 3 c + ky: 36 (TN = 3) pieces of 1 KiB, 5 per wave (the last ones repeat piece 35); the
+    // source is a scalar base + lane * 16: no vector arithmetic per piece
+    constexpr int WP = SLAB_BYTES / 1024, WPW = (WP + 7) / 8;
+    const uint8_t* wbase = Wdc + (int64_t)blockIdx.x * NC * 3 * SLAB_BYTES;
+    const uint32_t wlane = (uint32_t)lane * 16u;
+    auto issue_w = [&](int s) {
+        const uint8_t* slab = wbase + (int64_t)s * SLAB_BYTES;
+        const uint32_t base = lds0 + (uint32_t)(2 * PATCH_BYTES + (s & 1) * SLAB_BYTES);
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) {
+            int q = wave + 8 * i;
+            if (q > WP - 1) q = WP - 1;
+            glds16_s(slab + q * 1024, wlane, base + (uint32_t)q * 1024u);
+        }
+    };
+    issue_w(0);                                             // first: its latency covers the address arithmetic below
+
     // ---- this lane's patch pieces: piece q covers patch pixels 16 q .. 16 q + 15, lane -> pixel 16 q + lane / 4,
     // physical chunk lane % 4 (= logical chunk (lane % 4) ^ ((P >> 2) & 3) of the source pixel)
     // source pointer of each piece for the chunk to be requested next (padding lanes point into g_pad_rows and do not advance)
@@ -1741,21 +1758,7 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
             }
         }
     };
-    // ---- weight slab of step s = 3 c + ky: 36 (TN = 3) pieces of 1 KiB, 5 per wave (the last ones repeat piece 35); the
-    // source is a scalar base + lane * 16: no vector arithmetic per piece
-    constexpr int WP = SLAB_BYTES / 1024, WPW = (WP + 7) / 8;
-    const uint8_t* wbase = Wdc + (int64_t)blockIdx.x * NC * 3 * SLAB_BYTES;
-    const uint32_t wlane = (uint32_t)lane * 16u;
-    auto issue_w = [&](int s) {
-        const uint8_t* slab = wbase + (int64_t)s * SLAB_BYTES;
-        const uint32_t base = lds0 + (uint32_t)(2 * PATCH_BYTES + (s & 1) * SLAB_BYTES);
-#pragma unroll
-        for (int i = 0; i < WPW; ++i) {
-            int q = wave + 8 * i;
-            if (q > WP - 1) q = WP - 1;
-            glds16_s(slab + q * 1024, wlane, base + (uint32_t)q * 1024u);
-        }
-    };
+    issue_patch();                                          // chunk 0, behind the first weight slab (the counted waits rely on that order)
     // ---- this lane's output pixels -> patch pixel index of tap (0, 0)
     int pp[TM], pcol[TM];
 #pragma unroll
@@ -1801,8 +1804,6 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
 #ifdef EDADM_STAMPS
     unsigned long long d_wait = 0, d_first = 0, d_vm = 0;
 #endif
-    issue_w(0);
-    issue_patch();
     stage_epilogue_consts<BN, RA>(ec, tid, (int)blockDim.x, m0, n0, M, N, scale, bias, rowadd, rows_per_batch, 1.0f, nullptr);
     for (int s = 0; s < S; ++s) {
         const int c = s / 3, ky = s - 3 * c;
