@@ -86,6 +86,13 @@ __device__ __forceinline__ void mma_step(const uint4& fa, const uint4& fb, typen
     }
 }
 
+// a / b for non-negative operands: the 32-bit sequence (about 25 instructions) when both fit, which is always outside
+// multi-billion-row tensors; the 64-bit one is ~150 instructions, and several of these sit on every tile's critical path
+__device__ __forceinline__ int64_t div_nn(int64_t a, int64_t b) {
+    if ((uint64_t)(a | b) < (1ull << 32)) return (int64_t)((uint32_t)a / (uint32_t)b);
+    return a / b;
+}
+
 // Per-column epilogue constants live in LDS (scale, bias, and the time-embedding rows of the few batch
 // entries a tile spans), so the store phase issues no global load except the residual, and all residual
 // loads of a slab are issued before its first store: on gfx950 vmcnt counts stores too and retires in
@@ -102,7 +109,7 @@ __device__ __forceinline__ void stage_epilogue_consts(float* ec, int tid, int nt
         const bool in = col < N;
         ec[c] = in ? (scale ? scale[col] : alpha) : 0.f;
         ec[BN + c] = (in && bias) ? bias[col] : 0.f;
-        const int64_t b0 = m0 / rows_per_batch;
+        const int64_t b0 = div_nn(m0, rows_per_batch);
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
             const int64_t b = b0 + j;
@@ -133,7 +140,7 @@ __device__ __forceinline__ void load_epilogue_consts(EpiConsts<RA>& k, int tid, 
         const bool in = col < N;
         k.s = in ? (scale ? scale[col] : alpha) : 0.f;
         k.b = (in && bias) ? bias[col] : 0.f;
-        const int64_t b0 = m0 / rows_per_batch;
+        const int64_t b0 = div_nn(m0, rows_per_batch);
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
             const int64_t b = b0 + j;
@@ -170,7 +177,7 @@ __device__ __forceinline__ void gemm_epilogue(typename Acc<DT>::type (&acc)[TM][
         float* ep = reinterpret_cast<float*>(smem) + wave * (32 * EST);
         constexpr int C4 = TN * 8;
         constexpr int NIT = C4 / 2;                        // 32*C4 float4 per slab / 64 lanes
-        const int64_t b0 = m0 / rows_per_batch;
+        const int64_t b0 = div_nn(m0, rows_per_batch);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -247,7 +254,7 @@ __device__ __forceinline__ void gemm_epilogue(typename Acc<DT>::type (&acc)[TM][
         }
         return;
     }
-    const int64_t b0 = m0 / rows_per_batch;
+    const int64_t b0 = div_nn(m0, rows_per_batch);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int64_t col = col0 + j * 32 + fr;
@@ -306,8 +313,8 @@ template <int TN, int BN>
 __device__ __forceinline__ void load_epi_regs(EpiRegs<TN>& er, const float* ec, int lane, int64_t m0, int64_t row0, int ecol0,
                                               int64_t rows_per_batch) {
     const int fr = lane & 31;
-    const int64_t bw = row0 / rows_per_batch;
-    const int bj = (int)(bw - m0 / rows_per_batch);        // staged row-add entry of the wave's first row
+    const int64_t bw = div_nn(row0, rows_per_batch);
+    const int bj = (int)(bw - div_nn(m0, rows_per_batch));  // staged row-add entry of the wave's first row
     er.boundary = (bw + 1) * rows_per_batch;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -648,7 +655,7 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
 #endif
     const int64_t m0 = (int64_t)blockIdx.y * BM + g.r0, n0 = (int64_t)blockIdx.x * BN;   // g.r0: first row of a tail launch
     {   // batch index z = outer * inner + head: (batch, head) views of [B][N][heads*d] tensors
-        const int64_t zo = blockIdx.z / inner, zi = blockIdx.z % inner;
+        const int64_t zo = gridDim.z == 1 ? 0 : (int64_t)(blockIdx.z / (unsigned)inner), zi = gridDim.z == 1 ? 0 : (int64_t)(blockIdx.z % (unsigned)inner);
         A += zo * strideA_b + zi * strideA_i;
         Bm += zo * strideB_b + zi * strideB_i;
         const int64_t coff = zo * strideC + zi * strideC_i;      // in output elements
@@ -935,7 +942,7 @@ k_gemm_nt8(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, cons
     const int wm = wave >> 1, wn = wave & 1;
     const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
     {
-        const int64_t zo = blockIdx.z / inner, zi = blockIdx.z % inner;
+        const int64_t zo = gridDim.z == 1 ? 0 : (int64_t)(blockIdx.z / (unsigned)inner), zi = gridDim.z == 1 ? 0 : (int64_t)(blockIdx.z % (unsigned)inner);
         A += zo * strideA_b + zi * strideA_i;
         Bm += zo * strideB_b + zi * strideB_i;
         const int64_t coff = zo * strideC + zi * strideC_i;      // in output elements
@@ -1262,7 +1269,7 @@ k_gemm_p(const uint8_t* __restrict__ A, int64_t lda_b, const uint8_t* __restrict
             tap_s = 0; ci_s = 0;
             if (g.mode != 0) { tap_c = (sc * 16) / g.Cin; ci_c = (sc * 16) % g.Cin; }
             // epilogue constants of this tile: requested here, written to LDS with the tile's first K-step
-            const int64_t b0 = m0 / rows_per_batch;
+            const int64_t b0 = div_nn(m0, rows_per_batch);
 #pragma unroll
             for (int e = 0; e < NEC; ++e) {
                 const int idx = ltid + 256 * e, row = idx / BN, c = idx - row * BN;
