@@ -1894,6 +1894,7 @@ extern "C" int edadm_conv3_pack_w(const int8_t* w, int8_t* out, int64_t N, int64
 extern "C" int edadm_conv3_direct_ok(int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t N) {
     if (B <= 0 || H <= 0 || W <= 0 || Cin % 64 || N % 192 || Cin < 64) return 0;
     if (W != 8 && W != 16 && W != 32 && W != 64) return 0;
+    if (H & (H - 1)) return 0;                              // the kernel's tile arithmetic is shifts: H * W a power of two
     const int64_t HW = H * W;
     if (HW >= 256 ? (HW % 256 != 0) : (256 % HW != 0 || B % (256 / HW) != 0)) return 0;
     if (B * HW * Cin >= (1ll << 31)) return 0;
