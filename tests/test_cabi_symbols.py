@@ -29,3 +29,15 @@ def test_bad_arguments_return_errno_not_crash():
     l = lib.load()
     assert l.edadm_fake_quant_fwd(None, None, None, 10, None, None, 1, 1, 255.0, None, 1.0, 0, None) == -22
     assert l.edadm_qgemm_i8(None, 0, None, 0, 0, 0, 0, None, None, None, None, 0, None, 0, None, 0, None) == -22
+
+
+def test_direct_conv_shape_gate():
+    """edadm_conv3_direct_ok (host only): the shapes the direct 3x3 kernel takes -- 64-channel chunks, 192-column blocks,
+    widths 8 .. 64, power-of-two heights (its tile arithmetic is shifts), whole tiles of 256 pixels."""
+    from edadm import lib
+    ok = lib.load().edadm_conv3_direct_ok
+    for B, H, W, Cin, N, want in ((100, 64, 64, 192, 192, 1), (100, 8, 8, 960, 960, 1), (4, 16, 16, 576, 192, 1),
+                                  (3, 8, 8, 960, 960, 0),       # 3 images of 64 pixels do not fill 256-pixel tiles
+                                  (2, 96, 64, 64, 192, 0),      # height no power of two
+                                  (2, 64, 48, 64, 192, 0), (2, 64, 64, 96, 192, 0), (2, 64, 64, 64, 128, 0)):
+        assert ok(B, H, W, Cin, N) == want, (B, H, W, Cin, N)
