@@ -903,26 +903,30 @@ __global__ void __launch_bounds__(256) k_transpose_split_f16(const float* __rest
         if (order == 2) {
             // lane -> (output row j of 8, 16-row group g of 8): 16 values down one tile column become one
             // [hi x16 | lo x16] group = 64 contiguous bytes = four 16-byte stores; a wave writes 8 rows x 512 bytes
-            const int j = lane >> 3, gq = lane & 7;
-            const int64_t r = r0 + 16 * gq;
-            if (r < R) {
-                const int64_t sl = (int64_t)((uint32_t)r / (uint32_t)L), rl = r - sl * L;
+            // An output row's 512 bytes of this tile are 32 pieces of 16 bytes (group g = piece / 4: hi[0..7], hi[8..15],
+            // lo[0..7], lo[8..15]).  Store k of a lane writes piece 8 k + (lane & 7): the eight lanes of a row cover 128
+            // CONTIGUOUS bytes per instruction (a lane that owned a whole group wrote its four pieces 64 bytes apart from
+            // its neighbours': 64 partial segments per instruction).  A lane only ever produces hi or lo pieces.
+            const int j = lane >> 3, pc = lane & 7, sidx = pc & 3;
 #pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    const int cc = w * 16 + p * 8 + j;
-                    if (c0 + cc >= C) continue;
-                    _Float16 h[16], l[16];
+            for (int p = 0; p < 2; ++p) {
+                const int cc = w * 16 + p * 8 + j;
+                if (c0 + cc >= C) continue;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const float a = tile[16 * gq + i][cc] * s;
-                        h[i] = (_Float16)a;
-                        l[i] = (_Float16)(a - (float)h[i]);
+                for (int k = 0; k < 4; ++k) {
+                    const int g16 = 2 * k + (pc >> 2);
+                    const int64_t r = r0 + 16 * g16;
+                    if (r >= R) continue;
+                    const int64_t sl = (int64_t)((uint32_t)r / (uint32_t)L), rl = r - sl * L;
+                    _Float16 v8[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float a = tile[16 * g16 + 8 * (sidx & 1) + i][cc] * s;
+                        const _Float16 h = (_Float16)a;
+                        v8[i] = sidx < 2 ? h : (_Float16)(a - (float)h);
                     }
-                    uint4* o = reinterpret_cast<uint4*>(out + (c0 + cc) * ldo + sl * 2 * L + (rl >> 4) * 32);
-                    o[0] = reinterpret_cast<const uint4*>(h)[0];
-                    o[1] = reinterpret_cast<const uint4*>(h)[1];
-                    o[2] = reinterpret_cast<const uint4*>(l)[0];
-                    o[3] = reinterpret_cast<const uint4*>(l)[1];
+                    uint4* o = reinterpret_cast<uint4*>(out + (c0 + cc) * ldo + sl * 2 * L + (rl >> 4) * 32) + sidx;
+                    *o = *reinterpret_cast<const uint4*>(v8);
                 }
             }
             continue;
