@@ -133,15 +133,24 @@ __global__ void __launch_bounds__(256) k_fq_bwd(const float* __restrict__ gy, co
     };
     if (vec) {                                              // 16-byte accesses (n % 4 == 0, aligned operands)
         const int64_t n4 = n >> 2;
-        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-            const float4 g4 = reinterpret_cast<const float4*>(gy)[i], v4 = reinterpret_cast<const float4*>(x)[i];
+        auto quad = [&](const float4 g4, const float4 v4, int64_t i) {
             float4 o;
             acc += one(g4.x, v4.x, 4 * i, o.x);
             acc += one(g4.y, v4.y, 4 * i + 1, o.y);
             acc += one(g4.z, v4.z, 4 * i + 2, o.z);
             acc += one(g4.w, v4.w, 4 * i + 3, o.w);
             if (gx) reinterpret_cast<float4*>(gx)[i] = o;
+        };
+        // two quads per iteration: four 16-byte loads in flight per lane (the grid is capped at 1024 blocks for the partial
+        // sums); the order in which a thread adds up its elements is unchanged
+        int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        for (; i + stride < n4; i += 2 * stride) {
+            const float4 ga = reinterpret_cast<const float4*>(gy)[i], va = reinterpret_cast<const float4*>(x)[i];
+            const float4 gb = reinterpret_cast<const float4*>(gy)[i + stride], vb = reinterpret_cast<const float4*>(x)[i + stride];
+            quad(ga, va, i);
+            quad(gb, vb, i + stride);
         }
+        if (i < n4) quad(reinterpret_cast<const float4*>(gy)[i], reinterpret_cast<const float4*>(x)[i], i);
     } else {
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
             float gxi;
@@ -658,10 +667,16 @@ __global__ void __launch_bounds__(256) k_absmax_part(const float* __restrict__ x
     __shared__ float sm[4];
     float m = 0.f;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        const float4 v = reinterpret_cast<const float4*>(x)[i];
-        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    auto amax4 = [](const float4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); };
+    // four independent 16-byte loads per lane and iteration: with one, the 1024 blocks keep 16 KB per CU in flight and the
+    // scan runs at the memory latency's pace (2.8 TB/s); a maximum does not care about the order
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const float4 v0 = reinterpret_cast<const float4*>(x)[i], v1 = reinterpret_cast<const float4*>(x)[i + stride],
+                     v2 = reinterpret_cast<const float4*>(x)[i + 2 * stride], v3 = reinterpret_cast<const float4*>(x)[i + 3 * stride];
+        m = fmaxf(m, fmaxf(fmaxf(amax4(v0), amax4(v1)), fmaxf(amax4(v2), amax4(v3))));
     }
+    for (; i < n4; i += stride) m = fmaxf(m, amax4(reinterpret_cast<const float4*>(x)[i]));
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
     __syncthreads();
