@@ -344,9 +344,15 @@ __device__ __forceinline__ void epilogue_direct_body(typename Acc<DT>::type (&ac
     // register limit), the LDS pipe is idle during this epilogue.
     // GNREG (kernels with registers to spare, k_conv3_direct): the per-column sums of the wave's TM x 32 rows stay in
     // 2 TN registers across the store loop, the two lanes that share a column add up at the end: no LDS, no atomics
-    float gs[TN], gq[TN];
+    // The GNREG partials are per 64-row slab whatever the tile height, summed in ONE fixed order -- each 32-row half over its
+    // four row groups, its two lane halves, then half 0 + half 1 -- so that the statistics do not depend on whether a wave
+    // owns the whole slab (TM = 2) or two waves share it (TM = 1, the odd one hands its half over through `gacc`, 2 x 32 TN
+    // floats of LDS per wave pair): a layer evaluated at another batch size may get the other tile and must give the same bits.
+    float gs[TM][TN], gq[TM][TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) gs[j] = gq[j] = 0.f;
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) gs[i][j] = gq[i][j] = 0.f;
     if (!GNREG && gn_ws && lane < 32) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) *reinterpret_cast<float2*>(gacc + (j * 32 + fr) * 2) = make_float2(0.f, 0.f);
@@ -412,7 +418,7 @@ __device__ __forceinline__ void epilogue_direct_body(typename Acc<DT>::type (&ac
         }
         if constexpr (GNREG) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) { gs[j] += ps[j]; gq[j] += pq[j]; }
+            for (int j = 0; j < TN; ++j) { gs[i][j] += ps[j]; gq[i][j] += pq[j]; }
         } else if (gn_ws) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -423,12 +429,36 @@ __device__ __forceinline__ void epilogue_direct_body(typename Acc<DT>::type (&ac
         asm volatile("" ::: "memory");
     }
     if constexpr (GNREG) {
-        if (gn_ws) {
-            const int64_t slab = row0 / (TM * 32);
+        if (gn_ws) {                                        // workgroup-uniform
+            const int64_t slab = row0 >> 6;
+            float hs[TM][TN], hq[TM][TN];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const float a0 = gs[j] + __shfl_xor(gs[j], 32, 64), a1 = gq[j] + __shfl_xor(gq[j], 32, 64);
-                if (lane < 32) *reinterpret_cast<float2*>(gn_ws + (slab * N + col0 + j * 32 + fr) * 2) = make_float2(a0, a1);
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    hs[i][j] = gs[i][j] + __shfl_xor(gs[i][j], 32, 64);
+                    hq[i][j] = gq[i][j] + __shfl_xor(gq[i][j], 32, 64);
+                }
+            if constexpr (TM == 2) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    if (lane < 32)
+                        *reinterpret_cast<float2*>(gn_ws + (slab * N + col0 + j * 32 + fr) * 2) =
+                            make_float2(hs[0][j] + hs[1][j], hq[0][j] + hq[1][j]);
+            } else {
+                const bool upper = (row0 >> 5) & 1;         // this wave holds rows 32 .. 63 of the slab
+                if (upper && lane < 32) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) *reinterpret_cast<float2*>(gacc + (j * 32 + fr) * 2) = make_float2(hs[0][j], hq[0][j]);
+                }
+                __syncthreads();
+                if (!upper && lane < 32) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const float2 o = *reinterpret_cast<const float2*>(gacc + (j * 32 + fr) * 2);
+                        *reinterpret_cast<float2*>(gn_ws + (slab * N + col0 + j * 32 + fr) * 2) = make_float2(hs[0][j] + o.x, hq[0][j] + o.y);
+                    }
+                }
             }
         }
         return;
@@ -445,18 +475,19 @@ __device__ __forceinline__ void epilogue_direct_body(typename Acc<DT>::type (&ac
     }
 }
 
+// gpair (TM = 1): 2 x 32 TN floats of LDS shared by the two waves of a 64-row slab
 template <int DT, int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue_direct_gnreg(typename Acc<DT>::type (&acc)[TM][TN], const EpiRegs<TN>& er, int lane,
                                                            int64_t row0, int64_t col0, bool has_rowadd,
                                                            const float* __restrict__ residual, int64_t ldr,
                                                            float* __restrict__ out, int64_t ldo, float* __restrict__ gn_ws,
-                                                           int64_t N) {
+                                                           int64_t N, float* gpair = nullptr) {
     if (residual) {
-        if (has_rowadd) epilogue_direct_body<DT, TM, TN, true, true, true>(acc, er, lane, row0, col0, residual, ldr, out, ldo, nullptr, gn_ws, N);
-        else epilogue_direct_body<DT, TM, TN, false, true, true>(acc, er, lane, row0, col0, residual, ldr, out, ldo, nullptr, gn_ws, N);
+        if (has_rowadd) epilogue_direct_body<DT, TM, TN, true, true, true>(acc, er, lane, row0, col0, residual, ldr, out, ldo, gpair, gn_ws, N);
+        else epilogue_direct_body<DT, TM, TN, false, true, true>(acc, er, lane, row0, col0, residual, ldr, out, ldo, gpair, gn_ws, N);
     } else {
-        if (has_rowadd) epilogue_direct_body<DT, TM, TN, true, false, true>(acc, er, lane, row0, col0, residual, ldr, out, ldo, nullptr, gn_ws, N);
-        else epilogue_direct_body<DT, TM, TN, false, false, true>(acc, er, lane, row0, col0, residual, ldr, out, ldo, nullptr, gn_ws, N);
+        if (has_rowadd) epilogue_direct_body<DT, TM, TN, true, false, true>(acc, er, lane, row0, col0, residual, ldr, out, ldo, gpair, gn_ws, N);
+        else epilogue_direct_body<DT, TM, TN, false, false, true>(acc, er, lane, row0, col0, residual, ldr, out, ldo, gpair, gn_ws, N);
     }
 }
 
@@ -1664,19 +1695,22 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
 //   (surplus pieces repeat the last one: same bytes to the same place), weights before patch, so the wait in front of a
 //   step is vmcnt(PPW) when only the next chunk's patch may stay in flight and vmcnt(0) otherwise.
 // Integer accumulation: the order of taps and chunks does not change a bit of the result.
-template <int TN>
+// TM = 2: 256-pixel tiles (a wave owns 64 pixels x 96 columns); TM = 1: 128-pixel tiles (32 x 96 per wave) for the layers whose
+// 256-pixel tiles do not fill the chip -- the 8x8 level is 125 workgroups on 256 CUs; as 250 half-size ones every CU works.
+template <int TN, int TM>
 __global__ void __launch_bounds__(512)
 k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, int64_t M, int64_t N, int B, int H, int W,
                int Cin, int padval, int ups, const float* __restrict__ scale, const float* __restrict__ bias,
                const float* __restrict__ rowadd, int64_t rows_per_batch, const float* __restrict__ residual, int64_t ldr,
                float* __restrict__ out, int64_t ldo, float* __restrict__ gn_ws) {
-    constexpr int TM = 2, BM = 256, BN = 64 * TN;
+    constexpr int BM = 128 * TM, BN = 64 * TN, LBM = TM == 2 ? 8 : 7;
     STAMP(t_kernel);
     constexpr int PATCH_BYTES = 32 * 1024;                  // 8 waves x 4 pieces x 1 KiB >= 16 * ceil(NP / 16) * 64
     constexpr int SLAB_BYTES = 3 * BN * 64;                 // one filter row of one 64-channel chunk
     constexpr int RA = BM / 16 + 1;
     constexpr int EC_BYTES = (2 + RA) * BN * 4 + 16;
-    constexpr int SMEM_BYTES = 2 * PATCH_BYTES + 2 * SLAB_BYTES + EC_BYTES;
+    constexpr int GP_BYTES = TM == 1 ? 4 * (TN * 32) * 2 * 4 : 0;   // GroupNorm partial hand-over between the two waves of a slab
+    constexpr int SMEM_BYTES = 2 * PATCH_BYTES + 2 * SLAB_BYTES + EC_BYTES + GP_BYTES;
     __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM_BYTES];
     float* ec = reinterpret_cast<float*>(smem + 2 * PATCH_BYTES + 2 * SLAB_BYTES);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1694,7 +1728,7 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
     const int lw = 31 - __builtin_clz((unsigned)W), lhw = 31 - __builtin_clz((unsigned)HW);
     const int IMGS = HW >= BM ? 1 : BM >> lhw;
     const int TR = HW >= BM ? BM >> lw : H;
-    const int ltpi = HW >= BM ? lhw - 8 : 0;                // log2(tiles per image)
+    const int ltpi = HW >= BM ? lhw - LBM : 0;              // log2(tiles per image)
     const int b0 = (int)(HW >= BM ? tile >> ltpi : tile * IMGS);
     const int y0 = HW >= BM ? (int)(tile & ((1 << ltpi) - 1)) * TR : 0;
     const int PR = TR + 2, PW = W + 2;
@@ -1702,7 +1736,7 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
     auto div_small = [](int a, float r) { return (int)(((float)a + 0.5f) * r); };   // a / b for 0 <= a < 2^16, r = 1 / b
     const int NP = IMGS * PR * PW;
     const int pieces = (NP + 15) >> 4;
-    const int PPW = (pieces + 7) >> 3;                      // 3 or 4 (checked by the launcher)
+    const int PPW = (pieces + 7) >> 3;                      // 1 .. 4 (checked by the launcher)
     const int NC = Cin >> 6;
     const int KSH = W >= 32 ? 2 : 1;
     const uint8_t* pad_row = g_pad_rows + (int)(uint8_t)padval * 64;
@@ -1770,8 +1804,8 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
     int pp[TM], pcol[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int p = wm * 64 + i * 32 + fr;                // pixel of the tile, NHWC order
-        const int ltw = HW >= BM ? 8 : lhw;                 // TR * W = 256 or H * W
+        const int p = wm * (TM * 32) + i * 32 + fr;         // pixel of the tile, NHWC order
+        const int ltw = HW >= BM ? LBM : lhw;               // TR * W = BM or H * W
         const int img = p >> ltw, rem = p & ((1 << ltw) - 1);
         const int yl = rem >> lw, x = rem & (W - 1);
         pp[i] = (img * PR + yl) * PW + x;
@@ -1818,7 +1852,9 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
         // B(s) (and patch(c) when ky == 0) have landed once at most the next chunk's patch pieces are still in flight
         if (ky == 1 && c + 1 < NC) {
             if (PPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else if (PPW == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else if (PPW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -1849,12 +1885,15 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
         }
     }
     EpiRegs<TN> er;
-    load_epi_regs<TN, BN>(er, ec, lane, m0, m0 + wm * 64, wn * (TN * 32), rows_per_batch);
-    // gn_ws [M / 64][N][2]: per-channel (sum, sum of squares) of each 64-row slab of this output, for the GroupNorm that
-    // normalises it next (its statistics pass then only reduces these partials: no second read of the tensor)
+    load_epi_regs<TN, BN>(er, ec, lane, m0, m0 + wm * (TM * 32), wn * (TN * 32), rows_per_batch);
+    // gn_ws [M / (32 TM)][N][2]: per-channel (sum, sum of squares) of each wave-slab of this output (64 rows, 32 with 128-pixel
+    // tiles), for the GroupNorm that normalises it next (its statistics pass then only reduces these partials: no second read
+    // of the tensor)
     STAMP(t_main);
-    gemm_epilogue_direct_gnreg<0, TM, TN>(acc, er, lane, m0 + wm * 64, n0 + wn * (TN * 32), rowadd != nullptr, residual, ldr, out,
-                                          ldo, gn_ws, N);
+    float* gpair = TM == 1 ? reinterpret_cast<float*>(smem + 2 * PATCH_BYTES + 2 * SLAB_BYTES + EC_BYTES) + ((wm >> 1) * 2 + wn) * (TN * 32) * 2
+                           : nullptr;
+    gemm_epilogue_direct_gnreg<0, TM, TN>(acc, er, lane, m0 + wm * (TM * 32), n0 + wn * (TN * 32), rowadd != nullptr, residual, ldr,
+                                          out, ldo, gn_ws, N, gpair);
 #ifdef EDADM_STAMPS
     // slots: 0 prologue (entry -> first barrier passed), 1 waits in front of the other steps (6: their vmcnt part), 2 the rest of
     // the main loop, 3 epilogue incl. draining its stores, 4 samples, 5 total.  ONE wave of every eighth workgroup: the atomics
@@ -1891,22 +1930,35 @@ extern "C" int edadm_conv3_pack_w(const int8_t* w, int8_t* out, int64_t N, int64
     hipLaunchKernelGGL(k_conv3_pack_w, dim3(edadm_grid(N * 9 * Cin / 16, 256)), dim3(256), 0, (hipStream_t)stream, w, out, N, Cin, 192);
     return edadm_launch_status();
 }
-extern "C" int edadm_conv3_direct_ok(int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t N) {
+// the tile the kernel takes for a shape: 256 or 128 output pixels (0: not a shape for it)
+static int conv3_tile_fits(int64_t B, int64_t H, int64_t W, int64_t BMt) {
+    const int64_t HW = H * W;
+    if (HW >= BMt ? (HW % BMt != 0) : (BMt % HW != 0 || B % (BMt / HW) != 0)) return 0;
+    const int64_t imgs = HW >= BMt ? 1 : BMt / HW, tr = HW >= BMt ? BMt / W : H;
+    const int64_t pieces = (imgs * (tr + 2) * (W + 2) + 15) / 16, ppw = (pieces + 7) / 8;
+    return ppw >= 1 && ppw <= 4;
+}
+extern "C" int edadm_conv3_direct_tile(int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t N) {
     if (B <= 0 || H <= 0 || W <= 0 || Cin % 64 || N % 192 || Cin < 64) return 0;
     if (W != 8 && W != 16 && W != 32 && W != 64) return 0;
     if (H & (H - 1)) return 0;                              // the kernel's tile arithmetic is shifts: H * W a power of two
-    const int64_t HW = H * W;
-    if (HW >= 256 ? (HW % 256 != 0) : (256 % HW != 0 || B % (256 / HW) != 0)) return 0;
-    if (B * HW * Cin >= (1ll << 31)) return 0;
-    const int64_t imgs = HW >= 256 ? 1 : 256 / HW, tr = HW >= 256 ? 256 / W : H;
-    const int64_t pieces = (imgs * (tr + 2) * (W + 2) + 15) / 16, ppw = (pieces + 7) / 8;
-    return ppw == 3 || ppw == 4;
+    if (B * H * W * Cin >= (1ll << 31)) return 0;
+    const bool f256 = conv3_tile_fits(B, H, W, 256), f128 = conv3_tile_fits(B, H, W, 128);
+    static const int64_t small = getenv("EDADM_CONV3_TILE128_BELOW") ? atoll(getenv("EDADM_CONV3_TILE128_BELOW")) : 200;
+    // 256-pixel tiles unless they do not even fill one round of the 256 CUs (the 8x8 level: 125 workgroups -> 250 half-size
+    // ones, 88 -> 68 us; at 300 workgroups, the 16x16 level, both tile sizes take the same time)
+    if (f128 && (!f256 || (B * H * W / 256) * (N / 192) <= small)) return 128;
+    return f256 ? 256 : 0;
+}
+extern "C" int edadm_conv3_direct_ok(int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t N) {
+    return edadm_conv3_direct_tile(B, H, W, Cin, N) != 0;
 }
 extern "C" int edadm_qconv3_i8_direct(const int8_t* A, const int8_t* Wdc, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t N,
                                       int padval, int ups, const float* scale, const float* bias, const float* rowadd,
                                       int64_t rows_per_batch, const float* residual, int64_t ldr, float* out, int64_t ldo,
                                       float* gn_ws, void* stream) {
-    if (!A || !Wdc || !out || !scale || !edadm_conv3_direct_ok(B, H, W, Cin, N)) return EDADM_EINVAL;
+    const int tile = edadm_conv3_direct_tile(B, H, W, Cin, N);
+    if (!A || !Wdc || !out || !scale || !tile) return EDADM_EINVAL;
     if (gn_ws && (H * W) % 64) return EDADM_EINVAL;         // a 64-row slab must not straddle two images
     if (((uintptr_t)A & 15) || ((uintptr_t)Wdc & 15)) return EDADM_EINVAL;
     if (rowadd && rows_per_batch < 64) return EDADM_EINVAL;
@@ -1918,9 +1970,14 @@ extern "C" int edadm_qconv3_i8_direct(const int8_t* A, const int8_t* Wdc, int64_
         hipLaunchKernelGGL(k_init_pad_rows, dim3(1), dim3(256), 0, (hipStream_t)stream);
         pad_ready = true;
     }
-    hipLaunchKernelGGL((k_conv3_direct<3>), dim3((unsigned)(N / 192), (unsigned)(M / 256)), dim3(512), 0, (hipStream_t)stream,
-                       (const uint8_t*)A, (const uint8_t*)Wdc, M, N, (int)B, (int)H, (int)W, (int)Cin, padval, ups ? 1 : 0, scale, bias, rowadd,
-                       rows_per_batch, residual, ldr, out, ldo, gn_ws);
+    if (tile == 256)
+        hipLaunchKernelGGL((k_conv3_direct<3, 2>), dim3((unsigned)(N / 192), (unsigned)(M / 256)), dim3(512), 0, (hipStream_t)stream,
+                           (const uint8_t*)A, (const uint8_t*)Wdc, M, N, (int)B, (int)H, (int)W, (int)Cin, padval, ups ? 1 : 0, scale, bias,
+                           rowadd, rows_per_batch, residual, ldr, out, ldo, gn_ws);
+    else
+        hipLaunchKernelGGL((k_conv3_direct<3, 1>), dim3((unsigned)(N / 192), (unsigned)(M / 128)), dim3(512), 0, (hipStream_t)stream,
+                           (const uint8_t*)A, (const uint8_t*)Wdc, M, N, (int)B, (int)H, (int)W, (int)Cin, padval, ups ? 1 : 0, scale, bias,
+                           rowadd, rows_per_batch, residual, ldr, out, ldo, gn_ws);
     return edadm_launch_status();
 }
 #endif

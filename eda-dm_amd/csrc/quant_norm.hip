@@ -220,16 +220,21 @@ __global__ void __launch_bounds__(256) k_gn_partial(const float* __restrict__ x,
 // ws2 != nullptr: channels [C1, C) come from a second partials buffer (the other half of a skip concatenation)
 __global__ void __launch_bounds__(64) k_gn_final(const float* __restrict__ ws, const float* __restrict__ ws2, int64_t C1,
                                                  float* __restrict__ stats,
-                                                 int64_t HW, int64_t C, int64_t G, int nchunk, float eps, int64_t B2 = 0) {
+                                                 int64_t HW, int64_t C, int64_t G, int nchunk, float eps, int64_t B2 = 0,
+                                                 int nchunk2 = 0) {
+    // nchunk2: slabs per image of the second buffer when its producer cut the image differently (0: as the first)
     const int64_t b = blockIdx.y, g = blockIdx.x;
     const int64_t b2 = B2 > 0 ? b % B2 : b;               // the second buffer may hold a whole fraction of the batch (guidance pair)
     const int cpg = (int)(C / G);
+    const int nc2 = nchunk2 > 0 ? nchunk2 : nchunk;
     double s = 0.0, ss = 0.0;
-    const int items = nchunk * cpg;
+    const int items = (nchunk > nc2 ? nchunk : nc2) * cpg;
     for (int i = threadIdx.x; i < items; i += 64) {
         const int ch = i / cpg, c = (int)(g * cpg) + i % cpg;
-        const float* p = (!ws2 || c < C1) ? ws + ((b * nchunk + ch) * (ws2 ? C1 : C) + c) * 2
-                                          : ws2 + ((b2 * nchunk + ch) * (C - C1) + (c - C1)) * 2;
+        const bool first = !ws2 || c < C1;
+        if (ch >= (first ? nchunk : nc2)) continue;
+        const float* p = first ? ws + ((b * nchunk + ch) * (ws2 ? C1 : C) + c) * 2
+                               : ws2 + ((b2 * nc2 + ch) * (C - C1) + (c - C1)) * 2;
         s += (double)p[0];
         ss += (double)p[1];
     }
@@ -274,6 +279,18 @@ extern "C" int edadm_groupnorm_final_cat_rep(const float* ws1, int64_t C1, const
         return EDADM_EINVAL;
     hipLaunchKernelGGL(k_gn_final, dim3((unsigned)G, (unsigned)B), dim3(64), 0, (hipStream_t)stream, ws1, ws2, C1, stats, HW, C,
                        G, (int)nchunk, eps, B2);
+    return edadm_launch_status();
+}
+// the same with its own slab count for the second buffer (producers with 64-row and 32-row slabs on the two halves)
+extern "C" int edadm_groupnorm_final_cat_rep2(const float* ws1, int64_t C1, const float* ws2, int64_t C2, float* stats, int64_t B,
+                                              int64_t HW, int64_t G, int64_t nchunk1, int64_t nchunk2, float eps, int64_t B2,
+                                              void* stream) {
+    const int64_t C = C1 + (ws2 ? C2 : 0);
+    if (!ws1 || !stats || B <= 0 || HW <= 0 || C1 <= 0 || (ws2 && C2 <= 0) || G <= 0 || (C % G) || nchunk1 <= 0 || nchunk2 < 0 ||
+        B2 < 0 || (B2 > 0 && (!ws2 || B % B2)))
+        return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_gn_final, dim3((unsigned)G, (unsigned)B), dim3(64), 0, (hipStream_t)stream, ws1, ws2, C1, stats, HW, C,
+                       G, (int)nchunk1, eps, B2, (int)nchunk2);
     return edadm_launch_status();
 }
 extern "C" int edadm_groupnorm_final_cat(const float* ws1, int64_t C1, const float* ws2, int64_t C2, float* stats, int64_t B,

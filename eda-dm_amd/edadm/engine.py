@@ -297,7 +297,7 @@ class Engine:
                 ops.gn_partials_ok(M, L.N, gn_hw, rpb if rowadd is not None else None):
             ws = torch.empty(M // 64, L.N, 2, dtype=torch.float32, device=self.dev)
             gkw = dict(gn_ws=ws, gn_hw=gn_hw)
-            out._gn = (ws, gn_hw)
+            out._gn = (ws, gn_hw, 64)
         if geom is not None:
             s = L.segs[0]
 
@@ -361,7 +361,8 @@ class Engine:
 
             # GroupNorm partials of this output from the epilogue's registers (no atomics): the layer that normalises it next
             # skips its statistics pass over the tensor
-            ws = torch.empty(M // 64, L.N, 2, dtype=torch.float32, device=self.dev) if (self.gn_partials and (Hl * Wl) % 64 == 0) else None
+            slab = 64                                      # rows per partial slab, whatever tile the kernel takes
+            ws = torch.empty(M // slab, L.N, 2, dtype=torch.float32, device=self.dev) if (self.gn_partials and (Hl * Wl) % slab == 0) else None
 
             def run():
                 ops.qconv3_i8_direct(a, L.wdc, B, Hl, Wl, L.cin, L.N, padval, s0["scale"], L.bias, out, rowadd=rowadd,
@@ -374,7 +375,7 @@ class Engine:
             run()
             o4 = out.reshape(B, Hl, Wl, L.N)
             if ws is not None:
-                o4._gn = (ws, Hl * Wl)
+                o4._gn = (ws, Hl * Wl, slab)
             return o4
         geom = ops.make_geom(B, H, W, L.cin, Ho, Wo, L.kh, L.kh, L.stride, pad0, ups, padval)
         M = B * Ho * Wo
@@ -400,7 +401,7 @@ class Engine:
             ws2 = gs[1][0] if len(gs) == 2 else None
             rep = x.rep if isinstance(x, ops.Cat) else 1
             return ops.groupnorm_final(gs[0][0], parts[0].shape[-1], ws2, parts[-1].shape[-1], B, HW, norm.num_groups, norm.eps,
-                                       B2=parts[-1].shape[0] if rep > 1 else 0)
+                                       B2=parts[-1].shape[0] if rep > 1 else 0, rows1=gs[0][2], rows2=gs[-1][2])
         return ops.groupnorm_stats(x, norm.num_groups, norm.eps)
 
     def gn(self, norm, x, silu, qms=(), want_f32=False, scale_shift=None, raw=None):

@@ -413,12 +413,12 @@ def gn_partials_ok(M, N, hw, rowadd_rpb=None):
         (rowadd_rpb is None or rowadd_rpb >= 64)
 
 
-def groupnorm_final(ws1, C1, ws2, C2, B, HW, G, eps, B2=0):
-    """stats[B][G][2] from producer-written partials [B][HW/64][C][2] (ws2: second half of a concatenation, B2 > 0: of
-    B2 images read periodically)."""
+def groupnorm_final(ws1, C1, ws2, C2, B, HW, G, eps, B2=0, rows1=64, rows2=64):
+    """stats[B][G][2] from producer-written partials [B][HW/rows][C][2] (ws2: second half of a concatenation, B2 > 0: of
+    B2 images read periodically; rows1 / rows2: rows per slab of the two producers)."""
     stats = torch.empty(B, G, 2, dtype=torch.float32, device=ws1.device)
-    lib.call("edadm_groupnorm_final_cat_rep", _pf(ws1), C1, _pf(ws2), C2 if ws2 is not None else 0, _pf(stats), B, HW, G,
-             HW // 64, float(eps), int(B2), _stream())
+    lib.call("edadm_groupnorm_final_cat_rep2", _pf(ws1), C1, _pf(ws2), C2 if ws2 is not None else 0, _pf(stats), B, HW, G,
+             HW // int(rows1), HW // int(rows2) if ws2 is not None else 0, float(eps), int(B2), _stream())
     return stats
 
 
@@ -441,6 +441,12 @@ def qgemm_i8(A, Wt, M, N, K, scale, bias, out, geom=None, lda=None, ldw=None, ro
 
 def conv3_direct_ok(B, H, W, Cin, N):
     return bool(lib.load().edadm_conv3_direct_ok(int(B), int(H), int(W), int(Cin), int(N)))
+
+
+def conv3_direct_tile(B, H, W, Cin, N):
+    """output pixels per workgroup tile of edadm_qconv3_i8_direct for this shape (256 / 128; 0: not taken); its GroupNorm
+    partials come in slabs of tile / 4 rows"""
+    return int(lib.load().edadm_conv3_direct_tile(int(B), int(H), int(W), int(Cin), int(N)))
 
 
 def conv3_pack_w(w_i8, N, Cin):

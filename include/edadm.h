@@ -175,6 +175,10 @@ int edadm_groupnorm_final_cat(const float* ws1, int64_t C1, const float* ws2, in
  * half of a classifier-free-guidance pair; B2 = 0: same batch */
 int edadm_groupnorm_final_cat_rep(const float* ws1, int64_t C1, const float* ws2, int64_t C2, float* stats, int64_t B,
                                   int64_t HW, int64_t G, int64_t nchunk, float eps, int64_t B2, void* stream);
+/* the same with a slab count of its own for the second buffer (nchunk2 = 0: as the first): producers that cut an image into
+ * 64-row and 32-row slabs (edadm_qconv3_i8_direct with 256- and 128-pixel tiles) on the two halves of a concatenation */
+int edadm_groupnorm_final_cat_rep2(const float* ws1, int64_t C1, const float* ws2, int64_t C2, float* stats, int64_t B,
+                                   int64_t HW, int64_t G, int64_t nchunk1, int64_t nchunk2, float eps, int64_t B2, void* stream);
 /* LayerNorm over the last dim, same output options (ldm/modules/attention.py:222-242). */
 int edadm_layernorm_quant(const float* x, const float* gamma, const float* beta, int64_t rows, int64_t C,
                           float eps, float* out_f32, int8_t* q0, int8_t* q1, int8_t* q2, const float* qp,
@@ -338,13 +342,17 @@ int edadm_rng_epoch(uint64_t value, int add, void* stream);
  * input patch of a 256-pixel tile stays in LDS per 64-channel chunk, so an activation byte crosses L2 -> LDS once per
  * chunk instead of once per tap.  Wdc = the filter in the kernel's own layout (edadm_conv3_pack_w from the [N][3][3][Cin]
  * int8 filter of edadm_qgemm_i8); same epilogue contract as edadm_qgemm_i8 (scale, bias, per-image row-add, fp32 residual).
- * edadm_conv3_direct_ok: 1 when (B, H, W, Cin, N) is a shape the kernel takes (W in {8,16,32,64}, Cin % 64 == 0,
- * N % 192 == 0, whole 256-pixel tiles).  H, W are the dimensions the convolution runs over; with ups = 1 the stored
+ * edadm_conv3_direct_tile: the output pixels per workgroup tile for (B, H, W, Cin, N) -- 256, or 128 where 256-pixel tiles
+ * would not fill one round of the CUs (the 8x8 level) or do not divide the batch -- and 0 when the shape is not one the kernel takes
+ * (W in {8,16,32,64}, H a power of two, Cin % 64 == 0, N % 192 == 0, whole tiles); edadm_conv3_direct_ok: tile != 0.
+ * H, W are the dimensions the convolution runs over; with ups = 1 the stored
  * tensor is [B][H/2][W/2][Cin] and its nearest-2x upsample (openaimodel.py:110-118, diffusion.py:41-45) is read in place.
  * gn_ws (or NULL): [M / 64][N][2] per-channel (sum, sum of squares) of every 64-row slab of the output, written from the
- * epilogue's registers -- the partials edadm_groupnorm_final_cat reduces (H * W % 64 == 0). */
+ * epilogue's registers in an order that does not depend on the tile -- the partials edadm_groupnorm_final_cat reduces
+ * (H * W % 64 == 0). */
 int edadm_conv3_pack_w(const int8_t* w, int8_t* out, int64_t N, int64_t Cin, void* stream);
 int edadm_conv3_direct_ok(int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t N);
+int edadm_conv3_direct_tile(int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t N);
 int edadm_qconv3_i8_direct(const int8_t* A, const int8_t* Wdc, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t N,
                            int padval, int ups, const float* scale, const float* bias, const float* rowadd, int64_t rows_per_batch,
                            const float* residual, int64_t ldr, float* out, int64_t ldo, float* gn_ws, void* stream);

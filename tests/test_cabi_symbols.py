@@ -37,7 +37,12 @@ def test_direct_conv_shape_gate():
     from edadm import lib
     ok = lib.load().edadm_conv3_direct_ok
     for B, H, W, Cin, N, want in ((100, 64, 64, 192, 192, 1), (100, 8, 8, 960, 960, 1), (4, 16, 16, 576, 192, 1),
-                                  (3, 8, 8, 960, 960, 0),       # 3 images of 64 pixels do not fill 256-pixel tiles
+                                  (3, 8, 8, 960, 960, 0),       # 3 images of 64 pixels fill neither 256- nor 128-pixel tiles
+                                  (6, 8, 8, 960, 960, 1),       # ... 6 fill 128-pixel ones
                                   (2, 96, 64, 64, 192, 0),      # height no power of two
                                   (2, 64, 48, 64, 192, 0), (2, 64, 64, 96, 192, 0), (2, 64, 64, 64, 128, 0)):
         assert ok(B, H, W, Cin, N) == want, (B, H, W, Cin, N)
+    tile = lib.load().edadm_conv3_direct_tile
+    assert tile(100, 64, 64, 192, 192) == 256 and tile(100, 32, 32, 384, 384) == 256      # 1600 / 800 workgroups
+    assert tile(100, 16, 16, 576, 576) == 256 and tile(100, 8, 8, 960, 960) == 128        # 300 / 125 at 256 pixels
+    assert tile(6, 8, 8, 960, 960) == 128 and tile(3, 8, 8, 960, 960) == 0

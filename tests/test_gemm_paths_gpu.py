@@ -140,8 +140,11 @@ def test_qgemm_transposed_f16_output(ops, B, Nk, N, K):
     assert torch.equal(tr, plain.reshape(B, Nk, N).transpose(1, 2))
 
 
+# the small cases take 128-pixel tiles (fewer than 200 workgroups of 256 pixels); (100, 16, 16, 128, 960) is large enough for
+# 256-pixel tiles at that level, (6, 8, 8, ...) fits 128-pixel tiles only (two images each)
 @pytest.mark.parametrize("B,H,W,Cin,N", [(3, 64, 64, 192, 192), (5, 32, 32, 384, 384), (6, 16, 16, 576, 192), (8, 8, 8, 960, 384),
-                                          (2, 64, 64, 64, 192), (4, 32, 32, 1152, 384), (2, 16, 16, 128, 576)])
+                                          (2, 64, 64, 64, 192), (4, 32, 32, 1152, 384), (2, 16, 16, 128, 576),
+                                          (100, 16, 16, 128, 960), (6, 8, 8, 192, 192), (3, 16, 32, 64, 192)])
 def test_direct_conv3_equals_the_implicit_gemm_bit_for_bit(ops, B, H, W, Cin, N):
     """edadm_qconv3_i8_direct (input patch of a 256-pixel tile resident in LDS, weights streamed) against edadm_qgemm_i8's
     implicit-GEMM gather on the same operands: integer accumulation, same epilogue arithmetic -> identical fp32 bits, with
@@ -199,10 +202,11 @@ def test_direct_conv3_over_the_folded_upsample(ops, B, Hin, Cin, N):
     assert torch.equal(got.double(), ref)
 
 
-@pytest.mark.parametrize("B,H,Cin,N", [(4, 64, 192, 192), (6, 16, 576, 576), (8, 8, 960, 384)])
+@pytest.mark.parametrize("B,H,Cin,N", [(24, 64, 192, 192), (6, 16, 576, 576), (8, 8, 960, 384)])
 def test_direct_conv3_groupnorm_partials(ops, B, H, Cin, N):
     """edadm_qconv3_i8_direct with gn_ws: per-channel (sum, sum of squares) of every 64-row slab of the output, summed in
-    the epilogue's registers; reduced by edadm_groupnorm_final_cat[_rep] they give the statistics of the two-pass kernels on
+    the epilogue's registers (128-pixel tiles -- the last two cases -- split a slab over two waves, which add up in the same
+    order); reduced by edadm_groupnorm_final_cat[_rep2] they give the statistics of the two-pass kernels on
     the same output to 2e-5 (fp32 partial sums in another order, combined in fp64) -- alone, as the second half of a skip
     concatenation, and as the half-batch part of a guidance pair read periodically.  The output itself does not change."""
     g = torch.Generator().manual_seed(B + H + N)
@@ -213,21 +217,54 @@ def test_direct_conv3_groupnorm_partials(ops, B, H, Cin, N):
     wdc = ops.conv3_pack_w(w, N, Cin)
     res = torch.randn(M, N, generator=g).cuda()
     out0 = ops.qconv3_i8_direct(x, wdc, B, H, H, Cin, N, 3, scale, bias, torch.empty(M, N, device="cuda"), residual=res)
-    ws = torch.full((M // 64, N, 2), float("nan"), device="cuda")
+    rows = 64
+    assert ops.conv3_direct_tile(B, H, H, Cin, N) == (256 if H == 64 else 128)
+    ws = torch.full((M // rows, N, 2), float("nan"), device="cuda")
     out = ops.qconv3_i8_direct(x, wdc, B, H, H, Cin, N, 3, scale, bias, torch.empty(M, N, device="cuda"), residual=res, gn_ws=ws)
     assert torch.equal(out, out0) and torch.isfinite(ws).all()
     G = 32
     xo = out.reshape(B, HW, N)
     tol = lambda got, want: ((got - want).abs() <= 2e-5 * want.abs().clamp_min(1.0)).all()
-    assert tol(ops.groupnorm_final(ws, N, None, 0, B, HW, G, 1e-5), ops.groupnorm_stats(xo, G, 1e-5))
+    assert tol(ops.groupnorm_final(ws, N, None, 0, B, HW, G, 1e-5, rows1=rows), ops.groupnorm_stats(xo, G, 1e-5))
     other = torch.randn(B, HW, 64, generator=g).cuda() * 3
     ws_o = torch.empty(M // 64, 64, 2, device="cuda")
     o3 = other.reshape(M // 64, 64, 64)
     ws_o[..., 0], ws_o[..., 1] = o3.sum(1), (o3 * o3).sum(1)
-    assert tol(ops.groupnorm_final(ws_o, 64, ws, N, B, HW, G, 1e-5), ops.groupnorm_stats(ops.Cat(other, xo), G, 1e-5))
+    assert tol(ops.groupnorm_final(ws_o, 64, ws, N, B, HW, G, 1e-5, rows2=rows), ops.groupnorm_stats(ops.Cat(other, xo), G, 1e-5))
+    assert tol(ops.groupnorm_final(ws, N, ws_o, 64, B, HW, G, 1e-5, rows1=rows), ops.groupnorm_stats(ops.Cat(xo, other), G, 1e-5))
     # guidance pair: the second part holds half the images and is read periodically
     big = torch.cat([other, other * 0.5])
     ws_b = torch.cat([ws_o, ws_o * torch.tensor([0.5, 0.25], device="cuda")])
-    got = ops.groupnorm_final(ws_b, 64, ws, N, 2 * B, HW, G, 1e-5, B2=B)
+    got = ops.groupnorm_final(ws_b, 64, ws, N, 2 * B, HW, G, 1e-5, B2=B, rows2=rows)
     want = ops.groupnorm_stats(ops.Cat(big, xo), G, 1e-5)
     assert tol(got, want)
+
+
+def test_direct_conv3_partials_do_not_depend_on_the_tile(ops):
+    """The same images convolved inside a small batch (128-pixel tiles: two waves per 64-row slab) and inside a large one
+    (256-pixel tiles: one wave per slab) give the same output AND the same GroupNorm partials, bit for bit: the sampling
+    loop evaluates the prefix of a guidance pair at half the batch and must reproduce the doubled evaluation exactly."""
+    g = torch.Generator().manual_seed(5)
+    Cin = N = 192
+    H = 64
+    big, small = 16, 4
+    assert ops.conv3_direct_tile(big, H, H, Cin, N) == 256 and ops.conv3_direct_tile(small, H, H, Cin, N) == 128
+    x = torch.randint(-128, 128, (big, H, H, Cin), generator=g, dtype=torch.int8).cuda()
+    w = torch.randint(-8, 9, (N, 9 * Cin), generator=g, dtype=torch.int8).cuda()
+    scale, bias = (torch.rand(N, generator=g) * 1e-2 + 1e-3).cuda(), torch.randn(N, generator=g).cuda()
+    rowadd = torch.randn(big, N, generator=g).cuda()
+    wdc = ops.conv3_pack_w(w, N, Cin)
+
+    def run(xs, ra):
+        B = xs.shape[0]
+        M = B * H * H
+        ws = torch.full((M // 64, N, 2), float("nan"), device="cuda")
+        out = ops.qconv3_i8_direct(xs, wdc, B, H, H, Cin, N, 0, scale, bias, torch.empty(M, N, device="cuda"), rowadd=ra,
+                                   rows_per_batch=H * H, gn_ws=ws)
+        return out, ws
+
+    ob, wb = run(x, rowadd)
+    os_, ws_ = run(x[:small].contiguous(), rowadd[:small].contiguous())
+    n = small * H * H
+    assert torch.equal(ob[:n], os_)
+    assert torch.equal(wb[:n // 64], ws_)

@@ -36,7 +36,7 @@ def case(B, H, Cin, N, residual):
 
 
 SHAPES = ((100, 64, 192, 192), (100, 32, 384, 384), (100, 16, 576, 576), (100, 8, 960, 960), (100, 64, 576, 192),
-          (100, 8, 1920, 960))
+          (100, 8, 1920, 960), (100, 16, 1152, 576))
 if os.environ.get("SHAPES"):
     SHAPES = tuple(SHAPES[int(i)] for i in os.environ["SHAPES"].split(","))
 for B, H, Cin, N in SHAPES:
