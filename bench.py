@@ -422,7 +422,7 @@ def main():
 
     traffic = None
     try:        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-        with open(os.path.join(ROOT, "profiles", "r02j_gemm_traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r02z_gemm_traffic.json")) as fh:
             tj = json.load(fh)
             # bytes of all int8 GEMM launches of one UNet call / the GEMM calls timed above (a split or tail-re-tiled
             # layer is two device launches of one call)
