@@ -681,6 +681,9 @@ __global__ void __launch_bounds__(256) k_absmax_part(const float* __restrict__ x
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    // consumers scan all EDADM_RED_BLOCKS slots: block 0 clears the ones no block owns (instead of a memset launch per scan)
+    if (blockIdx.x == 0)
+        for (int i = (int)gridDim.x + (int)threadIdx.x; i < EDADM_RED_BLOCKS; i += 256) part[i] = 0.f;
 }
 
 // power-of-two scale that brings amax into [2^13, 2^14); 1 for an all-zero or non-finite tensor
@@ -979,7 +982,6 @@ extern "C" int edadm_absmax_parts(const float* x, int64_t n, float* parts, void*
     hipStream_t st = (hipStream_t)stream;
     int g = edadm_grid(n / 4, 256);
     if (g > EDADM_RED_BLOCKS) g = EDADM_RED_BLOCKS;
-    if (hipMemsetAsync(parts, 0, EDADM_RED_BLOCKS * sizeof(float), st) != hipSuccess) return EDADM_EIO;
     hipLaunchKernelGGL(k_absmax_part, dim3(g), dim3(256), 0, st, x, n / 4, parts);
     return edadm_launch_status();
 }
