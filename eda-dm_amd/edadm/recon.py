@@ -157,6 +157,9 @@ TIMING = None
 # in front of the capture (lazy initialisation, allocator warm-up)
 GRAPH_MIN_ITERS = int(os.environ.get("EDADM_RECON_GRAPH_MIN_ITERS", "32"))
 GRAPH_WARMUP = 2
+# parity tests: a callable (cur_inp) -> uniforms that replace the in-kernel RNG of the input mix (block_recon.py:141-145), the
+# counterpart of UniformAffineQuantizer.injected_uniform; None = the counter RNG keyed by (seed, element)
+INJECT_MIX_UNIFORM = None
 
 
 def fp_features(unit, hooks, cached_inps, resblock, sz, chunk, budget_bytes):
@@ -192,6 +195,9 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
     from qdiff.quant_block import BaseQuantBlock
     from qdiff.data_utils import save_inp_oup_data
     save_fn = save_fn or save_inp_oup_data
+    # the device-side mask epoch counts graph replays; every unit starts from 0 so that a calibration is a function of
+    # (random.seed, seed_mask_rng) alone, however many replays earlier units ran (edadm.h: epoch 0 leaves seeds as passed)
+    ops.rng_epoch(0)
     unit.set_quant_state(True, act_quant)
     round_mode = 'learned_hard_sigmoid'
     hooks, w_para, a_para, trained_aq = [], [], [], []
@@ -272,7 +278,11 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
         else:
             cur_inp, cur_sym = cached_inps[0][idx_t], cached_inps[1][idx_t]
         if input_prob < 1.0:
-            cur_inp = ops.mix_where(cur_inp.contiguous(), cur_sym.contiguous(), input_prob, seed=_mask_rng.getrandbits(62))
+            if INJECT_MIX_UNIFORM is not None:
+                cur_inp = ops.mix_where(cur_inp.contiguous(), cur_sym.contiguous(), input_prob,
+                                        u=INJECT_MIX_UNIFORM(cur_inp).contiguous())
+            else:
+                cur_inp = ops.mix_where(cur_inp.contiguous(), cur_sym.contiguous(), input_prob, seed=_mask_rng.getrandbits(62))
         elif is_block:
             cur_inp = cur_sym                 # block_recon.py:144-145 (the layer loop keeps cur_inp)
         for o in (w_opt, a_opt):

@@ -1183,7 +1183,7 @@ def _prepare_unit(unit, kind, act_quant, recon_w, recon_a):
 
 def reconstruct_unit(net, unit, kind, cali, batch_size=32, iters=20000, act_quant=False, lr_a=4e-5, lr_w=1e-2,
                      p=2.0, input_prob=1.0, recon_w=False, recon_a=False, add_loss=0.0, cache_batch=32,
-                     rand_fn=None, trace=None):
+                     rand_fn=None, trace=None, caches=None):
     """block_reconstruction / layer_reconstruction with asym=True, opt_mode='mse', round loss 'none';
     kind 'attn_layer' = AttnBlock_layer_reconstruction (attn_layer_recon.py:13-133: block output loss only, the
     attention step sizes the only trainables, cur_inp = cur_sym when input_prob == 1 as in the block loop)."""
@@ -1191,7 +1191,8 @@ def reconstruct_unit(net, unit, kind, cali, batch_size=32, iters=20000, act_quan
     layers, w_para, a_para, aqs = _prepare_unit(unit, kind, act_quant, recon_w, recon_a)
     w_opt = OAdam(w_para, lr_w, iters) if w_para else None
     a_opt = OAdam(a_para, lr_a, iters) if a_para else None
-    two, inp_q, inp_fp, out_fp = save_inp_oup_data(net, unit, cali, act_quant, cache_batch)
+    # `caches`: the (two, inp_q, inp_fp, out_fp) a test captured from the reference's own walk, instead of re-deriving them
+    two, inp_q, inp_fp, out_fp = caches if caches is not None else save_inp_oup_data(net, unit, cali, act_quant, cache_batch)
     sz = out_fp.size(0)
     for it in range(iters):
         idx = random.sample(range(sz), batch_size)

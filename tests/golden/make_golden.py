@@ -612,6 +612,136 @@ def g8_g12_recon():
     save("g8_recon", d)
 
 
+def _recon_variant(fname, prob, input_prob, N=32, iters=12):
+    """G8b / G8c: the G8 walk (layer_recon.py:13-129, block_recon.py:13-232 on the 2-block toy model) with everything a test
+    needs to REMOVE every cause of divergence but the loop itself: the reference's initial scales (init/qp/*), the cached
+    (inp_q, inp_fp, out_fp) tensors of every unit as the reference's save_inp_oup_data returned them during ITS walk
+    (data_utils.py:7-75), the drawn minibatch indices, and -- for prob / input_prob < 1, the shipped 0.5 / 0.5 of
+    sample_diffusion_ldm_imagenet.py:144,185 -- the uniforms of every torch.rand_like call (block_recon.py:141-145 input
+    mix; quant_layer.py:271-275 in both quantised forwards of an iteration, block_recon.py:154,167), supplied by
+    tests/golden/_uniforms.py through a patched torch.rand_like and logged in call order."""
+    import _uniforms
+    import qdiff.block_recon as rb_mod
+    import qdiff.layer_recon as rl_mod
+    seed_everything(808)
+    g = torch.Generator().manual_seed(808)
+    net = _ToyNet().eval()
+    d = {"sd/" + k: v for k, v in net.state_dict().items()}
+    aq = dict(AQ8)
+    aq["prob"] = prob
+    qnn = QuantModel(net, WQ4, aq, sm_abit=8)
+    qnn.eval()
+    x = torch.randn(N, 3, 8, 8, generator=g)
+    t = torch.randint(0, 1000, (N,), generator=g).float()
+    d["x"], d["t"] = x, t
+    d["prob"], d["input_prob"], d["iters"] = np.float64(prob), np.float64(input_prob), np.int64(iters)
+    cali = (x, t)
+    set_weight_quantize_params(qnn, cali)
+    set_act_quantize_params(qnn, cali, batch_size=32)
+    for k, v in qparams_of(qnn).items():
+        d["init/" + k] = v
+    kwargs = dict(cali_data=cali, iters=iters, act_quant=True, asym=True, opt_mode="mse", lr_a=1e-3, lr_w=5e-2,
+                  p=2.0, weight=0.0001, b_range=(20, 2), warmup=0.2, batch_size=16, input_prob=input_prob,
+                  add_loss=0.8, recon_w=True, recon_a=True, keep_gpu=True)
+    traj, cur, idx_log = {}, {"name": None, "phase": "iter"}, {}
+    rep = _uniforms.Replay()
+    checks = []
+    orig_step, orig_sample, orig_rand_like = torch.optim.Adam.step, random.sample, torch.rand_like
+
+    def step(self, *a, **k):
+        r = orig_step(self, *a, **k)
+        ps = [p for gr in self.param_groups for p in gr["params"]]
+        key = "%s/%s" % (cur["name"], "a" if ps[0].numel() == 1 else "w")
+        traj.setdefault(key, []).append(torch.cat([p.detach().flatten() for p in ps]).clone())
+        return r
+
+    def sample(pop, k):
+        r = orig_sample(pop, k)
+        idx_log.setdefault(cur["name"], []).append(list(r))
+        return r
+
+    def rand_like(xx, **k):
+        owner = sys._getframe(1).f_locals.get("self")
+        name = None
+        if owner is not None:
+            for n, m in qnn.named_modules():
+                if m is owner:
+                    name = n
+        if name is None:
+            assert owner is None, type(owner)
+            name = "input_mix:" + cur["name"]
+        u = _uniforms.uniform(name, cur["phase"], rep.counts.get((name, cur["phase"]), 0), xx.shape)
+        rep.draw(name, cur["phase"], xx.shape)
+        checks.append([float(u.reshape(-1)[0]), float(u.reshape(-1)[-1]), float(u.astype(np.float64).sum())])
+        return torch.from_numpy(u)
+
+    def wrap_save(mod):
+        orig = mod.save_inp_oup_data
+
+        def run(*a, **k):
+            cur["phase"] = "cache"
+            try:
+                res, ci, co = orig(*a, **k)
+            finally:
+                cur["phase"] = "iter"
+            key = "cache/%s/" % cur["name"]
+            d[key + "resblock"] = np.int64(res)
+            if res:
+                d[key + "inp_q"], d[key + "temb_q"] = ci[0][0], ci[0][1]
+                d[key + "inp_fp"], d[key + "temb_fp"] = ci[1][0], ci[1][1]
+            else:
+                d[key + "inp_q"], d[key + "inp_fp"] = ci[0], ci[1]
+            d[key + "out_fp"] = co
+            return res, ci, co
+        mod.save_inp_oup_data = run
+        return orig
+
+    torch.optim.Adam.step, random.sample, torch.rand_like = step, sample, rand_like
+    osb, osl = wrap_save(rb_mod), wrap_save(rl_mod)
+    units = (("conv_in", rl_mod.layer_reconstruction), ("temb_lin", rl_mod.layer_reconstruction),
+             ("rb", rb_mod.block_reconstruction), ("at", rb_mod.block_reconstruction),
+             ("conv_out", rl_mod.layer_reconstruction))
+    try:
+        random.seed(8080)
+        for name, fn in units:
+            cur["name"] = name
+            fn(qnn, getattr(qnn.model, name), **kwargs)
+    finally:
+        torch.optim.Adam.step, random.sample, torch.rand_like = orig_step, orig_sample, orig_rand_like
+        rb_mod.save_inp_oup_data, rl_mod.save_inp_oup_data = osb, osl
+    for k, v in traj.items():
+        d["traj/" + k] = torch.stack(v)
+    for k, v in idx_log.items():
+        d["idx/" + k] = np.array(v)
+    for k, v in qparams_of(qnn).items():
+        d["final/" + k] = v
+    for name, m in qnn.named_modules():
+        if isinstance(m, AdaRoundQuantizer):
+            d["final/alpha/" + name] = m.alpha
+            # index space: the hard-rounded integer weight codes the reference ends with (adaptive_rounding.py:49-60)
+            w = dict(qnn.named_modules())[name.rsplit(".", 1)[0]].org_weight
+            if name.endswith("_0"):
+                raise AssertionError("toy model has no split layer")
+            with torch.no_grad():
+                xi = torch.floor(w / m.delta) + (m.alpha >= 0).float()
+                d["final/codes/" + name] = torch.clamp(xi + m.zero_point, 0, m.n_levels - 1).to(torch.int16)
+    d["rand/log"] = np.array(["%s|%s|%d|%s" % (o, p, c, "x".join(map(str, s))) for o, p, c, s in rep.log])
+    d["rand/check"] = np.array(checks, dtype=np.float64).reshape(-1, 3)
+    qnn.set_quant_state(True, True)
+    with torch.no_grad():
+        d["final/out_q"] = qnn(x[:8], t[:8])
+    d["block_count"] = np.int64(qnn.block_count)
+    save(fname, d)
+
+
+def g8b_recon_masks():
+    _recon_variant("g8b_recon_masks", 0.5, 0.5)
+
+
+def g8c_recon_caches():
+    _recon_variant("g8c_recon_caches", 1.0, 1.0)
+
+
 def g9_tdac():
     """G9: TDAC scoring / allocation maths on synthetic feature maps (calibration.py:45-92;
     Church `>= 0` fix-up variant :332)."""
@@ -1093,7 +1223,8 @@ if __name__ == "__main__":
     jobs = dict(g1=g1_weight_init, g2=g2_act_init, g3=g3_uaq_forward, g4=g4_adaround, g5=g5_loss,
                 g6=g6_quant_module, g7=g7_blocks, g8=g8_g12_recon, g9=g9_tdac, g10=g10_steps,
                 g13c=g13_cifar_unet, g13i=lambda: g13_ldm_unet("imagenet"), g13h=lambda: g13_ldm_unet("church"), g14=g14_plms, g15=g15_decoder,
-                g17=g17_tdac_imagenet, g7b=g7b_blocks, g13w8=lambda: g13_cifar_unet(8, "g13_cifar_w8", 1301), g13sd=g13_ldm_sd, g16=g16_layer_recon)
+                g17=g17_tdac_imagenet, g7b=g7b_blocks, g13w8=lambda: g13_cifar_unet(8, "g13_cifar_w8", 1301), g13sd=g13_ldm_sd, g16=g16_layer_recon,
+                g8b=g8b_recon_masks, g8c=g8c_recon_caches)
     for k, fn in jobs.items():
         if not only or k in only:
             print("==", k)
