@@ -742,6 +742,191 @@ def g8c_recon_caches():
     _recon_variant("g8c_recon_caches", 1.0, 1.0)
 
 
+class _FakeLDUncond(nn.Module):
+    """Unconditional stand-in of LatentDiffusion (ddpm.py:895-997,1426-1445): schedules + apply_model, nothing else."""
+
+    def __init__(self, net, linear_start=0.0015, linear_end=0.0195):
+        super().__init__()
+
+        class Wrap(nn.Module):
+            def __init__(self, n):
+                super().__init__()
+                self.diffusion_model = n
+
+        self.model = Wrap(net)
+        self.num_timesteps = 1000
+        b = make_beta_schedule("linear", 1000, linear_start=linear_start, linear_end=linear_end)
+        ac = np.cumprod(1.0 - b, axis=0)
+        self.betas = torch.tensor(b, dtype=torch.float32)
+        self.alphas_cumprod = torch.tensor(ac, dtype=torch.float32)
+        self.alphas_cumprod_prev = torch.tensor(np.append(1.0, ac[:-1]), dtype=torch.float32)
+        self.device = torch.device("cpu")
+
+    def apply_model(self, x_, t_, c_):
+        return self.model.diffusion_model(x_, t_, context=c_)
+
+
+def g18_church_driver():
+    """G18: config 3's named path end to end on the Church-shaped fixture network (weights of g13_ldm_church), in the order
+    of sample_diffusion_ldm_church.py:256-311: TDAC_church_calib_data_generator (calibration.py:263-370, start noise and
+    permutation captured) -> set_weight_quantize_params_LDM / set_act_quantize_params_LDM through
+    DDIMSampler.sample(quant_unet=True, cali_data=[x, t, index]) (set_quantize_params_LDM.py:11-103, ddim.py:100-105,221-225)
+    -> Change_LDM_model_attnblock -> the unconditional recon_block_Qmodel walk (recon_block_Qmodel.py:18-94) with the shipped
+    kwargs (input_prob 0.5, quantizer prob 0.5, lr_w 5e-2, lr_a 1e-4, add_loss 1.0: for_church.sh) at 6 iterations per unit,
+    uniforms through tests/golden/_uniforms.py, per-unit trajectories, and the cached tensors of a few representative units."""
+    import _uniforms
+    import scripts.calibration as refcal
+    import qdiff.block_recon as rb_mod
+    import qdiff.layer_recon as rl_mod
+    from qdiff.set_quantize_params_LDM import set_weight_quantize_params_LDM, set_act_quantize_params_LDM
+    rbq = sys.modules['qdiff.recon_block_Qmodel']
+    base = np.load(os.path.join(HERE, "g13_ldm_church.npz"))
+    kw = {k[4:]: (base[k].tolist() if base[k].ndim else base[k].item()) for k in base.files if k.startswith("cfg/")}
+    seed_everything(1818)
+    model = UNetModel(**kw).eval()
+    model.load_state_dict({k[3:]: torch.as_tensor(base[k]) for k in base.files if k.startswith("sd/")})
+    aq = dict(AQ8)                                  # leaf_param True, prob 0.5 (sample_diffusion_ldm_church.py:257)
+    qnn = QuantModel(model, WQ4, aq, sm_abit=8)
+    qnn.eval()
+    qnn.set_first_last_layer_to_8bit()
+    qnn.disable_network_output_quantization()
+    qnn.set_quant_state(False, False)
+    ld = _FakeLDUncond(qnn)
+    N, nb, S = 32, 8, 10
+    args = SimpleNamespace(custom_steps=S, eta=0.0, lamda=1.0)
+    d = {"N": N, "nb": nb, "S": S, "lamda": 1.0}
+    perms, draws = [], []
+    orig_perm, orig_randn = torch.randperm, torch.randn
+    torch.randperm = lambda n, **k: (perms.append(orig_perm(n, **k)) or perms[-1])
+
+    def rec_randn(*a, **k):
+        r = orig_randn(*a, **k)
+        draws.append(r.clone())
+        return r
+
+    torch.randn = rec_randn
+    cwd = os.getcwd()
+    os.chdir("/tmp")
+    try:
+        torch.manual_seed(1818)
+        cali_data = refcal.TDAC_church_calib_data_generator(ld, args, N, nb, "cpu", S)
+    finally:
+        torch.randperm, torch.randn = orig_perm, orig_randn
+        os.chdir(cwd)
+    assert len(draws) == (N // nb) * (S + 1), len(draws)
+    d["tdac/x_T"] = torch.stack([draws[i * (S + 1)] for i in range(N // nb)])
+    d["tdac/perm"] = perms[-1]
+    d["tdac/calib_data"], d["tdac/t"], d["tdac/index"] = cali_data
+    qnn.model.split_shortcut = True
+    set_weight_quantize_params_LDM(ld, cali_data, args)
+    set_act_quantize_params_LDM(ld, cali_data, args, batch_size=16)        # two EMA batches
+    for k, v in qparams_of(qnn).items():
+        d["init/" + k] = v
+    qnn.set_quant_state(True, True)
+    with torch.no_grad():
+        d["init/out_q"] = qnn(cali_data[0][:8], cali_data[1][:8])
+    Change_LDM_model_attnblock(qnn, aq)
+    iters = 6
+    kwargs = dict(cali_data=cali_data[:-1], iters=iters, act_quant=True, asym=True, opt_mode='mse', lr_a=1e-4, lr_w=5e-2,
+                  p=2.0, weight=0.0001, b_range=(20, 2), warmup=0.2, batch_size=16, input_prob=0.5, add_loss=1.0,
+                  recon_w=True, recon_a=True, keep_gpu=False)
+    d["iters"] = np.int64(iters)
+    keep_caches = ("model.input_blocks.0.0", "model.input_blocks.1.0", "model.input_blocks.1.1", "model.input_blocks.2.0",
+                   "model.output_blocks.0.0", "model.output_blocks.1.2", "model.out.2")
+    traj, cur, idx_log, order = {}, {"name": None, "phase": "iter"}, {}, []
+    rep = _uniforms.Replay()
+    checks = []
+    orig_step, orig_sample, orig_rand_like = torch.optim.Adam.step, random.sample, torch.rand_like
+
+    def step(self, *a, **k):
+        r = orig_step(self, *a, **k)
+        ps = [p for gr in self.param_groups for p in gr["params"]]
+        key = "%s/%s" % (cur["name"], "a" if ps[0].numel() == 1 else "w")
+        traj.setdefault(key, []).append(torch.cat([p.detach().flatten() for p in ps]).clone())
+        return r
+
+    def sample(pop, k):
+        r = orig_sample(pop, k)
+        idx_log.setdefault(cur["name"], []).append(list(r))
+        return r
+
+    def rand_like(xx, **k):
+        owner = sys._getframe(1).f_locals.get("self")
+        name = None
+        if owner is not None:
+            for n, m in qnn.named_modules():
+                if m is owner:
+                    name = n
+        if name is None:
+            assert owner is None, type(owner)
+            name = "input_mix:" + cur["name"]
+        c = rep.counts.get((name, cur["phase"]), 0)
+        u = rep.draw(name, cur["phase"], xx.shape)
+        checks.append([float(u.reshape(-1)[0]), float(u.reshape(-1)[-1]), float(u.astype(np.float64).sum())])
+        return torch.from_numpy(u)
+
+    def wrap_save(mod):
+        orig = mod.save_inp_oup_data
+
+        def run(*a, **k):
+            cur["phase"] = "cache"
+            try:
+                res, ci, co = orig(*a, **k)
+            finally:
+                cur["phase"] = "iter"
+            if cur["name"] in keep_caches:
+                key = "cache/%s/" % cur["name"]
+                d[key + "resblock"] = np.int64(res)
+                if res:
+                    d[key + "inp_q"], d[key + "temb_q"] = ci[0][0], ci[0][1]
+                    d[key + "inp_fp"], d[key + "temb_fp"] = ci[1][0], ci[1][1]
+                else:
+                    d[key + "inp_q"], d[key + "inp_fp"] = ci[0], ci[1]
+                d[key + "out_fp"] = co
+            return res, ci, co
+        mod.save_inp_oup_data = run
+        return orig
+
+    ob, ol = rbq.block_reconstruction, rbq.layer_reconstruction
+
+    def wrap_unit(kind, fn):
+        def run(mdl, unit, **k2):
+            names = {m: n for n, m in qnn.named_modules()}
+            cur["name"] = names[unit]
+            order.append("%s:%s:%s" % (kind, names[unit], type(unit).__name__))
+            return fn(mdl, unit, **k2)
+        return run
+
+    torch.optim.Adam.step, random.sample, torch.rand_like = step, sample, rand_like
+    osb, osl = wrap_save(rb_mod), wrap_save(rl_mod)
+    rbq.block_reconstruction, rbq.layer_reconstruction = wrap_unit("block", ob), wrap_unit("layer", ol)
+    try:
+        random.seed(1818)
+        qnn.set_quant_state(True, True)
+        recon_block_Qmodel(args, qnn, cali_data, kwargs).recon()
+    finally:
+        torch.optim.Adam.step, random.sample, torch.rand_like = orig_step, orig_sample, orig_rand_like
+        rb_mod.save_inp_oup_data, rl_mod.save_inp_oup_data = osb, osl
+        rbq.block_reconstruction, rbq.layer_reconstruction = ob, ol
+    d["order"] = np.array(order)
+    for k, v in traj.items():
+        d["traj/" + k] = torch.stack(v)
+    for k, v in idx_log.items():
+        d["idx/" + k] = np.array(v)
+    for k, v in qparams_of(qnn).items():
+        d["final/" + k] = v
+    for name, m in qnn.named_modules():
+        if isinstance(m, AdaRoundQuantizer):
+            d["final/alpha/" + name] = m.alpha
+    d["rand/log"] = np.array(["%s|%s|%d|%s" % (o, p, c, "x".join(map(str, s))) for o, p, c, s in rep.log])
+    d["rand/check"] = np.array(checks, dtype=np.float64).reshape(-1, 3)
+    qnn.set_quant_state(True, True)
+    with torch.no_grad():
+        d["final/out_q"] = qnn(cali_data[0][:8], cali_data[1][:8])
+    d["block_count"] = np.int64(qnn.block_count)
+    save("g18_church_driver", d)
+
+
 def g9_tdac():
     """G9: TDAC scoring / allocation maths on synthetic feature maps (calibration.py:45-92;
     Church `>= 0` fix-up variant :332)."""
@@ -1224,7 +1409,7 @@ if __name__ == "__main__":
                 g6=g6_quant_module, g7=g7_blocks, g8=g8_g12_recon, g9=g9_tdac, g10=g10_steps,
                 g13c=g13_cifar_unet, g13i=lambda: g13_ldm_unet("imagenet"), g13h=lambda: g13_ldm_unet("church"), g14=g14_plms, g15=g15_decoder,
                 g17=g17_tdac_imagenet, g7b=g7b_blocks, g13w8=lambda: g13_cifar_unet(8, "g13_cifar_w8", 1301), g13sd=g13_ldm_sd, g16=g16_layer_recon,
-                g8b=g8b_recon_masks, g8c=g8c_recon_caches)
+                g8b=g8b_recon_masks, g8c=g8c_recon_caches, g18=g18_church_driver)
     for k, fn in jobs.items():
         if not only or k in only:
             print("==", k)
