@@ -4,10 +4,13 @@ ldm/modules/diffusionmodules/openaimodel.py:447-783 (`UNetModel`), with the bloc
 openaimodel.py:74-406 and ldm/modules/attention.py:37-287 it is assembled from, so that
 `qdiff.QuantModel` can rewrite it in place and reference checkpoints load unchanged.
 
-Differences by design: no gradient checkpointing (the reference's custom `checkpoint`,
-util.py:102-148, trades recompute for memory and re-draws dropout-like masks during the
-recompute; a 288 GB MI355X keeps the activations), so `use_checkpoint` / `checkpoint` arguments are
-accepted and ignored.  Quantised sampling does not execute this graph: edadm/engine.py compiles it.
+Gradient checkpointing: the FP blocks below never recompute (a 288 GB MI355X keeps the activations; without
+stochastic masks a recompute is transparent), so their `use_checkpoint` / `checkpoint` arguments only travel to the
+quantised wrappers.  Those (qdiff/quant_block.py) DO honour the flag through `checkpoint` below, because the
+reference's hand-written checkpoint (util.py:102-148) is not transparent during reconstruction: its backward re-runs
+the block, every training-mode activation quantizer draws a NEW prob-mask in that second forward
+(quant_layer.py:271-275), and the per-module loss sees outputs without a graph -- observable behaviour a drop-in has to
+reproduce (fixture G18).  Quantised sampling does not execute this graph: edadm/engine.py compiles it.
 """
 import math
 
@@ -19,8 +22,35 @@ from edadm import train_ops as T     # GroupNorm (+ SiLU), LayerNorm, GEGLU, sof
 
 
 # ----------------------------------------------------------------------------- small helpers
+class _RecomputeInBackward(torch.autograd.Function):
+    """forward: `fn` without a graph; backward: `fn` again WITH a graph (fresh quantizer masks), then the gradients of that
+    second evaluation for the block inputs and the listed parameters."""
+
+    @staticmethod
+    def forward(ctx, fn, n_in, *args):
+        ctx.fn, ctx.n_in, ctx.args = fn, n_in, args
+        with torch.no_grad():
+            return fn(*args[:n_in])
+
+    @staticmethod
+    def backward(ctx, *gout):
+        n_in, args = ctx.n_in, ctx.args
+        ins = [a.detach().requires_grad_(True) if torch.is_tensor(a) and a.is_floating_point() else a for a in args[:n_in]]
+        with torch.enable_grad():
+            out = ctx.fn(*ins)
+        wrt = [a for a in ins if torch.is_tensor(a) and a.requires_grad] + [p for p in args[n_in:] if p.requires_grad]
+        grads = iter(torch.autograd.grad(out, wrt, gout, allow_unused=True))
+        gin = [next(grads) if torch.is_tensor(a) and a.requires_grad else None for a in ins]
+        gpar = [next(grads) if p.requires_grad else None for p in args[n_in:]]
+        ctx.args = None
+        return (None, None) + tuple(gin) + tuple(gpar)
+
+
 def checkpoint(func, inputs, params=None, flag=False):
-    return func(*inputs)
+    """util.py:102-115 of the reference.  Without autograd (sampling, activation caching) or without the flag: a plain call."""
+    if not flag or not torch.is_grad_enabled():
+        return func(*inputs)
+    return _RecomputeInBackward.apply(func, len(inputs), *(tuple(inputs) + tuple(params or ())))
 
 
 def conv_nd(dims, *args, **kwargs):

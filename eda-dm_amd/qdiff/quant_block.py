@@ -11,7 +11,7 @@ import torch.nn as nn
 
 from qdiff.quant_layer import QuantModule, UniformAffineQuantizer, StraightThrough
 from edadm.nets.ldm_unet import (AttentionBlock, ResBlock, TimestepBlock, QKMatMul, SMVMatMul,
-                                 BasicTransformerBlock, resblock_forward, split_heads, merge_heads)
+                                 BasicTransformerBlock, resblock_forward, split_heads, merge_heads, checkpoint)
 from edadm.nets.ddpm_unet import ResnetBlock, AttnBlock, nonlinearity
 from edadm import train_ops as T
 
@@ -58,8 +58,9 @@ class QuantResBlock(BaseQuantBlock, TimestepBlock):
             x, emb = x
         if first:
             self.split = split
-            return resblock_forward(self, x, emb, self.split)
-        return resblock_forward(self, x, emb, 0)
+        sp = self.split if first else 0
+        # quant_block.py:78-84: checkpointed when the config says so (Stable Diffusion: use_checkpoint True)
+        return checkpoint(lambda a, b: resblock_forward(self, a, b, sp), (x, emb), list(self.parameters()), self.use_checkpoint)
 
 
 class QuantQKMatMul(BaseQuantBlock):
@@ -104,6 +105,10 @@ class QuantAttentionBlock(BaseQuantBlock):
         self.norm, self.qkv, self.attention, self.proj_out = attn.norm, attn.qkv, attn.attention, attn.proj_out
 
     def forward(self, x):
+        # quant_block.py:180-182: checkpointed with the flag hard-wired to True (see edadm/nets/ldm_unet.py `checkpoint`)
+        return checkpoint(self._forward, (x,), list(self.parameters()), True)
+
+    def _forward(self, x):
         b, c, *spatial = x.shape
         xf = x.reshape(b, c, -1)
         h = self.proj_out(self.attention(self.qkv(self.norm(xf))))
@@ -158,6 +163,10 @@ class QuantBasicTransformerBlock(BaseQuantBlock):
     def forward(self, x, context=None):
         if context is None and isinstance(x, (tuple, list)):
             x, context = x
+        # quant_block.py:275: checkpointed unless QuantModel.set_grad_ckpt(False) (which all conditional scripts call)
+        return checkpoint(self._forward, (x, context), list(self.parameters()), self.checkpoint)
+
+    def _forward(self, x, context=None):
         x = self.attn1(self.norm1(x)) + x
         x = self.attn2(self.norm2(x), context=context) + x
         return self.ff(self.norm3(x)) + x

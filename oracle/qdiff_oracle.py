@@ -888,22 +888,76 @@ class OSpatialTransformer:
         return self.proj_out(x) + x_in
 
 
+class _Recompute(torch.autograd.Function):
+    """The reference's hand-written gradient checkpoint (ldm/modules/diffusionmodules/util.py:102-148): forward without a
+    graph, backward = a SECOND forward with a graph -- in which every training-mode quantizer draws a new prob-mask
+    (quant_layer.py:271-275) -- and the gradients of that second evaluation."""
+
+    @staticmethod
+    def forward(ctx, fn, n_in, *args):
+        ctx.fn, ctx.n_in, ctx.args = fn, n_in, args
+        with torch.no_grad():
+            return fn(*args[:n_in])
+
+    @staticmethod
+    def backward(ctx, *gout):
+        ins = [a.detach().requires_grad_(True) for a in ctx.args[:ctx.n_in]]
+        with torch.enable_grad():
+            out = ctx.fn(*ins)
+        grads = torch.autograd.grad(out, ins + list(ctx.args[ctx.n_in:]), gout, allow_unused=True)
+        return (None, None) + tuple(grads)
+
+
 class OLegacyAttention:
     """AttentionBlock + QKVAttentionLegacy with QuantQKMatMul/QuantSMVMatMul swapped in
     (openaimodel.py:281-406; quant_block.py:119-162; get_specials quant_act=True)."""
 
     def __init__(self, B, sdp, name, heads):
         self.heads = heads
+        self.name = name
         self.norm = B.norm(sdp + ".norm", 1e-5)
         self.qkv = B.layer(sdp + ".qkv", name + ".qkv", "conv1d")
         self.qk = OQKMatMul(B, name + ".attention.qkv_matmul")
         self.smv = OSMVMatMul(B, name + ".attention.smv_matmul")
         self.proj_out = B.layer(sdp + ".proj_out", name + ".proj_out", "conv1d")
+        # Change_LDM_model_attnblock (recon_block_Qmodel.py:11-16) wraps the whole AttentionBlock into ONE
+        # QuantAttentionBlock (quant_block.py:165-201) after scale initialisation: the walk then reconstructs it as a block
+        # whose trainables are q, k, v, w of the two matmul wrappers, then qkv / proj_out (block_recon.py:66-79)
+        self.merged = False
+        self.split = 0
 
     def units(self):
+        if self.merged:
+            return [("block", self)]
         return [("layer", self.qkv), ("block", self.qk), ("block", self.smv), ("layer", self.proj_out)]
 
+    def layers(self):
+        return [self.qkv, self.proj_out]
+
+    def extra_quantizers(self):
+        return self.qk.extra_quantizers() + self.smv.extra_quantizers()
+
+    def set_quant_state(self, w, a):
+        for u in (self.qkv, self.qk, self.smv, self.proj_out):
+            u.set_quant_state(w, a)
+
+    def trainables(self):
+        out = []
+        for l in self.layers():
+            for q in l.quantizers():
+                out += [t for t in (getattr(q, "alpha", None), q.delta) if torch.is_tensor(t) and t.requires_grad]
+        for q in self.extra_quantizers():
+            if torch.is_tensor(q.delta) and q.delta.requires_grad:
+                out.append(q.delta)
+        return out
+
     def __call__(self, x, context=None):
+        # QuantAttentionBlock.forward is checkpointed with the flag hard-wired to True (quant_block.py:180-182)
+        if self.merged and torch.is_grad_enabled():
+            return _Recompute.apply(self._forward, 1, x, *self.trainables())
+        return self._forward(x)
+
+    def _forward(self, x, context=None):
         b, c, hh, ww = x.shape
         xf = x.reshape(b, c, -1)
         qkv = self.qkv(self.norm(xf))
@@ -914,6 +968,17 @@ class OLegacyAttention:
         weight = torch.softmax(self.qk(q, k).float(), dim=-1)
         a = self.smv(weight, v).reshape(bs, -1, length)
         return (xf + self.proj_out(a)).reshape(b, c, hh, ww)
+
+
+def change_ldm_model_attnblock(net):
+    """Change_LDM_model_attnblock (recon_block_Qmodel.py:11-16) on an OUNet."""
+    n = 0
+    for mods in net.input_blocks + [net.middle] + net.output_blocks:
+        for m in mods:
+            if isinstance(m, OLegacyAttention):
+                m.merged = True
+                n += 1
+    return n
 
 
 def ldm_timestep_embedding(t, dim, max_period=10000):

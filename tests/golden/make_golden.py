@@ -792,7 +792,7 @@ def g18_church_driver():
     qnn.disable_network_output_quantization()
     qnn.set_quant_state(False, False)
     ld = _FakeLDUncond(qnn)
-    N, nb, S = 32, 8, 10
+    N, nb, S = 32, 8, 20            # 20 steps: neighbouring early steps fall inside the density radius 0.3, later ones outside
     args = SimpleNamespace(custom_steps=S, eta=0.0, lamda=1.0)
     d = {"N": N, "nb": nb, "S": S, "lamda": 1.0}
     perms, draws = [], []
@@ -831,7 +831,7 @@ def g18_church_driver():
                   p=2.0, weight=0.0001, b_range=(20, 2), warmup=0.2, batch_size=16, input_prob=0.5, add_loss=1.0,
                   recon_w=True, recon_a=True, keep_gpu=False)
     d["iters"] = np.int64(iters)
-    keep_caches = ("model.input_blocks.0.0", "model.input_blocks.1.0", "model.input_blocks.1.1", "model.input_blocks.2.0",
+    keep_caches = ("model.time_embed.0", "model.time_embed.2", "model.input_blocks.0.0", "model.input_blocks.1.0", "model.input_blocks.1.1", "model.input_blocks.2.0",
                    "model.output_blocks.0.0", "model.output_blocks.1.2", "model.out.2")
     traj, cur, idx_log, order = {}, {"name": None, "phase": "iter"}, {}, []
     rep = _uniforms.Replay()
@@ -910,7 +910,9 @@ def g18_church_driver():
         rbq.block_reconstruction, rbq.layer_reconstruction = ob, ol
     d["order"] = np.array(order)
     for k, v in traj.items():
-        d["traj/" + k] = torch.stack(v)
+        # 834 k alphas: the first Adam step of every unit (the sign pattern of the first gradient) + the final state below;
+        # the few step sizes at every iteration
+        d["traj/" + k] = torch.stack(v) if k.endswith("/a") else v[0]
     for k, v in idx_log.items():
         d["idx/" + k] = np.array(v)
     for k, v in qparams_of(qnn).items():

@@ -14,6 +14,7 @@ import sys
 import numpy as np
 import pytest
 import torch
+from types import SimpleNamespace
 
 from helpers import build_toynet, WQ4, AQ8
 
@@ -162,3 +163,201 @@ def test_recon_iteration_gradients_teacher_forced(fixture, unit):
     dirty = sorted({k for k, key, err, med in res if err > 5e-5})
     print(fixture, unit, [(k, key, "%.2e" % err) for k, key, err, med in res], "iterations with a flip:", dirty)
     assert len(dirty) <= 2 and all(err < 5e-2 for _, _, err, _ in res), res
+
+
+def _church_ld(golden):
+    from edadm.latent import LatentDiffusionLite
+    from qdiff import QuantModel
+    from helpers import build_ldm
+    base = golden("g13_ldm_church")
+    qnn = QuantModel(build_ldm(base), WQ4, AQ8, sm_abit=8).cuda().eval()      # leaf_param True, prob 0.5: the shipped dicts
+    qnn.set_first_last_layer_to_8bit()
+    qnn.disable_network_output_quantization()
+    qnn.set_quant_state(False, False)
+    ld = LatentDiffusionLite(qnn, timesteps=1000, linear_start=0.0015, linear_end=0.0195, conditioning_key=None).cuda()
+    return qnn, ld
+
+
+def test_church_config3_tdac_and_ldm_scale_init_driver(golden):
+    """Config 3's named path, first half (sample_diffusion_ldm_church.py:271-283): TDAC_church_calib_data_generator
+    (calibration.py:263-370, the `>= 0` fix-up variant; the reference's start noise and permutation injected) VALUES, then
+    set_weight_quantize_params_LDM / set_act_quantize_params_LDM (set_quantize_params_LDM.py:11-103) driven through
+    DDIMSampler.sample(quant_unet=True, cali_data=[x, t, index]) on the reference's calibration tuple: weight step sizes
+    and zero points bit-exact, activation step sizes within the flat-minimum grid tolerance, quantised output."""
+    from scripts.calibration import TDAC_church_calib_data_generator
+    from qdiff import set_weight_quantize_params_LDM, set_act_quantize_params_LDM
+    from qdiff.quant_layer import UniformAffineQuantizer
+    g = golden("g18_church_driver")
+    qnn, ld = _church_ld(golden)
+    N, nb, S = int(g["N"]), int(g["nb"]), int(g["S"])
+    args = SimpleNamespace(custom_steps=S, eta=0.0, lamda=float(g["lamda"]))
+    xT = iter(torch.as_tensor(g["tdac/x_T"]))
+    orig_randn, orig_perm = torch.randn, torch.randperm
+    torch.randn = lambda *a, **k: next(xT).cuda()
+    torch.randperm = lambda n, **k: torch.as_tensor(g["tdac/perm"])
+    try:
+        calib, t, index = TDAC_church_calib_data_generator(ld, args, N, nb, torch.device("cuda"), S)
+    finally:
+        torch.randn, torch.randperm = orig_randn, orig_perm
+    np.testing.assert_array_equal(t.cpu().numpy(), g["tdac/t"])
+    np.testing.assert_array_equal(index.cpu().numpy(), g["tdac/index"])
+    err = np.abs(calib.cpu().numpy() - g["tdac/calib_data"]).max() / np.abs(g["tdac/calib_data"]).max()
+    print("TDAC church calibration latents vs the reference generator: max %.2e of range" % err)
+    assert err <= 1e-4
+    # the drivers on the REFERENCE's tuple (so that the scales are compared on identical inputs)
+    cali = (_cuda(g["tdac/calib_data"]), _cuda(g["tdac/t"]), _cuda(g["tdac/index"]))
+    qnn.model.split_shortcut = True
+    set_weight_quantize_params_LDM(ld, cali, args)
+    set_act_quantize_params_LDM(ld, cali, args, batch_size=16)
+    n, worst = 0, 0.0
+    for name, m in qnn.named_modules():
+        if isinstance(m, UniformAffineQuantizer) and m.delta is not None:
+            k = "init/qp/" + name
+            assert k + "/delta" in g.files, k
+            ref_d, ref_z = g[k + "/delta"].reshape(-1), g[k + "/zero_point"].reshape(-1)
+            got_d, got_z = m.delta.detach().cpu().numpy().reshape(-1), m.zero_point.cpu().numpy().reshape(-1)
+            assert m.n_bits == int(g[k + "/n_bits"]) and m.inited, k
+            if m.leaf_param:
+                worst = max(worst, float(np.abs(got_d / ref_d - 1).max()))
+                np.testing.assert_allclose(got_d, ref_d, rtol=0.1)
+                assert np.abs(got_z - ref_z).max() <= 1, k
+            else:
+                np.testing.assert_array_equal(got_d, ref_d)
+                np.testing.assert_array_equal(got_z, ref_z)
+            n += 1
+    assert n == len([k for k in g.files if k.startswith("init/qp/") and k.endswith("/delta")])
+    print("activation step sizes vs reference: worst %.3f" % worst)
+    qnn.set_quant_state(True, True)
+    with torch.no_grad():
+        out = qnn(cali[0][:8], cali[1][:8]).cpu().numpy()
+    err = np.abs(out - g["init/out_q"]) / np.abs(g["init/out_q"]).max()
+    # the first difference in an operand is a +-1 code (census test of round 2); a random 4-bit network spreads it
+    assert err.max() < 0.15 and err.mean() < 0.02, (err.max(), err.mean())
+
+
+def test_church_config3_unconditional_walk_with_shipped_masks(golden):
+    """Config 3's named path, second half (sample_diffusion_ldm_church.py:285-311): Change_LDM_model_attnblock + the
+    unconditional recon_block_Qmodel walk with the shipped kwargs (input_prob 0.5, quantizer prob 0.5), started from the
+    reference's scales, its uniforms replayed.  Units whose cached tensors the fixture holds run on those and must take the
+    reference's first Adam step and end with its hard rounding; the others run on the product's own caches (loose bound).
+    Includes the reference's checkpoint behaviour of QuantAttentionBlock (backward on re-drawn masks, no gradient from the
+    per-module loss: quant_block.py:180-182, util.py:117-148)."""
+    from qdiff import Change_LDM_model_attnblock, recon_block_Qmodel
+    from qdiff.adaptive_rounding import AdaRoundQuantizer
+    from qdiff.quant_layer import UniformAffineQuantizer
+    from qdiff.quant_block import QuantAttentionBlock
+    from edadm.state import load_quant_state
+    import edadm.recon as recon
+    import qdiff.data_utils as du
+    g = golden("g18_church_driver")
+    qnn, ld = _church_ld(golden)
+    cali = (_cuda(g["tdac/calib_data"]), _cuda(g["tdac/t"]), _cuda(g["tdac/index"]))
+    qnn.model.split_shortcut = True
+    with torch.no_grad():
+        qnn(cali[0][:2], cali[1][:2])                    # creates the split quantizers of the skip convolutions
+    n = load_quant_state(qnn, {k: g[k] for k in g.files if k.startswith("init/qp/")}, prefix="init/qp/")
+    assert n == len([k for k in g.files if k.startswith("init/qp/") and k.endswith("/delta")])
+    Change_LDM_model_attnblock(qnn, dict(AQ8))
+    assert sum(isinstance(m, QuantAttentionBlock) for m in qnn.modules()) == 7
+    iters = int(g["iters"])
+    kwargs = dict(cali_data=cali[:-1], iters=iters, act_quant=True, asym=True, opt_mode='mse', lr_a=1e-4, lr_w=5e-2, p=2.0,
+                  weight=0.0001, b_range=(20, 2), warmup=0.2, batch_size=16, input_prob=0.5, add_loss=1.0, recon_w=True,
+                  recon_a=True, keep_gpu=False)
+    rep = _uniforms.Replay()
+    cur = {"name": None, "phase": "iter"}
+    names = {m: nme for nme, m in qnn.named_modules()}
+    for name, m in qnn.named_modules():
+        if isinstance(m, UniformAffineQuantizer) and m.leaf_param:
+            m.injected_uniform = (lambda nm: lambda xx: torch.from_numpy(rep.draw(nm, cur["phase"], xx.shape)).to(xx.device))(name)
+    recon.INJECT_MIX_UNIFORM = lambda xx: torch.from_numpy(rep.draw("input_mix:" + cur["name"], "iter", xx.shape)).to(xx.device)
+    order, traj, idx_log = [], {}, {}
+    import qdiff.block_recon as brm
+    import qdiff.layer_recon as lrm
+    orig_save, orig_launch, orig_sample, orig_rec = du.save_inp_oup_data, recon.FusedAdam.launch, random.sample, recon.reconstruct
+
+    def save_fn(model, unit, cali_data, asym, act_quant, batch_size=32, input_prob=True, keep_gpu=True):
+        k = "cache/%s/" % cur["name"]
+        if k + "out_fp" in g.files:
+            if bool(g[k + "resblock"]):
+                return True, ([_cuda(g[k + "inp_q"]), _cuda(g[k + "temb_q"])], [_cuda(g[k + "inp_fp"]), _cuda(g[k + "temb_fp"])]), \
+                    _cuda(g[k + "out_fp"])
+            return False, (_cuda(g[k + "inp_q"]), _cuda(g[k + "inp_fp"])), _cuda(g[k + "out_fp"])
+        cur["phase"] = "cache"
+        try:
+            return orig_save(model, unit, cali_data, asym, act_quant, batch_size=batch_size, input_prob=input_prob, keep_gpu=keep_gpu)
+        finally:
+            cur["phase"] = "iter"
+
+    def rec(model, unit, cali_data, **kw):
+        cur["name"] = names[unit]
+        order.append("%s:%s:%s" % ("block" if kw["is_block"] else "layer", names[unit], type(unit).__name__))
+        return orig_rec(model, unit, cali_data, **kw)
+
+    def launch(self):
+        orig_launch(self)
+        key = "%s/%s" % (cur["name"], "a" if self.params[0].numel() == 1 else "w")
+        traj.setdefault(key, []).append(self.flat.detach().cpu().clone())
+
+    def sample(pop, k):
+        r = orig_sample(pop, k)
+        idx_log.setdefault(cur["name"], []).append(list(r))
+        return r
+
+    du.save_inp_oup_data, recon.FusedAdam.launch, random.sample = save_fn, launch, sample
+    brm.reconstruct = lrm.reconstruct = rec
+    try:
+        random.seed(1818)
+        qnn.set_quant_state(True, True)
+        recon_block_Qmodel(SimpleNamespace(), qnn, cali, kwargs).recon()
+    finally:
+        du.save_inp_oup_data, recon.FusedAdam.launch, random.sample = orig_save, orig_launch, orig_sample
+        brm.reconstruct = lrm.reconstruct = orig_rec
+        recon.INJECT_MIX_UNIFORM = None
+    assert order == list(g["order"])
+    for k in idx_log:
+        assert np.array_equal(np.asarray(idx_log[k]), g["idx/" + k]), k
+    ref_log = sorted(l for l in g["rand/log"] if "|iter|" in l)
+    got_log = sorted("%s|%s|%d|%s" % (o, p, c, "x".join(map(str, s))) for o, p, c, s in rep.log if p == "iter")
+    assert got_log == ref_log
+    cached_units = sorted({k.split("/")[1] for k in g.files if k.startswith("cache/")}, key=len, reverse=True)
+    for u in [o.split(":")[1] for o in order]:
+        cached = u in cached_units
+        d0 = np.abs(traj[u + "/w"][0].numpy() - g["traj/%s/w" % u])
+        ra, ra0 = 0.0, 0.0
+        if "traj/%s/a" % u in g.files:
+            ref_a = g["traj/%s/a" % u]
+            da = np.abs(torch.stack(traj[u + "/a"]).numpy() - ref_a) / 1e-4            # in Adam steps of lr_a
+            ra, ra0 = float(da.max()), float(da[0].max())
+        print(u, "reference caches" if cached else "own caches", "first step: frac>1e-2 %.5f max %.3g | step sizes: first step off "
+              "by %.3g lr_a, worst over %d steps %.3g lr_a" % ((d0 > 1e-2).mean(), d0.max(), ra0, iters, ra))
+        if cached:
+            # +-lr_w by the sign of the first gradient: the reference's step except where that gradient is rounding noise
+            # step sizes: the first Adam step identical; later ones may part where lr_a is a fifth of the step size itself (the
+            # softmax-probability quantizer of the 64-key attention: delta 4e-4, lr_a 1e-4 -- every step moves a fifth of the
+            # codes) -- bounded by one step of lr_a over the unit
+            assert (d0 > 1e-2).mean() < 2e-3 and ra0 < 2e-2 and ra < 1.0, (u, (d0 > 1e-2).mean(), ra0, ra)
+        else:
+            assert (d0 > 1e-2).mean() < 0.2, (u, (d0 > 1e-2).mean())
+    agree, total, bad = 0, 0, []
+    for name, m in qnn.named_modules():
+        if isinstance(m, AdaRoundQuantizer):
+            ref_alpha = g["final/alpha/" + name]
+            got = m.alpha.detach().cpu().numpy()
+            dis = (got >= 0) != (ref_alpha >= 0)
+            agree += int((~dis).sum())
+            total += got.size
+            if any(name.startswith(u + ".") for u in cached_units):
+                bad += [(name, float(r), float(o)) for r, o in zip(ref_alpha[dis], got[dis])]
+    print("final hard rounding: %d of %d agree (%.4f %%); on the reference's caches: %d disagreements %s" % (
+        agree, total, 100.0 * agree / total, len(bad), bad[:8]))
+    assert total == sum(g[k].size for k in g.files if k.startswith("final/alpha/"))
+    assert agree / total > 0.99
+    assert all(abs(r) < 1e-2 and abs(o) < 1e-2 for _, r, o in bad) and len(bad) <= 60, bad
+    assert qnn.block_count == int(g["block_count"])
+    qnn.set_quant_state(True, True)
+    with torch.no_grad():
+        out = qnn(cali[0][:8], cali[1][:8]).cpu().numpy()
+    ref = g["final/out_q"]
+    err = np.abs(out - ref) / np.abs(ref).max()
+    print("final quantised output vs reference: max %.3f mean %.4f of range" % (err.max(), err.mean()))
+    assert err.max() < 0.25 and err.mean() < 0.04
