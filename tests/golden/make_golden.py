@@ -929,6 +929,104 @@ def g18_church_driver():
     save("g18_church_driver", d)
 
 
+def g19_tdac_others():
+    """G19: the other TDAC generators end to end, values (calibration.py:12-155 cifar, :156-262 bedroom with the `> 0` fix-up,
+    :502-638 coco through the PLMSSampler with classifier-free guidance), each on the matching fixture network with the
+    start noise of every trajectory batch and the final permutation captured.  (Church: G18; ImageNet: G17.)"""
+    import scripts.calibration as refcal
+    from _weights import formula_state_dict
+    d = {}
+
+    def capture(fn):
+        perms, draws = [], []
+        orig_perm, orig_randn = torch.randperm, torch.randn
+        torch.randperm = lambda n, **k: (perms.append(orig_perm(n, **k)) or perms[-1])
+
+        def rec_randn(*a, **k):
+            r = orig_randn(*a, **k)
+            draws.append(r.clone())
+            return r
+
+        torch.randn = rec_randn
+        cwd = os.getcwd()
+        os.chdir("/tmp")
+        try:
+            out = fn()
+        finally:
+            torch.randperm, torch.randn = orig_perm, orig_randn
+            os.chdir(cwd)
+        return out, perms, draws
+
+    # ---- cifar (DDPM Model, cali_generalized_steps; ONE trajectory batch serves every calibration batch: :100-118)
+    base = np.load(os.path.join(HERE, "g13_cifar_unet.npz"))
+    seed_everything(1919)
+    cfg = cifar_cfg()
+    model = DDPMModel(cfg).eval()
+    model.load_state_dict({k[3:]: torch.as_tensor(base[k]) for k in base.files if k.startswith("sd/")})
+    qnn = QuantModel(model, WQ4, dict(AQ8), sm_abit=8)
+    qnn.eval()
+    qnn.set_quant_state(False, False)
+    S = 20
+    seq = [int(v) for v in (np.linspace(0, np.sqrt(1000 * 0.8), S) ** 2)]          # the 'quad' skip of sample_diffusion_ddim.py:125-133
+    betas = torch.linspace(1e-4, 2e-2, 1000)
+    diffusion = SimpleNamespace(seq=seq, betas=betas, args=SimpleNamespace(eta=0.0))
+    N, nb = 32, 16
+    torch.manual_seed(1919)
+    out, perms, draws = capture(lambda: refcal.TDAC_cifar_calib_data_generator(qnn.model, cfg, 1.2, N, nb, "cpu", diffusion, True))
+    d["cifar/N"], d["cifar/nb"], d["cifar/lamda"], d["cifar/seq"] = N, nb, 1.2, np.array(seq)
+    d["cifar/x_T"], d["cifar/perm"] = draws[0], perms[-1]
+    d["cifar/calib_data"], d["cifar/t"], d["cifar/cls"] = out
+
+    # ---- bedroom (unconditional LDM, `> 0` fix-up)
+    baseh = np.load(os.path.join(HERE, "g13_ldm_church.npz"))
+    kw = {k[4:]: (baseh[k].tolist() if baseh[k].ndim else baseh[k].item()) for k in baseh.files if k.startswith("cfg/")}
+    net = UNetModel(**kw).eval()
+    net.load_state_dict({k[3:]: torch.as_tensor(baseh[k]) for k in baseh.files if k.startswith("sd/")})
+    qnn = QuantModel(net, WQ4, dict(AQ8), sm_abit=8)
+    qnn.eval()
+    qnn.set_quant_state(False, False)
+    ld = _FakeLDUncond(qnn)
+    N, nb, S = 32, 8, 20
+    args = SimpleNamespace(custom_steps=S, eta=0.0, lamda=1.0)
+    torch.manual_seed(1920)
+    out, perms, draws = capture(lambda: refcal.TDAC_bedroom_calib_data_generator(ld, args, N, nb, "cpu", S))
+    assert len(draws) == (N // nb) * (S + 1), len(draws)
+    d["bedroom/N"], d["bedroom/nb"], d["bedroom/S"], d["bedroom/lamda"] = N, nb, S, 1.0
+    d["bedroom/x_T"] = torch.stack([draws[i * (S + 1)] for i in range(N // nb)])
+    d["bedroom/perm"] = perms[-1]
+    d["bedroom/calib_data"], d["bedroom/t"], d["bedroom/index"] = out
+
+    # ---- coco (Stable-Diffusion-shaped UNet, PLMS + classifier-free guidance)
+    seed_everything(1921)
+    g = torch.Generator().manual_seed(1921)
+    net = UNetModel(**SD_KW).eval()
+    sd = formula_state_dict([(k, v.shape) for k, v in net.state_dict().items()], 1305)
+    net.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    qnn = QuantModel(net, WQ4, dict(AQ8), sm_abit=8, act_quant_mode="qdiff")
+    qnn.eval()
+    qnn.set_quant_state(False, False)
+    qnn.set_grad_ckpt(False)
+    N, nb, S = 8, 2, 30            # 30 PLMS steps: some neighbouring steps inside the density radius 0.3, most outside
+    table = {"": torch.randn(77, 24, generator=g)}
+    prompts = ["p%d" % i for i in range(N)]
+    for p_ in prompts:
+        table[p_] = torch.randn(77, 24, generator=g)
+    ld = _FakeLDUncond(qnn, linear_start=0.00085, linear_end=0.012)
+    ld.get_learned_conditioning = lambda ps: torch.stack([table[p_] for p_ in ps])       # CLIP stand-in: a lookup
+    args = SimpleNamespace(custom_steps=S, scale=7.5, ddim_eta=0.0, plms=True, C=4, H=64, W=64, f=8, list_prompts=prompts, lamda=5.0)
+    torch.manual_seed(1921)
+    out, perms, draws = capture(lambda: refcal.TDAC_coco_calib_data_generator(ld, args, N, nb, "cpu", S))
+    d["coco/N"], d["coco/nb"], d["coco/S"], d["coco/lamda"], d["coco/scale"] = N, nb, S, 5.0, 7.5
+    d["coco/table"] = torch.stack([table[""]] + [table[p_] for p_ in prompts])
+    d["coco/n_draws"] = len(draws)
+    per = len(draws) // (N // nb)
+    d["coco/x_T"] = torch.stack([draws[i * per] for i in range(N // nb)])
+    d["coco/perm"] = perms[-1]
+    for k, v in zip(("calib_data", "t", "index", "cond", "uncond", "t_next"), out):
+        d["coco/" + k] = v
+    save("g19_tdac_others", d)
+
+
 def g9_tdac():
     """G9: TDAC scoring / allocation maths on synthetic feature maps (calibration.py:45-92;
     Church `>= 0` fix-up variant :332)."""
@@ -1411,7 +1509,7 @@ if __name__ == "__main__":
                 g6=g6_quant_module, g7=g7_blocks, g8=g8_g12_recon, g9=g9_tdac, g10=g10_steps,
                 g13c=g13_cifar_unet, g13i=lambda: g13_ldm_unet("imagenet"), g13h=lambda: g13_ldm_unet("church"), g14=g14_plms, g15=g15_decoder,
                 g17=g17_tdac_imagenet, g7b=g7b_blocks, g13w8=lambda: g13_cifar_unet(8, "g13_cifar_w8", 1301), g13sd=g13_ldm_sd, g16=g16_layer_recon,
-                g8b=g8b_recon_masks, g8c=g8c_recon_caches, g18=g18_church_driver)
+                g8b=g8b_recon_masks, g8c=g8c_recon_caches, g18=g18_church_driver, g19=g19_tdac_others)
     for k, fn in jobs.items():
         if not only or k in only:
             print("==", k)

@@ -361,3 +361,71 @@ def test_church_config3_unconditional_walk_with_shipped_masks(golden):
     err = np.abs(out - ref) / np.abs(ref).max()
     print("final quantised output vs reference: max %.3f mean %.4f of range" % (err.max(), err.mean()))
     assert err.max() < 0.25 and err.mean() < 0.04
+
+
+@pytest.mark.parametrize("which", ["cifar", "bedroom", "coco"])
+def test_tdac_generator_values_other_configs(golden, which):
+    """VALUES of the remaining TDAC generators against the reference's own runs (fixture G19; Church is in G18, ImageNet in G17):
+    TDAC_cifar_calib_data_generator (calibration.py:12-155: one trajectory batch serves every calibration batch),
+    TDAC_bedroom_… (:156-262, `> 0` fix-up), TDAC_coco_… (:502-638: PLMS + classifier-free guidance, t_next).  Start noise and
+    permutation injected; timesteps / indices exact, latents to trajectory accuracy."""
+    import scripts.calibration as cal
+    from edadm.latent import LatentDiffusionLite
+    from qdiff import QuantModel
+    from helpers import build_cifar, build_ldm, build_ldm_formula
+    g = golden("g19_tdac_others")
+    P = which + "/"
+    N, nb = int(g[P + "N"]), int(g[P + "nb"])
+    dev = torch.device("cuda")
+    if which == "cifar":
+        base = golden("g13_cifar_unet")
+        qnn = QuantModel(build_cifar(base), WQ4, dict(AQ8), sm_abit=8).cuda().eval()
+        qnn.set_quant_state(False, False)
+        diffusion = SimpleNamespace(seq=[int(v) for v in g[P + "seq"]], betas=torch.linspace(1e-4, 2e-2, 1000).cuda(),
+                                    args=SimpleNamespace(eta=0.0))
+        draws = iter([torch.as_tensor(g[P + "x_T"])])
+        run = lambda: cal.TDAC_cifar_calib_data_generator(qnn.model, qnn.model.config, float(g[P + "lamda"]), N, nb, dev, diffusion, True)
+    elif which == "bedroom":
+        base = golden("g13_ldm_church")
+        qnn = QuantModel(build_ldm(base), WQ4, dict(AQ8), sm_abit=8).cuda().eval()
+        qnn.set_quant_state(False, False)
+        ld = LatentDiffusionLite(qnn, timesteps=1000, linear_start=0.0015, linear_end=0.0195, conditioning_key=None).cuda()
+        S = int(g[P + "S"])
+        args = SimpleNamespace(custom_steps=S, eta=0.0, lamda=float(g[P + "lamda"]))
+        draws = iter(torch.as_tensor(g[P + "x_T"]))
+        run = lambda: cal.TDAC_bedroom_calib_data_generator(ld, args, N, nb, dev, S)
+    else:
+        base = golden("g13_ldm_sd")
+        qnn = QuantModel(build_ldm_formula(base), WQ4, dict(AQ8), sm_abit=8).cuda().eval()
+        qnn.set_quant_state(False, False)
+        qnn.set_grad_ckpt(False)
+        ld = LatentDiffusionLite(qnn, timesteps=1000, linear_start=0.00085, linear_end=0.012, conditioning_key="crossattn").cuda()
+        table = _cuda(g[P + "table"])
+        prompts = ["p%d" % i for i in range(N)]
+        look = {"": table[0], **{p: table[i + 1] for i, p in enumerate(prompts)}}
+        ld.get_learned_conditioning = lambda ps: torch.stack([look[p] for p in ps])
+        S = int(g[P + "S"])
+        args = SimpleNamespace(custom_steps=S, scale=float(g[P + "scale"]), ddim_eta=0.0, plms=True, C=4, H=64, W=64, f=8,
+                               list_prompts=prompts, lamda=float(g[P + "lamda"]))
+        draws = iter(torch.as_tensor(g[P + "x_T"]))
+        run = lambda: cal.TDAC_coco_calib_data_generator(ld, args, N, nb, dev, S)
+    orig_randn, orig_perm = torch.randn, torch.randperm
+    torch.randn = lambda *a, **k: next(draws).cuda()
+    torch.randperm = lambda n, **k: torch.as_tensor(g[P + "perm"])
+    try:
+        out = run()
+    finally:
+        torch.randn, torch.randperm = orig_randn, orig_perm
+    names = {"cifar": ("calib_data", "t", "cls"), "bedroom": ("calib_data", "t", "index"),
+             "coco": ("calib_data", "t", "index", "cond", "uncond", "t_next")}[which]
+    assert len(out) == len(names)
+    for nme, got in zip(names, out):
+        ref = g[P + nme]
+        got = got.detach().cpu().numpy()
+        assert got.shape == ref.shape, (nme, got.shape, ref.shape)
+        if ref.dtype.kind in "iu":
+            np.testing.assert_array_equal(got, ref, err_msg=nme)
+        else:
+            err = np.abs(got - ref).max() / np.abs(ref).max()
+            print(which, nme, "vs the reference generator: max %.2e of range" % err)
+            assert err <= 1e-4, (nme, err)
