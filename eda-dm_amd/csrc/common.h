@@ -5,6 +5,7 @@
 
 #define EDADM_EINVAL (-22)
 #define EDADM_EIO (-5)
+#define EDADM_MAX_DEVICES 64
 
 static inline int edadm_launch_status() { return hipGetLastError() == hipSuccess ? 0 : EDADM_EIO; }
 

@@ -18,6 +18,7 @@
 #ifndef EDADM_GEMM_DT
 #error "compile with -DEDADM_GEMM_DT=0|1|2|3"
 #endif
+#include <atomic>
 #include <type_traits>
 #include "../../include/edadm.h"
 #include <hip/hip_fp16.h>
@@ -338,12 +339,11 @@ __device__ __forceinline__ void epilogue_direct_body(typename Acc<DT>::type (&ac
                                                      float* gacc, float* __restrict__ gn_ws, int64_t N) {
     const int fr = lane & 31, fh4 = (lane >> 5) * 4;
     constexpr int NG = TM * 4;                             // row groups: 4 rows x TN columns per lane each
-    // GroupNorm partials of this output for the layer that normalises it next (K5 pass 1 folded into the producer):
-    // per row group the four values of a column are summed in registers and added to the wave's own LDS slots
-    // (sum, sum of squares per column) -- no accumulator lives across the store loop (the kernel is at its
-    // register limit), the LDS pipe is idle during this epilogue.
-    // GNREG (kernels with registers to spare, k_conv3_direct): the per-column sums of the wave's TM x 32 rows stay in
-    // 2 TN registers across the store loop, the two lanes that share a column add up at the end: no LDS, no atomics
+    // GroupNorm partials of this output for the layer that normalises it next (K5 pass 1 folded into the producer), GNREG
+    // only (kernels with registers to spare, k_conv3_direct): the per-column sums of the wave's TM x 32 rows stay in
+    // 2 TN registers across the store loop, the two lanes that share a column add up at the end: no LDS, no atomics.
+    // (The implicit-GEMM kernels are at their register limit; an LDS-atomic variant for them measured slower than the
+    // statistics pass it saved -- 58.4 vs 61.7 images/s in round 1 -- and was removed in round 3.)
     // The GNREG partials are per 64-row slab whatever the tile height, summed in ONE fixed order -- each 32-row half over its
     // four row groups, its two lane halves, then half 0 + half 1 -- so that the statistics do not depend on whether a wave
     // owns the whole slab (TM = 2) or two waves share it (TM = 1, the odd one hands its half over through `gacc`, 2 x 32 TN
@@ -353,10 +353,6 @@ __device__ __forceinline__ void epilogue_direct_body(typename Acc<DT>::type (&ac
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) gs[i][j] = gq[i][j] = 0.f;
-    if (!GNREG && gn_ws && lane < 32) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) *reinterpret_cast<float2*>(gacc + (j * 32 + fr) * 2) = make_float2(0.f, 0.f);
-    }
     constexpr int DEPTH = 2;
     const uint32_t ooff = (uint32_t)(fh4 * (int)ldo + fr) * 4u;
     const uint32_t roff = (uint32_t)(fh4 * (int)ldr + fr) * 4u;
@@ -410,21 +406,12 @@ __device__ __forceinline__ void epilogue_direct_body(typename Acc<DT>::type (&ac
                     ps[j] += v;
                     pq[j] += v * v;
                     asm volatile("" : "+v"(ps[j]), "+v"(pq[j]));
-                } else {
-                    ps[j] += v;
-                    pq[j] += v * v;
                 }
             }
         }
         if constexpr (GNREG) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) { gs[i][j] += ps[j]; gq[i][j] += pq[j]; }
-        } else if (gn_ws) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                atomicAdd(gacc + (j * 32 + fr) * 2, ps[j]);
-                atomicAdd(gacc + (j * 32 + fr) * 2 + 1, pq[j]);
-            }
         }
         asm volatile("" ::: "memory");
     }
@@ -460,17 +447,6 @@ __device__ __forceinline__ void epilogue_direct_body(typename Acc<DT>::type (&ac
                     }
                 }
             }
-        }
-        return;
-    }
-    if (gn_ws) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane < 32) {
-            const int64_t slab = row0 / (TM * 32);         // = b * (hw / 64) + chunk: images are whole numbers of slabs
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                *reinterpret_cast<float2*>(gn_ws + (slab * N + col0 + j * 32 + fr) * 2) =
-                    *reinterpret_cast<const float2*>(gacc + (j * 32 + fr) * 2);
         }
     }
 }
@@ -651,6 +627,22 @@ static __device__ unsigned long long g_stamps[8];
 static __global__ void k_init_pad_rows() {
     for (int i = threadIdx.x; i < 256 * 64; i += blockDim.x) g_pad_rows[i] = (uint8_t)(i >> 6);
 }
+// The table lives in device memory of EVERY device this process drives: initialised once per device, stream-ordered ahead of
+// the first launch that reads it.  A first call that lands inside a stream capture records the kernel in that graph (so the
+// graph is self-contained) but does not count: eager launches issued before the graph's first replay initialise it themselves.
+static void ensure_pad_rows(hipStream_t st) {
+    static std::atomic<bool> ready[EDADM_MAX_DEVICES];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= EDADM_MAX_DEVICES) dev = 0;
+    if (ready[dev].load(std::memory_order_acquire)) return;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) cs = hipStreamCaptureStatusNone;
+    hipLaunchKernelGGL(k_init_pad_rows, dim3(1), dim3(256), 0, st);
+    if (cs == hipStreamCaptureStatusNone) ready[dev].store(true, std::memory_order_release);
+}
+// Device-side error word of this translation unit (bit 0: a hand-off wait of the persistent kernel gave up).  Kernels are
+// asynchronous, so the launching call cannot report it; edadm_device_status() does, at the caller's next synchronisation.
+static __device__ unsigned int g_error_word;
 
 template <int DT, int TM, int TN>
 __global__ void __launch_bounds__(256, 2)      // two workgroups per CU: at most 256 registers (VGPR + AGPR) per lane
@@ -1235,14 +1227,18 @@ k_gemm_p(const uint8_t* __restrict__ A, int64_t lda_b, const uint8_t* __restrict
     const int G = ntl * nk;                                          // K-steps this workgroup runs in total
     if (tid < 2 * S) full_w[tid] = 0;
     __syncthreads();
-    bool dead = false;                                               // a hand-off that never arrives: stop waiting (wrong
-                                                                     // results, which the tests see) instead of hanging
+    bool dead = false;                                               // a hand-off that never arrives: stop waiting instead of
+                                                                     // hanging the GPU, and say so in g_error_word
     auto wait_at_least = [&](int* word, int target) {
         if (dead) return;
         for (int spins = 0;; ++spins) {
             const int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
             if (v >= target) return;
-            if (spins > (1 << 22)) { dead = true; return; }
+            if (spins > (1 << 22)) {
+                dead = true;
+                if (lane == 0) atomicOr(&g_error_word, 1u);
+                return;
+            }
             __builtin_amdgcn_s_sleep(1);
         }
     };
@@ -1531,6 +1527,11 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
                        int64_t sBi = 0, int64_t sCi = 0, int out_mode = 0, const float* oqp = nullptr,
                        float* gn_ws = nullptr, int64_t gn_hw = 0) {
     if (out_mode != 0 && (!oqp || (N & 3) || (out_mode != 4 && (ldo & 3)))) return EDADM_EINVAL;   // quantised outputs use the 16-byte path
+    // modes 3 (GEGLU pairs) and 4 (transposed) exist in the vector epilogues only: the element-wise fallback that a misaligned
+    // output takes handles modes 1 and 2
+    if ((out_mode == 3 && (((uintptr_t)out) & 1)) || (out_mode == 4 && (((uintptr_t)out) & 3)) ||
+        (out_mode >= 3 && residual && ((((uintptr_t)residual) & 15) || (ldr & 3))))
+        return EDADM_EINVAL;
     if (out_mode == 4) {                             // the transposed store exists in the register-direct epilogue only
         const int tn_ = N % 192 == 0 ? 3 : 2;
         if (batch != 1 || M % 128 || N % (64 * tn_)) return EDADM_EINVAL;
@@ -1544,11 +1545,7 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
             return EDADM_EINVAL;
     }
     if (!rowadd && out_mode != 4) rpb = M;                   // one (unused) batch entry (mode 4: rows of one image)
-    static bool pad_ready = false;
-    if (!pad_ready) {       // stream-ordered ahead of the first GEMM; idempotent if it lands inside a captured graph
-        hipLaunchKernelGGL(k_init_pad_rows, dim3(1), dim3(256), 0, st);
-        pad_ready = true;
-    }
+    ensure_pad_rows(st);
     // tile choice: widest N tile that divides N well (192 for the 192-multiples of LDM-4, else 128, 64)
     int tn = 2;
     if (N % 192 == 0) tn = 3;
@@ -1965,11 +1962,7 @@ extern "C" int edadm_qconv3_i8_direct(const int8_t* A, const int8_t* Wdc, int64_
     if (ups && ((H | W) & 1)) return EDADM_EINVAL;
     const int64_t M = B * H * W;
     if (!rowadd) rows_per_batch = M;
-    static bool pad_ready = false;
-    if (!pad_ready) {
-        hipLaunchKernelGGL(k_init_pad_rows, dim3(1), dim3(256), 0, (hipStream_t)stream);
-        pad_ready = true;
-    }
+    ensure_pad_rows((hipStream_t)stream);
     if (tile == 256)
         hipLaunchKernelGGL((k_conv3_direct<3, 2>), dim3((unsigned)(N / 192), (unsigned)(M / 256)), dim3(512), 0, (hipStream_t)stream,
                            (const uint8_t*)A, (const uint8_t*)Wdc, M, N, (int)B, (int)H, (int)W, (int)Cin, padval, ups ? 1 : 0, scale, bias,
@@ -1983,10 +1976,20 @@ extern "C" int edadm_qconv3_i8_direct(const int8_t* A, const int8_t* Wdc, int64_
 #endif
 
 #if EDADM_GEMM_DT == 0
-extern "C" int edadm_qgemm_i8_gn(const int8_t* A, int64_t lda, const int8_t* Wt, int64_t ldw, int64_t M, int64_t N,
-                                 int64_t K, const int32_t* geom, const float* scale, const float* bias,
-                                 const float* rowadd, int64_t rows_per_batch, const float* residual, int64_t ldr,
-                                 float* out, int64_t ldo, float* gn_ws, int64_t gn_hw, void* stream) {
+extern "C" int edadm_device_status(int clear, void* stream) {
+    unsigned int w = 0;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return EDADM_EIO;
+    if (hipMemcpyFromSymbol(&w, HIP_SYMBOL(g_error_word), sizeof(w)) != hipSuccess) return EDADM_EIO;
+    if (w && clear) {
+        const unsigned int z = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_error_word), &z, sizeof(z)) != hipSuccess) return EDADM_EIO;
+    }
+    return w ? EDADM_EIO : 0;
+}
+extern "C" int edadm_qgemm_i8(const int8_t* A, int64_t lda, const int8_t* Wt, int64_t ldw, int64_t M, int64_t N,
+                              int64_t K, const int32_t* geom, const float* scale, const float* bias,
+                              const float* rowadd, int64_t rows_per_batch, const float* residual, int64_t ldr,
+                              float* out, int64_t ldo, void* stream) {
     if (!A || !Wt || !out || !scale || M <= 0 || N <= 0 || K <= 0 || (K & 15) || (ldw & 15)) return EDADM_EINVAL;
     if (((uintptr_t)A & 15) || ((uintptr_t)Wt & 15)) return EDADM_EINVAL;
     ConvGeom g;
@@ -2005,14 +2008,7 @@ extern "C" int edadm_qgemm_i8_gn(const int8_t* A, int64_t lda, const int8_t* Wt,
     }
     if (rowadd && rows_per_batch < 16) return EDADM_EINVAL;   // the epilogue stages <= BM/16+1 row-add rows in LDS
     return launch_gemm<0>(A, lda, 0, Wt, ldw, 0, M, N, K, g, scale, bias, rowadd, rows_per_batch, residual, ldr,
-                             out, ldo, 0, 1, 1.0f, (hipStream_t)stream, 1, 0, 0, 0, 0, nullptr, gn_ws, gn_hw);
-}
-extern "C" int edadm_qgemm_i8(const int8_t* A, int64_t lda, const int8_t* Wt, int64_t ldw, int64_t M, int64_t N,
-                              int64_t K, const int32_t* geom, const float* scale, const float* bias,
-                              const float* rowadd, int64_t rows_per_batch, const float* residual, int64_t ldr,
-                              float* out, int64_t ldo, void* stream) {
-    return edadm_qgemm_i8_gn(A, lda, Wt, ldw, M, N, K, geom, scale, bias, rowadd, rows_per_batch, residual, ldr, out, ldo,
-                             nullptr, 0, stream);
+                             out, ldo, 0, 1, 1.0f, (hipStream_t)stream, 1, 0, 0, 0, 0, nullptr, nullptr, 0);
 }
 #endif
 

@@ -128,7 +128,6 @@ class Engine:
         self.pair_stats = {"prefix_blocks": 0, "half_attention_blocks": 0}   # what the last cfg_pair call shared
         self.ctx_r = None            # {id(transformer block): [B][C]} from context_branches(), set by a sampling loop
         self.emb_r = None            # {id(emb projection): [B][N]} time-embedding rows of the current step (emb_tables())
-        self.gn_from_producer = os.environ.get("EDADM_GN_FROM_PRODUCER", "0") == "1"   # measured slower (58.4 vs 61.7 img/s): off
         self.direct_conv = os.environ.get("EDADM_DIRECT_CONV", "1") != "0"        # LDS-resident-patch 3x3 convolution
         self.direct_conv_min_k = int(os.environ.get("EDADM_DIRECT_CONV_MIN_K", "1152"))
         self.gn_partials = os.environ.get("EDADM_GN_PARTIALS", "1") != "0"       # ... which also writes the next GroupNorm's partial sums
@@ -267,6 +266,11 @@ class Engine:
         return a
 
     def _gemm(self, L, a, M, geom=None, rowadd=None, rpb=1, residual=None, out_mode=0, oqp=None, gn_hw=0):
+        # only _quant() pads an operand to a padded K (kpad): the fused producers (LayerNorm / GroupNorm / SiLU / GEGLU / a
+        # producing GEMM's epilogue) write exactly the layer's channels, so a mismatch here means one of them fed a padded layer
+        if geom is None and L.mode in ("i8", "f16") and not L.split and a.shape[-1] != L.segs[0]["K"]:
+            raise NotImplementedError("operand of %s has %d channels, the layer contracts over %d (a fused producer in front of a "
+                                      "K-padded layer)" % (L.name, a.shape[-1], L.segs[0]["K"]))
         if self.tap is not None:
             self.tap.setdefault(L.name, []).append(a.detach().clone())
         if out_mode and (L.mode != "i8" or len(L.segs) != 1):
@@ -287,23 +291,12 @@ class Engine:
             return run()
         out = torch.empty(M, L.N, dtype=torch.float32, device=self.dev)
         fn = ops.qgemm_i8 if L.mode == "i8" else ops.qgemm_f16
-        # GroupNorm partials of the output, written by the epilogue of the (last) launch for the layer that
-        # normalises it next: that layer then runs only the tiny final pass (K5 pass 1 folded into K4).  Long-K
-        # layers only: the short-K ones run on the persistent kernel, which has no register room for it.
-        # Correct (tests/test_gemm_paths_gpu.py) but OFF by default: the LDS atomics lengthen every producing epilogue
-        # by more than the saved statistics pass (EDADM_GN_FROM_PRODUCER=1: 58.4 vs 61.7 images/s).
-        gkw = {}
-        if self.gn_from_producer and gn_hw and L.mode == "i8" and L.K > 1024 and \
-                ops.gn_partials_ok(M, L.N, gn_hw, rpb if rowadd is not None else None):
-            ws = torch.empty(M // 64, L.N, 2, dtype=torch.float32, device=self.dev)
-            gkw = dict(gn_ws=ws, gn_hw=gn_hw)
-            out._gn = (ws, gn_hw, 64)
         if geom is not None:
             s = L.segs[0]
 
             def run():
                 fn(a, s["w"], M, L.N, s["K"], s["scale"], L.bias, out, geom=geom, rowadd=rowadd, rows_per_batch=rpb,
-                   residual=residual, **gkw)
+                   residual=residual)
         else:
             ctot = a.shape[-1]
 
@@ -312,7 +305,7 @@ class Engine:
                     av = a if len(L.segs) == 1 else a[:, s["lo"]:s["hi"]]
                     fn(av, s["w"], M, L.N, s["K"], s["scale"], L.bias if i == 0 else None, out, lda=ctot,
                        rowadd=rowadd if i == 0 else None, rows_per_batch=rpb, residual=residual if i == 0 else out,
-                       **(gkw if i == len(L.segs) - 1 else {}))
+                       )
         if self.prof is not None:
             self.prof.append((L.mode, L.name, M, L.N, L.K, 2.0 * M * L.N * L.K, run,
                               self._alg_bytes(L, a, M, 4.0 * M * L.N, residual, "conv%d" % L.kh if geom is not None else "dense")))
@@ -819,12 +812,14 @@ class Engine:
                 t = ops.add_rowbcast(t, pend[0], N, rows=pend[1])
             (of,) = self.ln(blk.norm3, t, (ff0,))
         L0, L2 = self.L(ff0), self.L(ff2)
+        # both GEGLU forms hand ff.net.2 an int8 operand of exactly its K: that layer must be a plain int8 layer
+        if L2.mode != "i8" or L2.split or getattr(L2, "kpad", 0):
+            raise NotImplementedError("ff.net.2 with exact-f16 weights (an 8-bit layer spanning [-127, 128]), split quantisers or a "
+                                      "padded K behind GEGLU: no configuration of the reference produces it (W8 is shipped for "
+                                      "the DDPM UNet only)")
         if getattr(L0, "geglu_interleaved", False):
             g = self._gemm(L0, of, B * N, out_mode=3, oqp=L2.qp)
         else:
-            if L2.mode != "i8" or L2.split:
-                raise NotImplementedError("ff.net.2 with exact-f16 weights (an 8-bit layer spanning [-127, 128]) behind GEGLU: "
-                                          "no configuration of the reference produces it (W8 is shipped for the DDPM UNet only)")
             g = ops.geglu_quant_i8(self._gemm(L0, of, B * N), L2.qp)
         if out_qp is not None and L2.mode == "i8" and len(L2.segs) == 1:
             # the block output only feeds proj_out's activation quantizer: ff.net.2 emits that operand

@@ -406,13 +406,6 @@ def make_geom(B, H, W, Cin, Ho, Wo, KH, KW, stride, pad0, ups, padval):
     return (ctypes.c_int32 * 16)(1, B, H, W, Cin, Ho, Wo, KH, KW, stride, pad0, 1 if ups else 0, int(padval), 0, 0, 0)
 
 
-def gn_partials_ok(M, N, hw, rowadd_rpb=None):
-    """Can the GEMM that writes out[M][N] also emit the GroupNorm partials of its output (edadm_qgemm_i8_gn)?"""
-    tile_n = 192 if N % 192 == 0 else 128
-    return M % 256 == 0 and N % tile_n == 0 and hw > 0 and hw % 64 == 0 and M % hw == 0 and \
-        (rowadd_rpb is None or rowadd_rpb >= 64)
-
-
 def groupnorm_final(ws1, C1, ws2, C2, B, HW, G, eps, B2=0, rows1=64, rows2=64):
     """stats[B][G][2] from producer-written partials [B][HW/rows][C][2] (ws2: second half of a concatenation, B2 > 0: of
     B2 images read periodically; rows1 / rows2: rows per slab of the two producers)."""
@@ -422,17 +415,20 @@ def groupnorm_final(ws1, C1, ws2, C2, B, HW, G, eps, B2=0, rows1=64, rows2=64):
     return stats
 
 
+def device_status(clear=True):
+    """Synchronise the current stream and raise if a kernel recorded a deferred error (edadm_device_status)."""
+    rc = lib.load().edadm_device_status(1 if clear else 0, _stream())
+    if rc != 0:
+        raise RuntimeError("libedadm: deferred device error %d (a persistent-GEMM hand-off timed out: outputs of that launch "
+                           "are invalid)" % rc)
+
+
 def qgemm_i8(A, Wt, M, N, K, scale, bias, out, geom=None, lda=None, ldw=None, rowadd=None, rows_per_batch=1,
-             residual=None, gn_ws=None, gn_hw=0):
+             residual=None):
     """out[M][N] (fp32, contiguous rows of length N) = scale[n] * (A . Wt^T) + bias[n] [+rowadd] [+residual]."""
     lda = K if lda is None else lda
     ldw = K if ldw is None else ldw
     gptr = ctypes.cast(geom, ctypes.c_void_p) if geom is not None else None
-    if gn_ws is not None:
-        lib.call("edadm_qgemm_i8_gn", ctypes.c_void_p(A.data_ptr()), int(lda), ctypes.c_void_p(Wt.data_ptr()), int(ldw),
-                 int(M), int(N), int(K), gptr, _pf(scale), _pf(bias), _pf(rowadd), int(rows_per_batch), _pf(residual),
-                 int(N), _pf(out), int(N), _pf(gn_ws), int(gn_hw), _stream())
-        return out
     lib.call("edadm_qgemm_i8", ctypes.c_void_p(A.data_ptr()), int(lda), ctypes.c_void_p(Wt.data_ptr()), int(ldw),
              int(M), int(N), int(K), gptr, _pf(scale), _pf(bias), _pf(rowadd), int(rows_per_batch), _pf(residual),
              int(N), _pf(out), int(N), _stream())

@@ -327,7 +327,9 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
             continue
         if use_graph and it >= GRAPH_WARMUP:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # thread_local: with several ranks the RCCL watchdog thread polls events while this thread captures; in the default
+            # (global) mode any such call from another thread invalidates the capture
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 ops.rng_epoch(1, add=True)
                 body()
             graph.replay()                                 # capture does not execute: this runs iteration `it`

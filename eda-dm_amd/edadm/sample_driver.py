@@ -58,4 +58,8 @@ class ShardedSampler:
             cond, uncond = cond_fn(i, labels)
             sink(i, self.loop.sample(x_T, cond, uncond))
             done += 1
+        # kernels are asynchronous: a failure inside one (a persistent-GEMM hand-off that timed out) surfaces here, where the
+        # run synchronises anyway, as an exception instead of silently wrong images
+        from . import ops
+        ops.device_status()
         return done

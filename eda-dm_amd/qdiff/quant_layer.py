@@ -9,6 +9,7 @@ re-implemented on the HIP kernels of libedadm.so:
 Device tensors only: there is no CPU code path (ops raise on host tensors).
 """
 import logging
+import warnings
 import os
 import random
 
@@ -203,12 +204,46 @@ class UniformAffineQuantizer(nn.Module):
             return delta.reshape(shp), zero_point.reshape(shp)
         return delta.reshape(()), zero_point.reshape(())
 
+    def init_quantization_scale_2(self, x, channel_wise=False):
+        """scale_method='max' (quant_layer.py:278-330), the constructor default: the range rule on the (per-channel) extrema.
+        The reference evaluates it in Python floats (`.item()`, i.e. double) channel by channel; here the extrema come from one
+        device pass and the same double arithmetic runs vectorised on the host -- bit-identical step sizes.  Its symmetric
+        branch is delta = absmax / n_levels with zero_point 0 (negative values clamp to code 0): kept as is."""
+        import numpy as np
+        if 'max' not in self.scale_method:
+            raise NotImplementedError
+        with torch.no_grad():
+            xmin, xmax = self._aminmax(x)
+            if self.leaf_param and not channel_wise:
+                self.x_min, self.x_max = xmin.reshape(()), xmax.reshape(())
+            mn, mx = xmin.double().cpu().numpy(), xmax.double().cpu().numpy()
+        lo, hi = np.minimum(mn, 0.0), np.maximum(mx, 0.0)
+        if 'scale' in self.scale_method:
+            lo, hi = lo * (self.n_bits + 2) / 8, hi * (self.n_bits + 2) / 8
+        if self.sym:
+            delta = np.maximum(np.abs(lo), hi) / self.n_levels
+        else:
+            delta = (mx - mn) / (self.n_levels - 1)
+        if (delta < 1e-8).any():
+            warnings.warn('Quantization range close to zero')
+            delta = np.where(delta < 1e-8, 1e-8, delta)
+        zp = np.zeros_like(delta) if (self.sym or self.always_zero) else np.round(-lo / delta)     # round half to even, as Python's
+        delta = torch.as_tensor(delta.astype(np.float32), device=x.device)
+        zp = torch.as_tensor(zp.astype(np.float32) + 0.0, device=x.device)
+        if channel_wise:
+            shp = [1] * x.dim()
+            shp[0] = x.shape[0]
+            return delta.reshape(shp), zp.reshape(shp)
+        return delta.reshape(()), zp.reshape(())
+
     def forward(self, x):
         if self.inited is False:
-            if self.scale_method != 'mse':
-                # the shipped scripts only use 'mse' (sample_diffusion_*.py); 'max' is not built
+            if self.scale_method == 'mse':
+                delta, self.zero_point = self.init_quantization_scale_1(x, self.channel_wise)
+            elif self.scale_method == 'max':
+                delta, self.zero_point = self.init_quantization_scale_2(x, self.channel_wise)
+            else:
                 raise NotImplementedError
-            delta, self.zero_point = self.init_quantization_scale_1(x, self.channel_wise)
             self.delta = nn.Parameter(delta) if self.leaf_param else delta
         qmax = self.n_levels - 1
         if self.channel_wise:

@@ -168,7 +168,7 @@ int edadm_groupnorm_stats_cat_rep(const float* x1, int64_t C1, const float* x2, 
 int edadm_quant_i8_cat_rep(const float* x1, int64_t C1, const float* x2, int64_t C2, int8_t* out, int64_t rows,
                            const float* qp, int64_t split, int64_t rows2, void* stream);
 /* pass 2 alone: per-channel partials [B][nchunk][C][2] (sum, sum of squares) written by a producer's epilogue
- * (edadm_qgemm_i8_gn) -> stats; ws2 (may be NULL) holds the second half of a channel concatenation */
+ * (edadm_qconv3_i8_direct) -> stats; ws2 (may be NULL) holds the second half of a channel concatenation */
 int edadm_groupnorm_final_cat(const float* ws1, int64_t C1, const float* ws2, int64_t C2, float* stats, int64_t B,
                               int64_t HW, int64_t G, int64_t nchunk, float eps, void* stream);
 /* the same with the second partials buffer holding B2 < B images, read periodically (image b takes b % B2): the shared
@@ -220,14 +220,12 @@ int edadm_qgemm_i8(const int8_t* A, int64_t lda, const int8_t* Wt, int64_t ldw, 
                    int64_t K, const int32_t* geom, const float* scale, const float* bias,
                    const float* rowadd, int64_t rows_per_batch, const float* residual, int64_t ldr,
                    float* out, int64_t ldo, void* stream);
-/* edadm_qgemm_i8 that also writes the GroupNorm partials of its own output for the layer that normalises it next
- * (K5 pass 1 folded into K4's register-direct epilogue through LDS atomics): gn_ws[M / 64][N][2] = per-channel
- * (sum, sum of squares) of each 64-row slab; gn_hw = rows of one image (gn_hw % 64 == 0, M % 256 == 0, N a multiple
- * of the 128/192-wide tile, else EINVAL); NULL gn_ws = edadm_qgemm_i8 */
-int edadm_qgemm_i8_gn(const int8_t* A, int64_t lda, const int8_t* Wt, int64_t ldw, int64_t M, int64_t N,
-                   int64_t K, const int32_t* geom, const float* scale, const float* bias,
-                   const float* rowadd, int64_t rows_per_batch, const float* residual, int64_t ldr,
-                   float* out, int64_t ldo, float* gn_ws, int64_t gn_hw, void* stream);
+/* Deferred device-side errors.  Every entry point returns as soon as its kernels are enqueued, so a failure INSIDE a kernel
+ * (today: a hand-off wait of the persistent GEMM that gave up after 4 M polls instead of hanging the GPU -- its outputs are
+ * then wrong) cannot come back from the launching call: it sets a device error word.  This call synchronises `stream`, reads
+ * the word and returns 0 or -EIO; clear != 0 resets it.  Callers check it where they synchronise anyway (end of a sampling
+ * run, end of a calibration unit).  Never call it inside a stream capture. */
+int edadm_device_status(int clear, void* stream);
 /* Batched f16 NT GEMM for the attention products (integer-valued f16 operands, exact in fp32):
  * C[z][m][n] = alpha * sum_k A[z][m][k] * B[z][n][k], z = outer*inner + head with two-level
  * element strides (outer = batch sample, inner = attention head inside a [B][N][heads*d] tensor).

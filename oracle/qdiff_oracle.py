@@ -181,8 +181,9 @@ class OQ:
 
     def __init__(self, n_bits=8, symmetric=False, channel_wise=False, scale_method="mse", leaf_param=False,
                  always_zero=False, prob=1.0, name=""):
-        if scale_method != "mse":
+        if scale_method not in ("mse", "max"):
             raise NotImplementedError
+        self.scale_method, self.always_zero = scale_method, always_zero
         self.name = name
         self.n_bits, self.n_levels = n_bits, 2 ** n_bits
         self.sym, self.channel_wise, self.leaf_param = symmetric, channel_wise, leaf_param
@@ -212,10 +213,26 @@ class OQ:
             return self.running_min, self.running_max
         return mn, mx
 
+    def max_rule(self, x):
+        """scale_method='max', init_quantization_scale_2 (quant_layer.py:278-330): Python-float (double) arithmetic on the
+        extrema of each channel (weights) or of the tensor; symmetric -> absmax / n_levels with zero_point 0."""
+        xf = x.detach().reshape(x.shape[0], -1) if self.channel_wise else x.detach().reshape(1, -1)
+        mn, mx = xf.min(1)[0].double().numpy(), xf.max(1)[0].double().numpy()
+        lo, hi = np.minimum(mn, 0.0), np.maximum(mx, 0.0)
+        delta = np.maximum(np.abs(lo), hi) / self.n_levels if self.sym else (mx - mn) / (self.n_levels - 1)
+        delta = np.where(delta < 1e-8, 1e-8, delta)
+        zp = np.zeros_like(delta) if (self.sym or self.always_zero) else np.round(-lo / delta)
+        return torch.as_tensor(delta.astype(np.float32)), torch.as_tensor(zp.astype(np.float32) + 0.0)
+
     def init_scale(self, x):
         with torch.no_grad():
-            mn, mx = self.get_min_max(x.detach())
-            delta, zp = calculate_qparams(mn, mx, self.n_levels)
+            if self.scale_method == "max":
+                delta, zp = self.max_rule(x)
+                if not self.channel_wise:
+                    delta, zp = delta.reshape(()), zp.reshape(())
+            else:
+                mn, mx = self.get_min_max(x.detach())
+                delta, zp = calculate_qparams(mn, mx, self.n_levels)
         if self.channel_wise:
             shp = [1] * x.dim()
             shp[0] = x.shape[0]

@@ -108,6 +108,43 @@ def g1_weight_init():
     save("g1_weight_init", d)
 
 
+def g1b_max_init():
+    """G1b: scale_method='max' -- the constructor DEFAULT (quant_layer.py:48) -- init_quantization_scale_2 (:278-330): per
+    channel for weights, per tensor for activations (leaf_param / always_zero variants), and the forward that follows.
+    Note the reference's symmetric 'max' rule: delta = absmax / n_levels with zero_point 0, so negatives clamp to code 0."""
+    g = torch.Generator().manual_seed(111)
+    d = {}
+    wz = torch.randn(6, 5, 3, 3, generator=g) * 0.1
+    wz[2] = 0.0
+    cases = [("conv_two", torch.randn(8, 6, 3, 3, generator=g) * 0.2), ("lin_two", torch.randn(12, 20, generator=g) * 0.5),
+             ("conv1d_two", torch.randn(6, 10, 1, generator=g) * 0.3), ("conv_pos", torch.rand(8, 4, 3, 3, generator=g) * 0.3),
+             ("conv_neg", -(torch.rand(8, 4, 1, 1, generator=g) * 0.7)), ("conv_zero_ch", wz)]
+    import warnings
+    for cname, w in cases:
+        d["w/%s" % cname] = w
+        for bits in (4, 8):
+            for sym in (True, False):
+                q = UniformAffineQuantizer(n_bits=bits, symmetric=sym, channel_wise=True, scale_method="max")
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    out = q(w)
+                key = "%s/b%d/%s" % (cname, bits, "sym" if sym else "asym")
+                d[key + "/delta"], d[key + "/zero_point"], d[key + "/out"] = q.delta, q.zero_point, out
+    acts = [("act_two", torch.randn(4, 16, 8, 8, generator=g) * 1.7), ("act_pos", torch.rand(4, 16, 8, 8, generator=g) * 3.0),
+            ("act_tokens", torch.randn(2, 33, 24, generator=g))]
+    for aname, x in acts:
+        d["x/%s" % aname] = x
+        for sym in (True, False):
+            for az in (False, True):
+                q = UniformAffineQuantizer(n_bits=8, symmetric=sym, channel_wise=False, scale_method="max", leaf_param=True,
+                                           always_zero=az)
+                out = q(x)
+                key = "%s/%s/%s" % (aname, "sym" if sym else "asym", "az" if az else "nz")
+                d[key + "/delta"], d[key + "/zero_point"], d[key + "/out"] = q.delta, np.float32(q.zero_point), out
+                assert isinstance(q.delta, nn.Parameter)
+    save("g1b_max_init", d)
+
+
 def g2_act_init():
     """G2: act UAQ init with EMA over batches (quant_layer.py:79-85,150-199,246-264)."""
     g = torch.Generator().manual_seed(202)
@@ -1509,7 +1546,7 @@ if __name__ == "__main__":
                 g6=g6_quant_module, g7=g7_blocks, g8=g8_g12_recon, g9=g9_tdac, g10=g10_steps,
                 g13c=g13_cifar_unet, g13i=lambda: g13_ldm_unet("imagenet"), g13h=lambda: g13_ldm_unet("church"), g14=g14_plms, g15=g15_decoder,
                 g17=g17_tdac_imagenet, g7b=g7b_blocks, g13w8=lambda: g13_cifar_unet(8, "g13_cifar_w8", 1301), g13sd=g13_ldm_sd, g16=g16_layer_recon,
-                g8b=g8b_recon_masks, g8c=g8c_recon_caches, g18=g18_church_driver, g19=g19_tdac_others)
+                g8b=g8b_recon_masks, g8c=g8c_recon_caches, g18=g18_church_driver, g19=g19_tdac_others, g1b=g1b_max_init)
     for k, fn in jobs.items():
         if not only or k in only:
             print("==", k)

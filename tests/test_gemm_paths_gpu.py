@@ -96,36 +96,6 @@ def test_qgemm_quantised_outputs(ops, M, N, K):
     assert torch.equal(fused, alone), int((fused != alone).sum())
 
 
-@pytest.mark.parametrize("B,HW,N,K", [(14, 4096, 192, 1728), (56, 1024, 384, 1152), (512, 64, 192, 1216)])
-def test_qgemm_groupnorm_partials(ops, B, HW, N, K):
-    """edadm_qgemm_i8_gn: the producer-side GroupNorm partials (LDS atomics in the direct epilogue) + final pass give
-    the statistics of the two-pass kernels on the same output (fp32 partial sums in a different order: 2e-5 relative),
-    also as one half of a channel concatenation; the output itself is unchanged."""
-    M = B * HW
-    A, W, scale, bias, g = _mk(M, N, K, M + N)
-    rowadd, res = torch.randn(B, N, generator=g).cuda(), torch.randn(M, N, generator=g).cuda()
-    out, out0 = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
-    ws = torch.full((M // 64, N, 2), float("nan"), device="cuda")
-    assert ops.gn_partials_ok(M, N, HW, HW)
-    args = (A.cuda(), W.cuda(), M, N, K, (scale * 10).cuda(), bias.cuda())
-    ops.qgemm_i8(*args, out0, rowadd=rowadd, rows_per_batch=HW, residual=res)
-    ops.qgemm_i8(*args, out, rowadd=rowadd, rows_per_batch=HW, residual=res, gn_ws=ws, gn_hw=HW)
-    assert torch.equal(out, out0)
-    G = 32
-    x = out.reshape(B, HW, N)
-    want = ops.groupnorm_stats(x, G, 1e-5)
-    got = ops.groupnorm_final(ws, N, None, 0, B, HW, G, 1e-5)
-    assert torch.isfinite(got).all()
-    assert ((got - want).abs() <= 2e-5 * want.abs().clamp_min(1.0)).all(), float((got - want).abs().max())
-    other = torch.randn(B, HW, 64, generator=g).cuda() * 3
-    ws_o = torch.empty(M // 64, 64, 2, device="cuda")
-    xo = other.reshape(M // 64, 64, 64)
-    ws_o[..., 0], ws_o[..., 1] = xo.sum(1), (xo * xo).sum(1)
-    want = ops.groupnorm_stats(ops.Cat(x, other), G, 1e-5)
-    got = ops.groupnorm_final(ws, N, ws_o, 64, B, HW, G, 1e-5)
-    assert ((got - want).abs() <= 2e-5 * want.abs().clamp_min(1.0)).all(), float((got - want).abs().max())
-
-
 @pytest.mark.parametrize("B,Nk,N,K", [(56, 1024, 384, 384), (50, 64, 960, 960), (7, 256, 576, 192)])
 def test_qgemm_transposed_f16_output(ops, B, Nk, N, K):
     """out_mode 4: the f16 operand of mode 1, stored transposed per image ([B][N][Nk]) -- bit-identical codes."""

@@ -52,7 +52,7 @@ def test_g7_cifar_blocks(golden):
         close(rb(x, temb, split=32), g["cifar/rb_q0"], rtol=1e-4, atol=1e-5)
         close(at(xa), g["cifar/at_q0"], rtol=1e-4, atol=1e-5)
         for q in block_qs(rb) + block_qs(at):
-            assert q.inited is False or True
+            assert q.inited is False            # like the reference's (`# self.inited = True`, quant_layer.py:264)
             k = "cifar/qp/model." + q.name
             np.testing.assert_array_equal(q.delta.numpy().reshape(-1), g[k + "/delta"].reshape(-1))
             np.testing.assert_array_equal(q.zero_point.numpy().reshape(-1), g[k + "/zero_point"].reshape(-1))

@@ -227,3 +227,29 @@ def test_g18_church_ldm_driver_and_unconditional_walk(golden):
     print("final quantised output vs reference: max %.3f mean %.4f of range" % (err.max(), err.mean()))
     # 0.19 % of the 4-bit weights of a random network rounded the other way (own-cache units): a few % of range at the output
     assert err.max() < 0.2 and err.mean() < 0.03
+
+
+def _g1b_cases(g):
+    for k in g.files:
+        if k.endswith("/delta"):
+            parts = k.split("/")
+            src = ("w/" if parts[0].startswith(("conv", "lin")) else "x/") + parts[0]
+            yield k[:-6], parts, T(g[src])
+
+
+def test_g1b_scale_method_max(golden):
+    """scale_method='max' (the constructor default, quant_layer.py:48,278-330): step sizes / zero points bit-exact, forward."""
+    g = golden("g1b_max_init")
+    n = 0
+    for key, parts, x in _g1b_cases(g):
+        if parts[1].startswith("b"):
+            q = O.OQ(n_bits=int(parts[1][1:]), symmetric=parts[2] == "sym", channel_wise=True, scale_method="max")
+        else:
+            q = O.OQ(n_bits=8, symmetric=parts[1] == "sym", channel_wise=False, scale_method="max", leaf_param=True,
+                     always_zero=parts[2] == "az")
+        out = q(x)
+        np.testing.assert_array_equal(q.delta.detach().numpy().reshape(-1), g[key + "/delta"].reshape(-1), err_msg=key)
+        np.testing.assert_array_equal(q.zero_point.numpy().reshape(-1), g[key + "/zero_point"].reshape(-1), err_msg=key)
+        close(out.detach(), g[key + "/out"], rtol=1e-6, atol=1e-7)
+        n += 1
+    assert n == 36

@@ -429,3 +429,57 @@ def test_tdac_generator_values_other_configs(golden, which):
             err = np.abs(got - ref).max() / np.abs(ref).max()
             print(which, nme, "vs the reference generator: max %.2e of range" % err)
             assert err <= 1e-4, (nme, err)
+
+
+def test_scale_method_max_bit_exact(golden):
+    """scale_method='max' -- the reference constructor's default (quant_layer.py:48,278-330) -- through the product quantizer on
+    the device: per-channel weight and per-tensor activation step sizes / zero points bit-exact against fixture G1b, and the
+    fake-quant forward (K1) that follows."""
+    from qdiff.quant_layer import UniformAffineQuantizer
+    import torch.nn as nn
+    g = golden("g1b_max_init")
+    n = 0
+    for k in g.files:
+        if not k.endswith("/delta"):
+            continue
+        key, parts = k[:-6], k.split("/")
+        x = _cuda(g[("w/" if parts[0].startswith(("conv", "lin")) else "x/") + parts[0]])
+        if parts[1].startswith("b"):
+            q = UniformAffineQuantizer(n_bits=int(parts[1][1:]), symmetric=parts[2] == "sym", channel_wise=True, scale_method="max")
+        else:
+            q = UniformAffineQuantizer(n_bits=8, symmetric=parts[1] == "sym", channel_wise=False, scale_method="max",
+                                       leaf_param=True, always_zero=parts[2] == "az")
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out = q(x)
+        assert isinstance(q.delta, nn.Parameter) == q.leaf_param
+        np.testing.assert_array_equal(q.delta.detach().cpu().numpy().reshape(-1), g[key + "/delta"].reshape(-1), err_msg=key)
+        np.testing.assert_array_equal(q.zero_point.cpu().numpy().reshape(-1), g[key + "/zero_point"].reshape(-1), err_msg=key)
+        np.testing.assert_allclose(out.detach().cpu().numpy(), g[key + "/out"], rtol=1e-6, atol=1e-7, err_msg=key)
+        n += 1
+    assert n == 36
+    assert UniformAffineQuantizer().scale_method == "max"               # the default constructs and runs
+    UniformAffineQuantizer()(torch.randn(4, 4, device="cuda"))
+
+
+def test_deferred_device_status_and_rejected_misaligned_pair_output():
+    """include/edadm.h edadm_device_status: after healthy launches of the persistent GEMM (the kernel whose hand-off wait can
+    give up) the deferred error word is clean; the GEGLU-pair output form refuses an output pointer its vector epilogue cannot
+    serve (-EINVAL) instead of falling into the element-wise form that does not know the pair layout."""
+    from edadm import ops, lib
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 102400, 3072, 384                                   # the LDM-4 GEGLU projection: persistent kernel
+    A = torch.randint(-128, 128, (M, K), generator=g, dtype=torch.int8).cuda()
+    W = torch.randint(-8, 9, (N, K), generator=g, dtype=torch.int8).cuda()
+    scale, bias = (torch.rand(N, generator=g) * 1e-3 + 1e-4).cuda(), torch.randn(N, generator=g).cuda()
+    qp = ops.qp_tensor([(0.041, 123.0, 255.0)], "cuda")
+    out = ops.qgemm_i8_q(A, W, M, N, K, scale, bias, 3, qp)
+    assert out.shape == (M, N // 2)
+    ops.device_status()                                            # synchronises; raises on a recorded hand-off timeout
+    assert lib.load().edadm_device_status(0, None) == 0
+    buf = torch.empty(M * (N // 2) + 16, dtype=torch.int8, device="cuda")
+    import ctypes
+    rc = lib.load().edadm_qgemm_i8_q(A.data_ptr(), K, W.data_ptr(), K, M, N, K, None, scale.data_ptr(), bias.data_ptr(), None, 1,
+                                     None, 0, buf.data_ptr() + 1, N // 2, 3, qp.data_ptr(), None)
+    assert rc == -22
