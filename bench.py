@@ -165,15 +165,14 @@ def time_calibration(qnn, dev, n_calib=256, iters=40):
     # look-ahead FP activation cache (qdiff/data_utils.py): scale its byte budget with the sample count so that this
     # bounded run groups the units exactly as the 1024-sample run does and the linear extrapolation stays honest
     import qdiff.data_utils as du
-    full_gb = float(os.environ.get("EDADM_FP_TRACE_GB", "48"))
-    os.environ["EDADM_FP_TRACE_GB"] = repr(full_gb * n_calib / 1024)
-    memo_gb = float(os.environ.get("EDADM_Q_MEMO_GB", "64"))              # memo of reconstructed units: same scaling
-    os.environ["EDADM_Q_MEMO_GB"] = repr(memo_gb * n_calib / 1024)
+    import edadm.recon as er
+    full_gb, memo_gb, feat_gb = du.FP_TRACE_GB, du.Q_MEMO_GB, er.FP_FEAT_GB
+    du.FP_TRACE_GB = full_gb * n_calib / 1024
+    du.Q_MEMO_GB = memo_gb * n_calib / 1024                                # memo of reconstructed units: same scaling
     # per-sample FP feature maps (edadm/recon.py fp_features): pays off over the 1000 iterations of the real run, so it
     # is forced on here, its byte budget scaled like the others, and its time extrapolated with the sample count
-    feat_gb = float(os.environ.get("EDADM_FP_FEAT_GB", "56"))
-    os.environ["EDADM_FP_FEAT_GB"] = repr(feat_gb * n_calib / 1024)
-    os.environ["EDADM_FP_FEAT_FORCE"] = "1"
+    er.FP_FEAT_GB = feat_gb * n_calib / 1024
+    er.FP_FEAT_FORCE = True
     du.STATS.update(fp_passes=0, fp_captures=0, units_served=0, memo_hits=0)
 
     def timed_save(*a, **k):
@@ -197,10 +196,7 @@ def time_calibration(qnn, dev, n_calib=256, iters=40):
     finally:
         cb.save_inp_oup_data, cl.save_inp_oup_data = orig
         timing, er.TIMING = er.TIMING, None
-        os.environ["EDADM_FP_TRACE_GB"] = repr(full_gb)
-        os.environ["EDADM_Q_MEMO_GB"] = repr(memo_gb)
-        os.environ["EDADM_FP_FEAT_GB"] = repr(feat_gb)
-        os.environ.pop("EDADM_FP_FEAT_FORCE", None)
+        du.FP_TRACE_GB, du.Q_MEMO_GB, er.FP_FEAT_GB, er.FP_FEAT_FORCE = full_gb, memo_gb, feat_gb, False
     loop = total - t_cache[0]
     units = qnn.block_count
     # steady-state seconds of ONE iteration of every unit (iterations after the first of each unit, edadm/recon.py);

@@ -23,6 +23,13 @@
 #include "../../include/edadm.h"
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
+// Launch heuristics are compile-time constants in the product; the diagnostic build (`make diag` / `make stamps`,
+// -DEDADM_DIAG, loaded only by tools/ through EDADM_LIB_PATH) reads them from the environment to sweep kernel structures.
+#ifdef EDADM_DIAG
+#define EDADM_TUNE_I(name, dflt) (getenv(name) ? atoll(getenv(name)) : (long long)(dflt))
+#else
+#define EDADM_TUNE_I(name, dflt) ((long long)(dflt))
+#endif
 #ifndef EDADM_USE_NT8
 #define EDADM_USE_NT8 1
 #endif
@@ -1554,7 +1561,7 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
     if (M <= 64) tm = 1;
     {   // few 128-row tiles (the 8x8 level: 250 for 256 CUs with room for two workgroups each): 64-row tiles double the
         // resident workgroups per CU, which is what hides the operand latency there
-        static const int64_t thr = getenv("EDADM_GEMM_TM1_BELOW") ? atoll(getenv("EDADM_GEMM_TM1_BELOW")) : 0;
+        static const int64_t thr = EDADM_TUNE_I("EDADM_GEMM_TM1_BELOW", 0);
         const int64_t t128 = ((M + 127) / 128) * ((N + 64 * tn - 1) / (64 * tn)) * batch;
         if (t128 < thr) tm = 1;
     }
@@ -1562,7 +1569,7 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
     const int64_t tiles8 = ((M + 255) / 256) * ((N + 64 * tn - 1) / (64 * tn)) * batch;
     // convolutions whose Cin is a multiple of 64 but not of 128 keep scalar tap arithmetic only with 64-byte K-steps
     const bool nt8_gather_ok = true;
-    static const int force = getenv("EDADM_GEMM_FORCE") ? atoi(getenv("EDADM_GEMM_FORCE")) : 0;   // diagnostics only
+    static const int force = (int)EDADM_TUNE_I("EDADM_GEMM_FORCE", 0);   // diagnostic build only
     if constexpr (DT == 0) {
         // persistent wave-specialised kernel: full 256-row tiles of the short-K, wide-N layers (the GEGLU projections:
         // many N tiles re-use each A block from L2), where a per-tile launch spends most of its life in prologue latency
@@ -1598,14 +1605,14 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
     // K <= 2048 (the 192-channel 3x3 convolutions, ff.net.2): with the register-direct epilogues the 4-wave tile at two
     // workgroups per CU overlaps one workgroup's output burst with the other's main loop and wins; longer K amortises
     // the 8-wave tile's smaller operand traffic per flop (tools/gemm_table.py, EDADM_GEMM_FORCE=2 vs 3)
-    static const int64_t nt8_min_kb = getenv("EDADM_NT8_MIN_KB") ? atoll(getenv("EDADM_NT8_MIN_KB")) : 2049;
+    static const int64_t nt8_min_kb = EDADM_TUNE_I("EDADM_NT8_MIN_KB", 2049);
     if (force != 2 && EDADM_USE_NT8 && (force == 3 || (tiles8 >= 224 && Kb >= nt8_min_kb)) && nt8_gather_ok &&
         !(out_mode == 4 && M % 256)) {
         // Tail re-tiling: one workgroup per CU means the launch runs in rounds of #CU tiles, and a last round that is
         // mostly empty costs a full round (300 tiles on 256 CUs: 2 rounds for 1.17 rounds of work).  The m-tiles that
         // fill whole rounds go to this kernel; the remaining rows go to the 128-row, two-per-CU kernel in a second
         // launch (same arithmetic, same epilogue, rows offset by g.r0).
-        static const int tailsplit = getenv("EDADM_GEMM_TAILSPLIT") ? atoi(getenv("EDADM_GEMM_TAILSPLIT")) : 1;
+        static const int tailsplit = (int)EDADM_TUNE_I("EDADM_GEMM_TAILSPLIT", 1);
         int64_t m_main = M;
         if (DT == 0 && tailsplit && batch == 1 && M % 256 == 0 && !gn_ws && tn >= 2) {
             static int ncu8 = 0;
@@ -1941,7 +1948,7 @@ extern "C" int edadm_conv3_direct_tile(int64_t B, int64_t H, int64_t W, int64_t 
     if (H & (H - 1)) return 0;                              // the kernel's tile arithmetic is shifts: H * W a power of two
     if (B * H * W * Cin >= (1ll << 31)) return 0;
     const bool f256 = conv3_tile_fits(B, H, W, 256), f128 = conv3_tile_fits(B, H, W, 128);
-    static const int64_t small = getenv("EDADM_CONV3_TILE128_BELOW") ? atoll(getenv("EDADM_CONV3_TILE128_BELOW")) : 200;
+    static const int64_t small = EDADM_TUNE_I("EDADM_CONV3_TILE128_BELOW", 200);
     // 256-pixel tiles unless they do not even fill one round of the 256 CUs (the 8x8 level: 125 workgroups -> 250 half-size
     // ones, 88 -> 68 us; at 300 workgroups, the 16x16 level, both tile sizes take the same time)
     if (f128 && (!f256 || (B * H * W / 256) * (N / 192) <= small)) return 128;

@@ -434,8 +434,7 @@ extern "C" int edadm_groupnorm_apply_cat_raw(const float* x1, int64_t C1, const 
     if ((q0 || q1 || q2) && !qp) return EDADM_EINVAL;
     if (qraw && (!qp_raw || raw_split < 0 || raw_split >= C || (raw_split & 3))) return EDADM_EINVAL;
     if (B2 < 0 || (B2 > 0 && (!x2 || B % B2))) return EDADM_EINVAL;
-    static const bool wide = !getenv("EDADM_GN_APPLY16") || atoi(getenv("EDADM_GN_APPLY16")) != 0;
-    if (wide && !out_f32 && !scale_shift && nq == 1 && q0 && !q1 && !q2 && (C & 15) == 0 && (C1 & 15) == 0 && C <= 4096 &&
+    if (!out_f32 && !scale_shift && nq == 1 && q0 && !q1 && !q2 && (C & 15) == 0 && (C1 & 15) == 0 && C <= 4096 &&
         (!qraw || (raw_split & 15) == 0) && !((uintptr_t)q0 & 15) && !((uintptr_t)qraw & 15) && !((uintptr_t)x1 & 15) &&
         !((uintptr_t)x2 & 15)) {
         const int G16 = (int)(C >> 4), RS = 256 / G16;

@@ -17,10 +17,10 @@ import torch
 
 from . import ops
 
-IMPLICIT_DGRAD = os.environ.get("EDADM_IMPLICIT_DGRAD", "1") != "0"
+IMPLICIT_DGRAD = True      # input gradients of stride-1 convolutions as implicit GEMMs (False: im2col GEMM + col2im; tools only)
 # large products run as ONE f16-MFMA GEMM over the two-term f16 expansion of both fp32 operands (three products,
 # fp32 accumulation: fp32-grade result at 2x the exact-fp32 MFMA's rate, csrc/elem.hip); 0 = exact-fp32 MFMA only
-F16X3 = os.environ.get("EDADM_F16X3", "1") != "0"
+F16X3 = True
 
 
 def _f16x3_linear(M, N, K):

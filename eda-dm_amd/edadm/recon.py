@@ -155,8 +155,12 @@ def _attention_quantizers(module, control=True):
 TIMING = None
 # iterations from which a unit's loop replays a HIP graph of one iteration (0 / huge = always eager), and the eager iterations
 # in front of the capture (lazy initialisation, allocator warm-up)
-GRAPH_MIN_ITERS = int(os.environ.get("EDADM_RECON_GRAPH_MIN_ITERS", "32"))
+GRAPH_MIN_ITERS = 32
 GRAPH_WARMUP = 2
+# HBM budget of the per-sample FP feature maps of the fine-grained loss (fp_features), and a force flag for short measuring
+# runs (bench.py) in which a sample is drawn less than twice
+FP_FEAT_GB = 56.0
+FP_FEAT_FORCE = False
 # parity tests: a callable (cur_inp) -> uniforms that replace the in-kernel RNG of the input mix (block_recon.py:141-145), the
 # counterpart of UniformAffineQuantizer.injected_uniform; None = the counter RNG keyed by (seed, element)
 INJECT_MIX_UNIFORM = None
@@ -247,12 +251,12 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
     model.engine = None
     feats = None
     # worth it when every sample is drawn more than once (bench.py forces it on its short run and scales the time)
-    if is_block and hooks and (iters * batch_size >= 2 * sz or os.environ.get("EDADM_FP_FEAT_FORCE") == "1"):
+    if is_block and hooks and (iters * batch_size >= 2 * sz or FP_FEAT_FORCE):
         if TIMING is not None:
             torch.cuda.synchronize()
             _t_feat = time.time()
         feats = fp_features(unit, hooks, cached_inps, resblock, sz, batch_size,
-                            int(float(os.environ.get("EDADM_FP_FEAT_GB", "56")) * (1 << 30)))
+                            int(FP_FEAT_GB * (1 << 30)))
         unit.set_quant_state(True, act_quant)
         if TIMING is not None:
             torch.cuda.synchronize()

@@ -60,6 +60,7 @@ class ShardedSampler:
             done += 1
         # kernels are asynchronous: a failure inside one (a persistent-GEMM hand-off that timed out) surfaces here, where the
         # run synchronises anyway, as an exception instead of silently wrong images
-        from . import ops
-        ops.device_status()
+        if torch.device(self.device).type == "cuda":
+            from . import ops
+            ops.device_status()
         return done

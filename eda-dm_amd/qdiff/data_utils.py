@@ -101,6 +101,10 @@ def recon_units(module, out=None):
     return out
 
 
+# HBM budgets (GB of the 288) of the two activation caches below; 0 = the reference's schedule (a double prefix pass per unit).
+# Deployment knobs set by code (bench.py scales them with the calibration-set size), not by the environment.
+FP_TRACE_GB = 48.0          # look-ahead FP activations of pending units
+Q_MEMO_GB = 64.0            # outputs of already reconstructed units under the quantised prefix
 STATS = {"fp_passes": 0, "fp_captures": 0, "units_served": 0, "memo_hits": 0}    # counters for bench.py / tests
 
 
@@ -115,7 +119,7 @@ class FPTrace:
         self.memo = {}           # reconstructed unit -> {batch index: output under the quantised prefix}
         self.memo_admit = {}     # unit -> admitted (bytes reserved for all local batches) or refused
         self.memo_bytes = 0
-        self.memo_budget = int(float(os.environ.get("EDADM_Q_MEMO_GB", "64")) * (1 << 30))
+        self.memo_budget = int(Q_MEMO_GB * (1 << 30))
 
     @staticmethod
     def _density(unit, out):
@@ -216,7 +220,7 @@ class FPTrace:
 
 
 def _trace_for(model, cali_data, batch_size, batch_transform):
-    gb = float(os.environ.get("EDADM_FP_TRACE_GB", "48"))
+    gb = FP_TRACE_GB
     if gb <= 0:
         return None
     key = (tuple((c.data_ptr(), tuple(c.shape)) for c in cali_data), batch_size, batch_transform)

@@ -73,20 +73,24 @@ def _flat(r):
 
 def _walk(model, cali, trace_gb, memo_gb):
     import qdiff.data_utils as du
-    os.environ["EDADM_FP_TRACE_GB"], os.environ["EDADM_Q_MEMO_GB"] = trace_gb, memo_gb
-    du.clear_fp_trace(model)
-    du.STATS.update(fp_passes=0, fp_captures=0, units_served=0, memo_hits=0)
-    units = du.recon_units(model)
-    res = []
-    with torch.no_grad():
-        for u in units:
-            u.gain.zero_()
-    for u in units:
-        res.append(_flat(du.save_inp_oup_data(model, u, cali, True, True, batch_size=32, input_prob=True)))
+    old = du.FP_TRACE_GB, du.Q_MEMO_GB
+    du.FP_TRACE_GB, du.Q_MEMO_GB = float(trace_gb), float(memo_gb)
+    try:
+        du.clear_fp_trace(model)
+        du.STATS.update(fp_passes=0, fp_captures=0, units_served=0, memo_hits=0)
+        units = du.recon_units(model)
+        res = []
         with torch.no_grad():
-            u.gain.fill_(0.25)                      # "reconstruction": the unit's quantised behaviour changes
-    stats = dict(du.STATS)
-    du.clear_fp_trace(model)
+            for u in units:
+                u.gain.zero_()
+        for u in units:
+            res.append(_flat(du.save_inp_oup_data(model, u, cali, True, True, batch_size=32, input_prob=True)))
+            with torch.no_grad():
+                u.gain.fill_(0.25)                      # "reconstruction": the unit's quantised behaviour changes
+        stats = dict(du.STATS)
+        du.clear_fp_trace(model)
+    finally:
+        du.FP_TRACE_GB, du.Q_MEMO_GB = old
     return units, res, stats
 
 

@@ -272,8 +272,8 @@ def test_fp_trace_matches_per_unit_passes(golden, monkeypatch):
     def walk_all(trace_gb, memo_gb):
         """save_inp_oup_data for every unit in walk order; after each unit its weight scales are perturbed, standing
         in for the reconstruction that changes what the units after it see."""
-        monkeypatch.setenv("EDADM_FP_TRACE_GB", trace_gb)
-        monkeypatch.setenv("EDADM_Q_MEMO_GB", memo_gb)
+        monkeypatch.setattr(du, "FP_TRACE_GB", float(trace_gb))
+        monkeypatch.setattr(du, "Q_MEMO_GB", float(memo_gb))
         du.clear_fp_trace(qnn)
         du.STATS.update(fp_passes=0, fp_captures=0, units_served=0, memo_hits=0)
         undo, res = [], []

@@ -1,10 +1,11 @@
 """Diagnostic: the quantised-output GEMM shapes of LDM-4 under each kernel structure (EDADM_GEMM_FORCE: 0 heuristic,
-2 four-wave tile, 3 eight-wave tile, 5 persistent wave-specialised).  python tools/force_sweep.py  (re-runs itself per value)"""
+2 four-wave tile, 3 eight-wave tile, 5 persistent wave-specialised) on the DIAGNOSTIC build (`make -C eda-dm_amd/csrc diag`: the
+product library has these heuristics compiled in).  python tools/force_sweep.py  (re-runs itself per value)"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) == 1:
     for f in ("0", "2", "3", "5"):
-        env = dict(os.environ, EDADM_GEMM_FORCE=f)
+        env = dict(os.environ, EDADM_GEMM_FORCE=f, EDADM_LIB_PATH=os.path.join(ROOT, "eda-dm_amd", "csrc", "libedadm_diag.so"))
         r = subprocess.run([sys.executable, os.path.abspath(__file__), f], env=env, capture_output=True, text=True)
         print(r.stdout, end="")
         if r.returncode:
