@@ -1,13 +1,17 @@
 #!/usr/bin/env python3
-"""bench.py — images/sec of W4A8 LDM-4 ImageNet 256x256 sampling on MI355X (BASELINE.json metric).
+"""bench.py -- images/sec of W4A8 LDM-4 ImageNet 256x256 on MI355X, and the full calibration wall-clock (BASELINE.json metric).
 
-A "step" = one batch of 50 images taken through the whole quantised sampling path: 20 DDIM steps,
-classifier-free guidance 3.0 (100 UNet rows per call), on the frozen int8 executor with the UNet
-forward replayed from a HIP graph.  Inputs (noise latents, class-embedding context) are resident
-in HBM before the timed region; weights are random-init LDM-4 (cin256-v2 shapes, 400.9 M params),
-quantised W4A8 by the build's own scale-initialisation path (no checkpoint / dataset is available).
-The first-stage VQ decoder (FP32, never quantised, SURVEY.md §8f-3 "next") is not part of the hot
-path and is outside the timed region.
+A "step" = one batch of 50 images taken through the path the reference's sampling loop takes per batch
+(sample_diffusion_ldm_imagenet.py:215-249): 20 DDIM steps x classifier-free guidance 3.0 (100 UNet rows per call) on the frozen
+int8 executor, UNet forward replayed from a HIP graph, THEN the VQ-f4 first-stage decode of the batch to 256x256 pixels (on a
+second HIP stream, overlapping the next batch's sampling).  `value` = decoded images per second; `sampling_only` (same line) is the
+quantised-UNet part alone.  Inputs (noise latents, class-embedding context) are resident in HBM before the timed region; weights
+are random-init LDM-4 (cin256-v2 shapes, 400.9 M params) -- no checkpoint / dataset exists in the tree.
+
+At N = 1 the run then measures the OTHER half of the metric in the same process: the whole calibration job at the shipped size --
+TDAC calibration set (1024 samples) -> scale initialisation over all 1024 -> 1000 iterations x 80 units of reconstruction --
+stage by stage (`calibration.stages`), with the reconstruction loop's roofline (`calibration.h1_roofline`).  ~9 minutes;
+`--calib bounded` / `--calib none` shorten the run.
 
     python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
 """
@@ -76,15 +80,9 @@ VQF4 = dict(ch=128, out_ch=3, ch_mult=(1, 2, 4), num_res_blocks=2, attn_resoluti
             resolution=256, z_channels=3)        # models/first_stage_models/vq-f4/config.yaml (embed_dim 3, 8192 codes)
 
 
-def time_decoder(dev, B):
-    """SURVEY 8(f)-3, reported next to the headline (never part of `value`): the VQ-f4 first-stage decoder
-    (55.3 M parameters, 318 GMAC per image, fp32) on the HIP fp32 kernels, B latents -> B images of 256x256."""
-    from edadm.nets.vq_decoder import Decoder
-    from edadm.decoder import DecoderEngine
-    torch.manual_seed(4321)
-    dec = Decoder(**VQF4).to(dev).eval()
-    pq = torch.nn.Conv2d(3, 3, 1).to(dev)
-    eng = DecoderEngine(dec, pq, codebook=torch.randn(8192, 3, device=dev))
+def time_decoder(eng, dev, B):
+    """the VQ-f4 first-stage decoder on its own (55.3 M parameters, 318 GMAC per image, fp32) on the HIP fp32-grade
+    kernels, B latents -> B images of 256x256."""
     z = torch.randn(B, 3, 64, 64, device=dev)
     eng(z)                                   # untimed pass at the full batch: allocator pools and code objects warm
     torch.cuda.synchronize()
@@ -99,80 +97,55 @@ def time_decoder(dev, B):
                       "expansions (fp32-grade, DESIGN.md section 4), the rest on the exact-fp32 MFMA; random-init weights"}
 
 
-def end_to_end(loop, noise, cond, uncond, args, dev, B):
-    """Latents -> images as the reference's loop delivers them (sample_diffusion_ldm_imagenet.py:215-249 decodes every
-    batch): the VQ-f4 decode of batch k runs on a second HIP stream while batch k + 1 samples on the first."""
+def make_decoder(dev):
     from edadm.nets.vq_decoder import Decoder
     from edadm.decoder import DecoderEngine
     torch.manual_seed(4321)
-    dec = DecoderEngine(Decoder(**VQF4).to(dev).eval(), torch.nn.Conv2d(3, 3, 1).to(dev), codebook=torch.randn(8192, 3, device=dev))
-    side = torch.cuda.Stream(device=dev)
-    n = max(args.steps, 2)
-    lat = loop.sample(noise[0], cond, uncond)
-    with torch.cuda.stream(side):
-        dec(lat)                                      # warm the side stream's buffers
-    torch.cuda.synchronize()
-    out = {}
-    for mode in ("serial", "overlapped"):
-        torch.cuda.synchronize()
-        t0 = time.time()
-        prev, imgs = None, 0
-        for i in range(n):
-            if mode == "overlapped" and prev is not None:
-                side.wait_stream(torch.cuda.current_stream(dev))
-                with torch.cuda.stream(side):
-                    prev.record_stream(side)
-                    imgs += dec(prev).shape[0]
-                prev = None
-            lat = loop.sample(noise[i % len(noise)], cond, uncond)
-            if mode == "serial":
-                imgs += dec(lat).shape[0]
-            else:
-                prev = lat
+    return DecoderEngine(Decoder(**VQF4).to(dev).eval(), torch.nn.Conv2d(3, 3, 1).to(dev), codebook=torch.randn(8192, 3, device=dev))
+
+
+def run_steps(loop, dec, side, noise, cond, uncond, first, last, dev):
+    """Steps [first, last): sample batch k on the current stream, decode it on `side` while batch k + 1 samples (the loop of
+    sample_diffusion_ldm_imagenet.py:215-249 delivers decoded images).  dec None: sampling only.  Returns images delivered."""
+    prev, imgs = None, 0
+    cur = torch.cuda.current_stream(dev)
+    for i in range(first, last):
         if prev is not None:
-            side.wait_stream(torch.cuda.current_stream(dev))
+            side.wait_stream(cur)
             with torch.cuda.stream(side):
                 prev.record_stream(side)
                 imgs += dec(prev).shape[0]
-        torch.cuda.synchronize()
-        out[mode] = imgs / (time.time() - t0)
-    return {"metric": "images/sec, latents sampled AND decoded to 256x256 pixels", "value": max(out.values()), "unit": "images/sec",
-            "serial": out["serial"], "decode_on_second_stream": out["overlapped"], "batches": n}
+            prev = None
+        lat = loop.sample(noise[i % len(noise)], cond, uncond)
+        if dec is None:
+            imgs += lat.shape[0]
+        else:
+            prev = lat
+    if prev is not None:
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            prev.record_stream(side)
+            imgs += dec(prev).shape[0]
+    return imgs
 
 
-def time_calibration(qnn, dev, n_calib=256, iters=40):
-    """The calibration hot loop (H1) on the same full-size UNet: the conditional reconstruction walk
-    (qdiff_control.recon_block_Qmodel, every unit of the model) with `n_calib` synthetic calibration samples
-    (CFG-doubled rows) and `iters` iterations per unit.  The shipped setting is 1024 samples x 1000 iterations
-    (sample_diffusion_ldm_imagenet.py:165-196): `--full-calib` runs exactly that and reports the measured wall-clock;
-    the default bench line runs a bounded 256 x 40 (iterations replayed from a HIP graph, as in the full run) and extrapolates linearly, next to the committed measurement."""
+def instrumented_walk(qnn, cali, kwargs, n_calib):
+    """The conditional reconstruction walk (qdiff_control.recon_block_Qmodel, every unit of the model) with its phases timed:
+    activation caching (save_inp_oup_data), per-sample FP feature maps, steady-state iterations, per-unit setup; the cache budgets
+    scaled with the calibration-set size so that a bounded run groups and memoises exactly as the full-size run does."""
     import qdiff_control.block_recon as cb
     import qdiff_control.layer_recon as cl
     from qdiff_control import recon_block_Qmodel
-    g = torch.Generator().manual_seed(11)
-    x = torch.randn(n_calib, 3, 64, 64, generator=g).to(dev)
-    ts = np.arange(0, 1000, 50) + 1
-    idx = torch.randint(0, 20, (n_calib,), generator=g)
-    t = torch.tensor(ts[idx.numpy()], dtype=torch.long, device=dev)
-    cond = torch.randn(n_calib, 1, 512, generator=g).to(dev)
-    uncond = torch.randn(1, 1, 512, generator=g).expand(n_calib, 1, 512).contiguous().to(dev)
-    cali = (x, t, idx.to(dev), cond, uncond)
-    kwargs = dict(cali_data=cali, iters=iters, act_quant=True, asym=True, opt_mode='mse', lr_a=1e-4, lr_w=5e-1, p=2.0,
-                  weight=0.0001, b_range=(20, 2), warmup=0.2, batch_size=32, input_prob=0.5, add_loss=0.8,
-                  recon_w=True, recon_a=True, keep_gpu=False)
-    t_cache = [0.0]
-    orig = (cb.save_inp_oup_data, cl.save_inp_oup_data)
-    # look-ahead FP activation cache (qdiff/data_utils.py): scale its byte budget with the sample count so that this
-    # bounded run groups the units exactly as the 1024-sample run does and the linear extrapolation stays honest
     import qdiff.data_utils as du
     import edadm.recon as er
+    iters = kwargs["iters"]
+    t_cache = [0.0]
+    orig = (cb.save_inp_oup_data, cl.save_inp_oup_data)
     full_gb, memo_gb, feat_gb = du.FP_TRACE_GB, du.Q_MEMO_GB, er.FP_FEAT_GB
     du.FP_TRACE_GB = full_gb * n_calib / 1024
-    du.Q_MEMO_GB = memo_gb * n_calib / 1024                                # memo of reconstructed units: same scaling
-    # per-sample FP feature maps (edadm/recon.py fp_features): pays off over the 1000 iterations of the real run, so it
-    # is forced on here, its byte budget scaled like the others, and its time extrapolated with the sample count
+    du.Q_MEMO_GB = memo_gb * n_calib / 1024
     er.FP_FEAT_GB = feat_gb * n_calib / 1024
-    er.FP_FEAT_FORCE = True
+    er.FP_FEAT_FORCE = iters < 1000          # pays off over the 1000 iterations of the real run: forced on in a bounded one
     du.STATS.update(fp_passes=0, fp_captures=0, units_served=0, memo_hits=0)
 
     def timed_save(*a, **k):
@@ -184,7 +157,6 @@ def time_calibration(qnn, dev, n_calib=256, iters=40):
         return r
 
     cb.save_inp_oup_data = cl.save_inp_oup_data = timed_save
-    import edadm.recon as er
     er.TIMING = {"iter_s": 0.0, "iters": 0}
     try:
         qnn.set_quant_state(True, True)
@@ -200,15 +172,23 @@ def time_calibration(qnn, dev, n_calib=256, iters=40):
     loop = total - t_cache[0]
     units = qnn.block_count
     # steady-state seconds of ONE iteration of every unit (iterations after the first of each unit, edadm/recon.py);
-    # what is left of the loop time is per-unit setup (AdaRound init, optimiser state, first-iteration warm-up),
-    # paid once per unit whatever the iteration count
+    # what is left of the loop time is per-unit setup (AdaRound init, optimiser state, first iterations, graph capture)
     per_iter_all_units = timing["iter_s"] / max(timing["iters"], 1) * units
     feat = timing.get("feat_s", 0.0)
     setup = max(loop - timing["iter_s"] - feat, 0.0)
+    flops = timing.get("flops", 0.0)
+    tf = flops / max(timing["iter_s"], 1e-9) / 1e12
     return dict(units=units, calib_samples=n_calib, iters_per_unit=iters, wall_s=total, caching_s=t_cache[0],
-                loop_s=loop, unit_setup_s=setup, s_per_iteration_all_units=per_iter_all_units,
+                loop_s=loop, steady_iterations_s=timing["iter_s"], unit_setup_s=setup, fp_features_s=feat,
+                s_per_iteration_all_units=per_iter_all_units,
                 per_unit_ms=[{"unit": u, "weights": n, "ms_per_iteration": ms} for u, n, ms in timing.get("per_unit", [])],
                 graphed_units=timing.get("graphed_units", 0),
+                h1_roofline={"bound": "mfma", "what": "contractions of the steady-state reconstruction iterations (forward x2-3, input and "
+                             "weight gradients; attention products included), executed fp32-equivalent flops counted on the host as they "
+                             "are issued / wall time of those iterations (everything in them: elementwise, Adam, gathers)",
+                             "executed_fp32_equivalent_pflop": flops / 1e15, "seconds": timing["iter_s"], "achieved": tf, "unit": "TFLOP/s",
+                             "peak_f16_three_product": 2516.0 / 3, "frac": tf / (2516.0 / 3),
+                             "peak_fp32_mfma": 157.0, "frac_of_fp32_mfma": tf / 157.0},
                 fp_features={"s": feat, "units_cached": timing.get("feat_units", 0), "budget_gb_at_1024_samples": feat_gb},
                 fp_trace={"budget_gb_at_1024_samples": full_gb, "fp_prefix_sweeps": du.STATS["fp_captures"],
                           "units_served": du.STATS["units_served"], "memo_budget_gb_at_1024_samples": memo_gb,
@@ -217,6 +197,57 @@ def time_calibration(qnn, dev, n_calib=256, iters=40):
                                      "fp_features_1024_samples": feat * 1024 / n_calib,
                                      "loops_1000_iters": setup + per_iter_all_units * 1000,
                                      "total": (t_cache[0] + feat) * 1024 / n_calib + setup + per_iter_all_units * 1000})
+
+
+SHIPPED_RECON = dict(act_quant=True, asym=True, opt_mode='mse', lr_a=1e-4, lr_w=5e-1, p=2.0, weight=0.0001, b_range=(20, 2),
+                     warmup=0.2, batch_size=32, input_prob=0.5, add_loss=0.8, recon_w=True, recon_a=True, keep_gpu=False)
+
+
+def time_calibration(qnn, dev, n_calib=256, iters=40):
+    """Bounded form (`--calib bounded`, and the multi-rank leg): the reconstruction walk on the full-size UNet with `n_calib`
+    synthetic calibration rows and `iters` iterations per unit, extrapolated linearly to 1024 x 1000."""
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n_calib, 3, 64, 64, generator=g).to(dev)
+    ts = np.arange(0, 1000, 50) + 1
+    idx = torch.randint(0, 20, (n_calib,), generator=g)
+    t = torch.tensor(ts[idx.numpy()], dtype=torch.long, device=dev)
+    cond = torch.randn(n_calib, 1, 512, generator=g).to(dev)
+    uncond = torch.randn(1, 1, 512, generator=g).expand(n_calib, 1, 512).contiguous().to(dev)
+    cali = (x, t, idx.to(dev), cond, uncond)
+    return instrumented_walk(qnn, cali, dict(cali_data=cali, iters=iters, **SHIPPED_RECON), n_calib)
+
+
+def full_calibration(dev):
+    """The whole calibration job at the shipped size (scripts/for_imagenet.sh:15-16 -> sample_diffusion_ldm_imagenet.py:142-199):
+    1024 calibration samples in trajectory batches of 64, 20 DDIM steps, CFG 3.0, lambda 1.2; scale initialisation over all 1024;
+    1000 iterations x every unit.  A fresh FP model (the job starts from the checkpoint, not from a quantised model)."""
+    from scripts import sample_diffusion_ldm_imagenet as H
+    args = H.parser().parse_args(["calibrate", "--calib_num_samples", "1024", "--batch_samples", "64", "--iters", "1000"])
+    walk_out = {}
+
+    def walk(qnn, cali, kwargs):
+        walk_out.update(instrumented_walk(qnn, cali, kwargs, args.calib_num_samples))
+
+    torch.cuda.reset_peak_memory_stats(dev)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    ld, qnn, st = H.calibration_flow(args, dev, walk=walk)
+    torch.cuda.synchronize()
+    total = time.time() - t0
+    r = dict(walk_out)
+    r.pop("extrapolated_full_s", None)
+    r["stages"] = {"model_build_and_wrap_s": total - sum(st.values()), "tdac_s": st["tdac_s"],
+                   "scale_init_s": st["weight_scale_init_s"] + st["act_scale_init_s"],
+                   "weight_scale_init_s": st["weight_scale_init_s"], "act_scale_init_s": st["act_scale_init_s"],
+                   "caching_s": r["caching_s"], "fp_features_s": r["fp_features_s"], "loop_s": r["steady_iterations_s"] + r["unit_setup_s"],
+                   "reconstruction_s": st["reconstruction_s"]}
+    r["wall_s"] = st["tdac_s"] + st["weight_scale_init_s"] + st["act_scale_init_s"] + st["reconstruction_s"]
+    r["measured_in_this_run"] = True
+    r["config"] = "1024 TDAC calibration samples (trajectory batches of 64, 20 DDIM steps, CFG 3.0, lambda 1.2) -> " \
+                  "set_{weight,act}_quantize_params_Conditional over all 1024 (batches of 32) -> 1000 iterations x %d units, batch 32, " \
+                  "shipped kwargs of sample_diffusion_ldm_imagenet.py:165-196 (input_prob 0.5, quantizer prob 0.5)" % r["units"]
+    r["peak_hbm_gb"] = torch.cuda.max_memory_allocated(dev) / 2 ** 30
+    return r
 
 
 def time_h1_contraction(dev):
@@ -288,16 +319,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-calib", action="store_true", help="skip the bounded reconstruction timing")
-    ap.add_argument("--no-decode", action="store_true", help="skip the first-stage decoder timing")
-    ap.add_argument("--full-calib", action="store_true",
-                    help="run ONLY the full calibration (1024 samples x 1000 iterations x every unit, ~10 min) and print its line")
+    ap.add_argument("--calib", choices=["full", "bounded", "none"], default="full",
+                    help="N = 1 only.  full (default): the whole calibration job at the shipped size, measured (~9 min); bounded: a 256-sample "
+                         "x 40-iteration reconstruction walk extrapolated linearly (~1 min); none")
+    ap.add_argument("--no-calib", action="store_true", help="= --calib none")
     ap.add_argument("--calib-ranks", action="store_true",
                     help="with --gpus N > 1: also time a bounded reconstruction walk with the activation caching sharded over the "
                          "ranks (all_gather_into_tensor of the cached slabs + broadcast of the learned parameters per unit)")
-    ap.add_argument("--calib-samples", type=int, default=None)
-    ap.add_argument("--calib-iters", type=int, default=None)
     args = ap.parse_args()
+    if args.no_calib:
+        args.calib = "none"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` on its own: start N ranks (one process per GPU) through torch.distributed.run as a
@@ -329,28 +360,16 @@ def main():
         ranks_seen = int(seen.item())
         assert ranks_seen == world, (ranks_seen, world)
 
-    from edadm import lib
+    from edadm import lib, ops
     lib.load()                                                # fail loudly if the HIP library is missing
     from edadm.sampling import DDIMLoop
 
     qnn, sd_cpu, calib = build_quantised_unet(dev)
-    if args.full_calib:
-        n, it = args.calib_samples or 1024, args.calib_iters or 1000
-        torch.cuda.synchronize()
-        t0 = time.time()
-        r = time_calibration(qnn, dev, n_calib=n, iters=it)
-        r["h1_contraction"] = time_h1_contraction(dev)
-        r["scale_init"] = calib
-        r["peak_hbm_gb"] = torch.cuda.max_memory_allocated(dev) / 2 ** 30
-        print(json.dumps({"metric": "full calibration+recon wall-clock, W4A8 LDM-4 ImageNet 256x256", "value": r["wall_s"],
-                          "unit": "s", "higher_is_better": False, "n_gpus": 1, "data": "synthetic", "measured": True,
-                          "config": {"workload": "%d calibration samples (CFG-doubled rows) x %d iterations x %d units, batch 32, "
-                                                 "shipped kwargs of sample_diffusion_ldm_imagenet.py:165-196" % (n, it, r["units"])},
-                          "calibration": r}))
-        return
     eng = qnn.freeze()
     B = args.batch
     loop = DDIMLoop(eng, (3, 64, 64), B, steps=20, eta=0.0, scale=3.0, context_shape=(1, 512), device=dev)
+    dec = make_decoder(dev)
+    side = torch.cuda.Stream(device=dev)
     # a batch is a pure function of (seed, global batch index) (edadm/sample_driver.py): rank r makes the batches
     # {i : i mod world = r} of the one global sequence, so the union over ranks is the same images whatever N is
     from edadm.sample_driver import batch_noise, batch_generator
@@ -360,21 +379,30 @@ def main():
     cond = torch.randn(B, 1, 512, generator=gen, device=dev)
     uncond = torch.randn(1, 1, 512, generator=gen, device=dev).expand(B, 1, 512).contiguous()
 
-    for i in range(args.warmup):
-        loop.sample(noise[i], cond, uncond)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.time()
-    for i in range(args.warmup, n_total):
-        loop.sample(noise[i], cond, uncond)
-    torch.cuda.synchronize()
-    elapsed = time.time() - t0
-    if world > 1:
-        dist.barrier()
-        tt = torch.tensor([elapsed], device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    def timed(decoder):
+        """W untimed + exactly K timed steps between barrier + synchronize on both sides; max over ranks"""
+        run_steps(loop, decoder, side, noise, cond, uncond, 0, args.warmup, dev)
+        if args.warmup == 0 and decoder is not None:
+            with torch.cuda.stream(side):
+                decoder(torch.zeros(B, 3, 64, 64, device=dev))
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.time()
+        n = run_steps(loop, decoder, side, noise, cond, uncond, args.warmup, n_total, dev)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        assert n == B * args.steps
+        if world > 1:
+            dist.barrier()
+            tt = torch.tensor([dt], device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    elapsed = timed(dec)                      # the headline: sampled AND decoded
+    elapsed_unet = timed(None)                # the quantised UNet sampling alone
+    ops.device_status()                       # a deferred in-kernel failure (persistent-GEMM hand-off timeout) raises here
 
     # roofline pass: HIP events around every int8 MFMA GEMM launch of one eager UNet call as the sampling loop issues it
     # per step (the context-only cross-attention vectors and the time-embedding rows come in precomputed, as in the step
@@ -416,15 +444,29 @@ def main():
     torch.cuda.synchronize()
     unet_ms = ev0.elapsed_time(ev1)
 
-    traffic = None
-    try:        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-        with open(os.path.join(ROOT, "profiles", "r02z_gemm_traffic.json")) as fh:
-            tj = json.load(fh)
+    traffic, traffic_src = None, None
+    for name in ("r03z_gemm_traffic.json", "r02z_gemm_traffic.json"):
+        try:        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                tj = json.load(fh)
             # bytes of all int8 GEMM launches of one UNet call / the GEMM calls timed above (a split or tail-re-tiled
             # layer is two device launches of one call)
             traffic = tj["hbm_bytes_per_launch"] * tj["launches"] / tj.get("unet_calls", 4) / max(len(i8), 1)
-    except Exception:
-        pass
+            traffic_src = "profiles/" + name
+            break
+        except Exception:
+            pass
+    decode = None
+    if world == 1:
+        try:
+            d = time_decoder(dec, dev, B)
+            d["roofline"] = {"bound": "mfma", "achieved": 3 * d["tflops_fp32"], "peak": 2516.0, "unit": "TFLOP/s",
+                             "frac": 3 * d["tflops_fp32"] / 2516.0,
+                             "note": "three f16 MFMA products per fp32 product (fp32-grade result): fp32-equivalent rate x 3 "
+                                     "against the dense f16 MFMA peak"}
+            decode = d
+        except Exception as e:
+            decode = {"error": repr(e)}
     calib_mr = None
     if world > 1 and args.calib_ranks:
         # every rank runs the walk (the loop is replicated); the caching batches are sharded and all-gathered
@@ -438,22 +480,32 @@ def main():
     if rank == 0:
         images = B * args.steps * world
         achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12
+        ips, ips_unet = images / elapsed, images / elapsed_unet
         line = {
-            "metric": "images/sec W4A8 LDM-4 ImageNet 256x256 sampling (20 DDIM steps, CFG 3.0)",
-            "value": images / elapsed, "unit": "images/sec", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps,
+            "metric": "images/sec W4A8 LDM-4 ImageNet 256x256: 20 DDIM steps x CFG 3.0 on the int8 executor AND VQ-f4 decode to pixels "
+                      "(what the reference's loop delivers per batch); full calibration wall-clock under `calibration`",
+            "value": ips, "unit": "images/sec", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "int8 (i8 MFMA, i32 accumulate; fp32 epilogues)",
+            "scaling": "weak", "vs_baseline": None, "dtype": "int8 (i8 MFMA, i32 accumulate; fp32 epilogues); decoder fp32-grade (f16 x3 MFMA)",
             "data": "synthetic",
             "config": {"workload": "ImageNet LDM-4 256x256 W4A8: 50-image batches x 20 DDIM steps x CFG (100 UNet rows/call), "
-                                   "400.9M-param cin256-v2 UNet, random-init weights, latents+context resident in HBM; the one-token "
+                                   "400.9M-param cin256-v2 UNet, random-init weights, latents+context resident in HBM, each batch decoded by "
+                                   "the VQ-f4 first stage (55.3M params, fp32) on a second stream; the one-token "
                                    "cross-attention vectors (a function of the context alone) and the time-embedding rows of "
                                    "the 20 timesteps are evaluated once per batch inside the timed sample() call, and the "
                                    "attention-free leading blocks (identical for the two halves of a guidance pair) once "
-                                   "per pair: all bit-identical to the plain evaluation; "
-                                   "first-stage VQ decode outside the hot path (SURVEY 8f-3)",
+                                   "per pair: all bit-identical to the plain evaluation",
                        "images_per_step": B, "ddim_steps": 20, "cfg_scale": 3.0, "parallelism": "dp%d (independent batches, no collective)" % world},
+            "sampling_only": {"metric": "images/sec of the quantised UNet sampling path alone (latents, not decoded)", "value": ips_unet,
+                              "ms_per_step": 1e3 * elapsed_unet / args.steps, "steps": args.steps, "warmup": args.warmup},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": I8_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / I8_PEAK_TFLOPS, "traffic": traffic,
+                         "frac": achieved / I8_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac_definition": "dominant kernel GROUP: executed flops of every int8 GEMM launch of one UNet call / their summed "
+                                            "device time (each launch re-played 5x between HIP events) / dense int8 MFMA peak",
+                         "frac_survey_8d": {"definition": "SURVEY 8(d): images/s x algorithmic FLOP/image / peak, on the per-GPU rate",
+                                            "unet_flop_per_image": 40 * UNET_GFLOP_PER_ROW * 1e9,
+                                            "sampling_only": ips_unet / world * 40 * UNET_GFLOP_PER_ROW * 1e9 / (I8_PEAK_TFLOPS * 1e12),
+                                            "sampled_and_decoded": ips / world * 40 * UNET_GFLOP_PER_ROW * 1e9 / (I8_PEAK_TFLOPS * 1e12)},
                          "algorithmic_bytes": gemm_alg_bytes / max(len(i8), 1),
                          "algorithmic_bytes_note": "per GEMM call, like `traffic`: int8 activation tensor + integer weights + output in "
                                                    "its stored type + fp32 residual, each element once (a convolution's input counted "
@@ -466,46 +518,38 @@ def main():
                                  "frac": (traffic * len(i8) / (gemm_ms * 1e-3) / 8e12) if traffic else None},
                          "unet_call_ms": unet_ms,
                          "unet_algorithmic_tflops": 2 * B * UNET_GFLOP_PER_ROW / unet_ms},
-            "calibration": calib,
+            "calibration": {"quick_scale_init_of_the_sampling_model": calib},
         }
+        if decode is not None:
+            line["first_stage_decode"] = decode
         if calib_mr is not None:
             line["calibration"]["multi_rank"] = calib_mr
-        if world == 1 and not args.no_calib:
-            try:
-                line["calibration"]["reconstruction"] = time_calibration(qnn, dev)
-                line["calibration"]["h1_contraction"] = time_h1_contraction(dev)
-                try:        # the MEASURED full run (python bench.py --full-calib, committed) next to this run's extrapolation
-                    with open(os.path.join(ROOT, "profiles", "r02z_full_calibration.json")) as fh:
-                        full = json.load(fh)["calibration"]
-                    ext = line["calibration"]["reconstruction"]["extrapolated_full_s"]["total"]
-                    line["calibration"]["measured_full_s"] = {
-                        "wall_s": full["wall_s"], "caching_s": full["caching_s"], "loop_s": full["loop_s"],
-                        "source": "profiles/r02z_full_calibration.json: 1024 samples x 1000 iterations x 80 units on one MI355X, "
-                                  "iterations replayed as HIP graphs (the first measured run of the round, "
-                                  "profiles/r02a_full_calibration.json, took 529.6 s)",
-                        "this_run_extrapolation_s": ext, "extrapolation_over_measured": ext / full["wall_s"]}
-                except Exception:
-                    pass
-            except Exception as e:
-                line["calibration"]["reconstruction"] = {"error": repr(e)}
-        if world == 1 and not args.no_decode:
-            try:
-                d = time_decoder(dev, B)
-                d["images_per_sec_unet_plus_decode"] = 1.0 / (elapsed / (B * args.steps) + d["wall_s"] / B)
-                d["roofline"] = {"bound": "mfma", "achieved": 3 * d["tflops_fp32"], "peak": 2516.0, "unit": "TFLOP/s",
-                                 "frac": 3 * d["tflops_fp32"] / 2516.0,
-                                 "note": "three f16 MFMA products per fp32 product (fp32-grade result): fp32-equivalent rate x 3 "
-                                         "against the dense f16 MFMA peak"}
-                line["first_stage_decode"] = d
-                line["end_to_end"] = end_to_end(loop, noise, cond, uncond, args, dev, B)
-            except Exception as e:
-                line["first_stage_decode"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(qnn, sd_cpu)
             except Exception as e:      # the baseline is a report, never a reason to lose the bench line
                 line["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": torch.get_num_threads(),
                                         "kind": "port", "sample": "failed: %r" % (e,)}
+        if world == 1 and args.calib != "none":
+            try:
+                if args.calib == "bounded":
+                    line["calibration"]["reconstruction_bounded"] = time_calibration(qnn, dev)
+                else:
+                    # the sampling model, its engine, graphs and the decoder leave HBM first: the job needs ~175 GB
+                    del loop, eng, dec, prof, i8
+                    qnn.engine = None
+                    qnn = None
+                    import gc
+                    gc.collect()
+                    torch.cuda.empty_cache()
+                    full = full_calibration(dev)
+                    line["calibration"].update(full)
+                    line["calibration"]["metric"] = "full calibration+recon wall-clock, W4A8 LDM-4 ImageNet 256x256, 1 x MI355X"
+                    line["calibration"]["value_s"] = full["wall_s"]
+                line["calibration"]["h1_contraction"] = time_h1_contraction(dev)
+            except Exception as e:
+                import traceback
+                line["calibration"]["error"] = repr(e) + " | " + traceback.format_exc()[-600:]
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -21,6 +21,9 @@ IMPLICIT_DGRAD = True      # input gradients of stride-1 convolutions as implici
 # large products run as ONE f16-MFMA GEMM over the two-term f16 expansion of both fp32 operands (three products,
 # fp32 accumulation: fp32-grade result at 2x the exact-fp32 MFMA's rate, csrc/elem.hip); 0 = exact-fp32 MFMA only
 F16X3 = True
+# Executed fp32-equivalent flops (2 M N K per product: forward, input gradient, weight gradient), counted on the host as
+# the products are issued -- bench.py reads the counter around one captured reconstruction iteration for H1's roofline
+FLOPS = [0.0]
 
 
 def _f16x3_linear(M, N, K):
@@ -125,6 +128,7 @@ class _LinearFn(torch.autograd.Function):
         x2p, K = _pad4(x2)
         wp, _ = _pad4(weight.contiguous())
         ctx.px = _amax(x2p)
+        FLOPS[0] += 2.0 * x2p.shape[0] * wp.shape[0] * K
         out = _matmul_nt(x2p, wp, bias, amax=ctx.px)
         ctx.save_for_backward(x2p, wp)
         ctx.meta = (x.shape, K, bias is not None)
@@ -138,6 +142,7 @@ class _LinearFn(torch.autograd.Function):
         gy2p, O = _pad4(gy2)
         pg = _amax(gy2p) if gy2p is gy2 else None
         gx = gw = gb = None
+        FLOPS[0] += 2.0 * gy2.shape[0] * wp.shape[0] * K * (int(ctx.needs_input_grad[0]) + int(ctx.needs_input_grad[1]))
         if ctx.needs_input_grad[0]:
             wT, _ = _pad4(ops.transpose_f32(wp))                                   # [Kp][O]
             gx = _matmul_nt(gy2p, wT, amax=pg)[:, :K].reshape(xshape)
@@ -170,6 +175,7 @@ class _Conv2dFn(torch.autograd.Function):
         # the im2col matrix is only rebuilt in backward, for the weight gradient
         M = B * Ho * Wo
         px = None
+        FLOPS[0] += 2.0 * M * O * KH * KW * C
         if ((M + 127) // 128) * ((O + 127) // 128) >= 128:
             if F16X3 and ops.f16x3_conv_ok(xh, w4):
                 px = _amax(xh)
@@ -192,6 +198,7 @@ class _Conv2dFn(torch.autograd.Function):
         gyh = ops.nchw_to_nhwc(gy.contiguous()).reshape(B * Ho * Wo, O)
         pg = _amax(gyh)
         gx = gw = gb = None
+        FLOPS[0] += 2.0 * B * Ho * Wo * O * KH * KW * C * (int(ctx.needs_input_grad[0]) + int(ctx.needs_input_grad[1]))
         if ctx.needs_input_grad[0]:
             M = B * Ho * Wo
             big = ((B * H * W + 127) // 128) * ((Cp + 127) // 128) >= 512      # few tiles: the split-K GEMM + col2im wins

@@ -333,9 +333,13 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
             graph = torch.cuda.CUDAGraph()
             # thread_local: with several ranks the RCCL watchdog thread polls events while this thread captures; in the default
             # (global) mode any such call from another thread invalidates the capture
+            from . import contract
+            f0 = contract.FLOPS[0]
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 ops.rng_epoch(1, add=True)
                 body()
+            if TIMING is not None:                         # executed fp32-equivalent flops of one iteration of this unit
+                TIMING["flops"] = TIMING.get("flops", 0.0) + (contract.FLOPS[0] - f0) * (iters - t_first)
             graph.replay()                                 # capture does not execute: this runs iteration `it`
             continue
         body()

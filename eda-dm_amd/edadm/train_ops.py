@@ -179,6 +179,8 @@ def _nt(a, b, alpha=1.0):
     """a [Z, M, K], b [Z, N, K] (contiguous) -> alpha * a . b^T [Z, M, N] on the exact-fp32 MFMA (edadm_gemm_f32_nt)."""
     Z, M, K = a.shape
     N = b.shape[1]
+    from . import contract
+    contract.FLOPS[0] += 2.0 * Z * M * N * K
     if K % 4:                                       # the staging moves 16-byte pieces: zero columns add nothing
         a, b = F.pad(a, (0, 4 - K % 4)), F.pad(b, (0, 4 - K % 4))
         K = a.shape[2]

@@ -102,45 +102,62 @@ def quantise(ld, args):
     return qnn
 
 
-def calibrate(args):
+def calibration_flow(args, dev, walk=None):
+    """The calibration job of sample_diffusion_ldm_imagenet.py:142-199 stage by stage: FP model -> QuantModel -> TDAC calibration
+    set -> set_{weight,act}_quantize_params_Conditional over ALL calibration samples -> conditional reconstruction walk.
+    `walk(qnn, cali, kwargs)` replaces the plain walk (bench.py passes its instrumented one).  Returns (ld, qnn, stage seconds)."""
     from scripts.calibration import TDAC_imagenet_calib_data_generator
     from qdiff_control import (set_weight_quantize_params_Conditional, set_act_quantize_params_Conditional,
                                recon_block_Qmodel)
-    from edadm import state
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
-    torch.cuda.set_device(dev)
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        torch.distributed.init_process_group("nccl")
+
+    def now():
+        torch.cuda.synchronize()
+        return time.time()
+
     ld = build_models(args, dev)
     qnn = quantise(ld, args)
     args.latent_shape = list(args.latent)
-    data = torch.randint(0, 1000, (args.calib_num_samples,), generator=torch.Generator().manual_seed(args.seed)).to(dev)
-    args.data = data
-    t0 = time.time()
+    args.data = torch.randint(0, 1000, (args.calib_num_samples,), generator=torch.Generator().manual_seed(args.seed)).to(dev)
+    t0 = now()
     cali = TDAC_imagenet_calib_data_generator(ld, args, args.calib_num_samples, args.batch_samples, dev, args.custom_steps)
-    t1 = time.time()
+    t1 = now()
     if args.split:
         qnn.model.split_shortcut = True
     set_weight_quantize_params_Conditional(ld, cali, args)
+    t2 = now()
     set_act_quantize_params_Conditional(ld, cali, args)
-    t2 = time.time()
+    t3 = now()
+    stages = {"tdac_s": t1 - t0, "weight_scale_init_s": t2 - t1, "act_scale_init_s": t3 - t2, "reconstruction_s": 0.0}
     if not args.no_recon:
         kwargs = dict(cali_data=cali, iters=args.iters, act_quant=True, asym=True, opt_mode='mse', lr_a=args.lr_a, lr_w=args.lr_w,
                       p=2.0, weight=0.0001, b_range=(20, 2), warmup=0.2, batch_size=32, input_prob=0.5, add_loss=args.add_loss,
                       recon_w=True, recon_a=True, keep_gpu=False)
         qnn.set_quant_state(True, True)
-        ld.model.diffusion_model = recon_block_Qmodel(args, qnn, cali, kwargs).recon()
+        if walk is not None:
+            walk(qnn, cali, kwargs)
+        else:
+            ld.model.diffusion_model = recon_block_Qmodel(args, qnn, cali, kwargs).recon()
     qnn.set_quant_state(True, True)
-    torch.cuda.synchronize()
-    t3 = time.time()
+    stages["reconstruction_s"] = now() - t3
+    return ld, qnn, stages
+
+
+def calibrate(args):
+    from edadm import state
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        torch.distributed.init_process_group("nccl")
+    ld, qnn, st = calibration_flow(args, dev)
     rank = int(os.environ.get("RANK", "0"))
     if rank == 0:
         os.makedirs(args.out, exist_ok=True)
         np.savez(os.path.join(args.out, "quant_state.npz"), **state.quant_state_dict(qnn))
         nbytes = state.save_frozen(qnn, os.path.join(args.out, "frozen.npz"))
         torch.save(ld.cond_stage_model.state_dict(), os.path.join(args.out, "class_embedder.pt"))
-        print(json.dumps({"job": "calibrate", "units": qnn.block_count, "tdac_s": t1 - t0, "scale_init_s": t2 - t1,
-                          "reconstruction_s": t3 - t2, "frozen_bytes": nbytes, "out": args.out}))
+        print(json.dumps({"job": "calibrate", "units": qnn.block_count, "tdac_s": st["tdac_s"],
+                          "scale_init_s": st["weight_scale_init_s"] + st["act_scale_init_s"],
+                          "reconstruction_s": st["reconstruction_s"], "frozen_bytes": nbytes, "out": args.out}))
 
 
 def sample(args):
