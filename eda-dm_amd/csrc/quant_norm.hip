@@ -105,6 +105,36 @@ extern "C" int edadm_quant_f16(const float* x, int64_t ldx, void* out, int64_t l
     return edadm_launch_status();
 }
 
+// the legacy AttentionBlock's qkv tensor [rows][heads x (q | k | v) x d] (openaimodel.py:390-393) in ONE pass: column c belongs to
+// group (c / d) % 3, each group with its own quantiser (qp[0..2]) and pre-multiplier; same layout out, f16 codes minus zero point
+__global__ void __launch_bounds__(256) k_quant_f16_qkv(const float* __restrict__ x, int64_t ldx, __half* __restrict__ out,
+                                                       int64_t ldo, int64_t rows, int64_t C, int64_t d,
+                                                       const QP* __restrict__ qp, float pm0, float pm1, float pm2) {
+    const QP q0 = qp_load(qp, 0), q1 = qp_load(qp, 1), q2 = qp_load(qp, 2);
+    const int64_t C4 = C >> 2, n = rows * C4, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t r = i / C4, c = (i - r * C4) * 4;
+        const int grp = (int)((c / d) % 3);
+        const QP& q = grp == 0 ? q0 : grp == 1 ? q1 : q2;
+        const float pm = grp == 0 ? pm0 : grp == 1 ? pm1 : pm2;
+        const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
+        const float e[4] = {v.x, v.y, v.z, v.w};
+        __half h[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) h[k] = __float2half(q_code_f(pm != 1.0f ? e[k] * pm : e[k], q) - q.z);
+        *reinterpret_cast<uint2*>(out + r * ldo + c) = *reinterpret_cast<const uint2*>(h);
+    }
+}
+extern "C" int edadm_quant_f16_qkv(const float* x, int64_t ldx, void* out, int64_t ldo, int64_t rows, int64_t C, int64_t d,
+                                   const float* qp3, float premul_q, float premul_k, float premul_v, void* stream) {
+    if (!x || !out || !qp3 || rows <= 0 || C <= 0 || d <= 0 || (d & 3) || C % (3 * d) || ldx < C || ldo < C || (ldx & 3) ||
+        (ldo & 3) || ((uintptr_t)x & 15) || ((uintptr_t)out & 7))
+        return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_quant_f16_qkv, dim3(edadm_grid(rows * C / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                       (__half*)out, ldo, rows, C, d, (const QP*)qp3, premul_q, premul_k, premul_v);
+    return edadm_launch_status();
+}
+
 // ------------------------------------------------------------------ NCHW <-> NHWC (model boundary)
 __global__ void __launch_bounds__(256) k_nchw_to_nhwc(const float* __restrict__ x, float* __restrict__ out,
                                                       int64_t B, int64_t C, int64_t HW) {

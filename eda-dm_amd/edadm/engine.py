@@ -123,6 +123,8 @@ class Engine:
         self.fuse_skip_quant = True      # skip-convolution operand written by the GroupNorm apply pass
         self.fuse_rowadd_ln = True       # broadcast add + norm3 in one pass
         self.cfg_shared_prefix = True    # a guidance pair evaluates the context-independent prefix once
+        self.fused_attention = True      # K6f for heads of d <= 160 (False: the three-kernel path with the scores in memory;
+                                         # the two differ only in the order of the fp32 row sum, i.e. in rare +-1 probability codes)
         # classifier-free guidance evaluates [x, x] with contexts [uncond, cond]: the two halves are identical until the first
         # context-dependent layer.  A sampling loop that builds the pair itself sets cfg_pair: that prefix then runs on
         # one half and its skip tensors stay at half the batch (read periodically by their consumers)
@@ -549,6 +551,19 @@ class Engine:
         kcols = kcols or [h * d for h in range(heads)]
         vcols = vcols or [h * d for h in range(heads)]
         (qpq, dq), (qpk, dk), (qpv, dv), (qpw, dw) = self._aq(aq_q), self._aq(aq_k), self._aq(aq_v), self._aq(aq_w)
+        if self.fused_attention and not v_transposed and ops.attention_fused_ok(heads, d, Nq, Nk):
+            # K6f: scores, softmax, probability codes and P V in one kernel -- no heads x Nq x Nk tensor in memory
+            oqp = out_qp if (out_qp is not None and hd % 4 == 0) else None
+            legacy = ((not coded) and q2d is k2d and k2d is v2d and q2d.shape[1] == 3 * hd
+                      and qcols == [h * 3 * d for h in range(heads)] and kcols == [c + d for c in qcols]
+                      and vcols == [c + 2 * d for c in qcols])
+            if legacy and d % 8 == 0:
+                key = ("qkv3", id(aq_q), id(aq_k), id(aq_v))
+                if key not in self._attn_cache:
+                    self._attn_cache[key] = torch.cat([qpq, qpk, qpv]).contiguous()
+                qkvh = ops.quant_f16_qkv(q2d, d, self._attn_cache[key], (premul, premul, 1.0))
+                return ops.attention_fused(qkvh, qkvh, qkvh, B, heads, Nq, Nk, d, dq * dk * scale, qpw, dw * dv, q_off=0, k_off=d,
+                                           v_off=2 * d, head_stride=3 * d, out_qp=oqp)
 
         def codes(x2d, cols, qp, rows, pm):
             out = torch.empty(rows, hd, dtype=torch.float16, device=self.dev)
@@ -567,6 +582,9 @@ class Engine:
             kh = codes(k2d, kcols, qpk, B * Nk, premul)
             vh = codes(v2d, vcols, qpv, B * Nk, 1.0)
         assert d % 8 == 0, "head dim must be a multiple of 8"
+        if self.fused_attention and not v_transposed and ops.attention_fused_ok(heads, d, Nq, Nk):
+            return ops.attention_fused(qh, kh, vh, B, heads, Nq, Nk, d, dq * dk * scale, qpw, dw * dv,
+                                       out_qp=out_qp if (out_qp is not None and hd % 4 == 0) else None)
         s = ops.gemm_f16_nt(qh, hd, Nq * hd, kh, hd, Nk * hd, B, Nq, Nk, d, dq * dk * scale, inner=heads,
                             strideA_i=d, strideB_i=d)
         nkp = (Nk + 7) // 8 * 8
@@ -731,7 +749,9 @@ class Engine:
         q = self._gemm(self.L(attn.to_q), x2d_q, B * Nq, out_mode=1, oqp=self._aq(attn.act_quantizer_q)[0])
         k = self._gemm(self.L(attn.to_k), ctx_ops[0], B * Nk, out_mode=1, oqp=self._aq(attn.act_quantizer_k)[0])
         Lv = self.L(attn.to_v)
-        vt_ok = Lv.mode == "i8" and len(Lv.segs) == 1 and ops.vt_mode_ok(B * Nk, Lv.N, Nk)
+        heads_ = attn.heads
+        fused = self.fused_attention and ops.attention_fused_ok(heads_, self.L(attn.to_q).N // heads_, Nq, Nk)
+        vt_ok = (not fused) and Lv.mode == "i8" and len(Lv.segs) == 1 and ops.vt_mode_ok(B * Nk, Lv.N, Nk)
         # the v projection writes the P.V product's B operand directly: f16 codes, transposed per image
         v = self._gemm(Lv, ctx_ops[1], B * Nk, out_mode=4 if vt_ok else 1, oqp=self._aq(attn.act_quantizer_v)[0], rpb=Nk)
         heads = attn.heads

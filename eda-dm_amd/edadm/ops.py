@@ -251,6 +251,35 @@ def quant_f16(x2d, qp, premul=1.0, out=None):
     return out
 
 
+def quant_f16_qkv(x2d, d, qp3, premuls):
+    """legacy qkv tensor [rows][heads x (q|k|v) x d] -> f16 codes, same layout, one launch (edadm_quant_f16_qkv)"""
+    rows, C = x2d.shape
+    out = torch.empty(rows, C, dtype=torch.float16, device=x2d.device)
+    lib.call("edadm_quant_f16_qkv", _pf(x2d), x2d.stride(0), ctypes.c_void_p(out.data_ptr()), C, rows, C, int(d), _pf(qp3),
+             float(premuls[0]), float(premuls[1]), float(premuls[2]), _stream())
+    return out
+
+
+def attention_fused_ok(heads, d, Nq, Nk):
+    return bool(lib.load().edadm_attention_fused_ok(int(heads), int(d), int(Nq), int(Nk)))
+
+
+def attention_fused(q, k, v, B, heads, Nq, Nk, d, alpha_qk, pqp, alpha_pv, q_off=0, k_off=0, v_off=0, head_stride=None,
+                    out_qp=None):
+    """K6f: q [B*Nq][ldq], k / v [B*Nk][ld] f16 codes (head h at column *_off + h * head_stride) -> [B*Nq][heads*d] fp32, or the
+    consumer's int8 operand with out_qp.  No score matrix in memory."""
+    hs = int(head_stride or d)
+    hd = heads * d
+    out = torch.empty(B * Nq, hd, dtype=torch.int8 if out_qp is not None else torch.float32, device=q.device)
+    esz = 2
+    lib.call("edadm_attention_fused_f16", ctypes.c_void_p(q.data_ptr() + q_off * esz), q.stride(0), Nq * q.stride(0), hs,
+             ctypes.c_void_p(k.data_ptr() + k_off * esz), k.stride(0), Nk * k.stride(0), hs,
+             ctypes.c_void_p(v.data_ptr() + v_off * esz), v.stride(0), Nk * v.stride(0), hs,
+             ctypes.c_void_p(out.data_ptr()), hd, Nq * hd, int(B), int(heads), int(Nq), int(Nk), int(d), float(alpha_qk), _pf(pqp),
+             float(alpha_pv), 2 if out_qp is not None else 0, _pf(out_qp), _stream())
+    return out
+
+
 def nchw_to_nhwc(x):
     B, C = x.shape[0], x.shape[1]
     HW = x.numel() // (B * C)

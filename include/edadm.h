@@ -252,6 +252,22 @@ int edadm_qgemm_i8_q(const int8_t* A, int64_t lda, const int8_t* Wt, int64_t ldw
                      int64_t K, const int32_t* geom, const float* scale, const float* bias,
                      const float* rowadd, int64_t rows_per_batch, const float* residual, int64_t ldr,
                      void* out, int64_t ldo, int out_mode, const float* oqp, void* stream);
+/* K6f: the whole quantised attention core in one kernel -- S = alpha_qk Qc Kc^T, P = softmax(S), Pc = quantise(P; pqp), O = alpha_pv
+ * Pc Vc -- for heads of 8 <= d <= 160 (d % 8 == 0) and any number of queries / keys >= 2: the heads x Nq x Nk score matrix is
+ * never written (quant_block.py:204-235, :119-162, :398-451; openaimodel.py:384-406).  Q [B][Nq][..], K / V [B][Nk][..]: f16 integer
+ * codes minus zero point, head h at columns h*head*.. of its tensor (d for [.., heads*d]; 3d for the legacy (q|k|v)-per-head
+ * layout, openaimodel.py:390-393; ld*, batch and head strides in elements, multiples of 8);
+ * out [B][Nq][heads*d]: fp32 (out_mode 0) or the consumer's int8 operand (out_mode 2, oqp).  edadm_attention_fused_ok: shape gate. */
+int edadm_attention_fused_ok(int64_t heads, int64_t d, int64_t Nq, int64_t Nk);
+/* the legacy AttentionBlock's qkv tensor [rows][heads x (q|k|v) x d] quantised to f16 codes in one pass, same layout: column c
+ * takes quantiser qp3[(c / d) % 3] and that group's pre-multiplier (q * scale, k * scale: openaimodel.py:391-399) */
+int edadm_quant_f16_qkv(const float* x, int64_t ldx, void* out, int64_t ldo, int64_t rows, int64_t C, int64_t d,
+                        const float* qp3, float premul_q, float premul_k, float premul_v, void* stream);
+int edadm_attention_fused_f16(const void* Q, int64_t ldq, int64_t strideQ, int64_t headQ, const void* K, int64_t ldk,
+                              int64_t strideK, int64_t headK, const void* V, int64_t ldv, int64_t strideV, int64_t headV,
+                              void* out, int64_t ldo, int64_t strideO,
+                              int64_t B, int64_t heads, int64_t Nq, int64_t Nk, int64_t d, float alpha_qk,
+                              const float* pqp, float alpha_pv, int out_mode, const float* oqp, void* stream);
 int edadm_gemm_f16_nt_q(const void* A, int64_t lda, int64_t strideA, int64_t strideA_i, const void* Bm,
                         int64_t ldb, int64_t strideB, int64_t strideB_i, void* C, int64_t ldc,
                         int64_t strideC, int64_t strideC_i, int64_t batch, int64_t inner, int64_t M,

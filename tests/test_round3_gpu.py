@@ -483,3 +483,55 @@ def test_deferred_device_status_and_rejected_misaligned_pair_output():
     rc = lib.load().edadm_qgemm_i8_q(A.data_ptr(), K, W.data_ptr(), K, M, N, K, None, scale.data_ptr(), bias.data_ptr(), None, 1,
                                      None, 0, buf.data_ptr() + 1, N // 2, 3, qp.data_ptr(), None)
     assert rc == -22
+
+
+@pytest.mark.parametrize("B,heads,d,Nq,Nk", [(2, 8, 8, 16, 16), (2, 8, 8, 16, 77), (2, 2, 16, 16, 7), (2, 8, 40, 200, 77), (2, 8, 24, 96, 96),
+                                             (1, 8, 40, 1024, 1024), (2, 8, 80, 256, 256), (1, 4, 160, 64, 64), (2, 1, 32, 130, 130)])
+def test_fused_attention_against_torch_on_the_same_codes(B, heads, d, Nq, Nk):
+    """K6f (csrc/attn.hip, edadm_attention_fused_f16): quantise -> Q K^T -> softmax -> 8-bit probability codes -> P V in one kernel,
+    no score matrix in memory (quant_block.py:204-235 / :119-162 / :398-451), against torch on the same integer codes.  The
+    products are exact; what may differ is a probability code that sits on a rounding boundary (fp32 row-sum order, last bit of
+    the exponential): outputs equal except in a small fraction of elements, each off by at most two codes' worth; also the
+    legacy (q|k|v)-per-head operand layout, the int8-operand output form, and agreement with the three-kernel path."""
+    from edadm import ops
+    from edadm.engine import Engine
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(B * 1000 + heads * 100 + d + Nk)
+    hd = heads * d
+    q, k, v = (torch.randn(B * n, hd, generator=g).to(dev) for n in (Nq, Nk, Nk))
+    mkq = lambda delta, zp: SimpleNamespace(delta=torch.tensor(delta, device=dev), zero_point=torch.tensor(float(zp), device=dev), n_levels=256)
+    aq, ak, av, aw = mkq(0.03, 128), mkq(0.031, 127), mkq(0.029, 128), mkq(1 / 255.0, 0)
+    scale = d ** -0.5
+
+    def run(fused, **kw):
+        eng = Engine.__new__(Engine)
+        eng.dev, eng._attn_cache, eng.fused_attention = dev, {}, fused
+        return eng.attention(q, k, v, B, Nq, Nk, heads, d, aq, ak, av, aw, scale, **kw)
+
+    out = run(True)
+    codes = lambda x, qz: torch.clamp(torch.round(x / qz.delta) + qz.zero_point, 0, 255) - qz.zero_point
+    sp = lambda t, n: t.reshape(B, n, heads, d).permute(0, 2, 1, 3)
+    cq, ck, cv = codes(q, aq), codes(k, ak), codes(v, av)
+    s = torch.einsum("bhid,bhjd->bhij", sp(cq, Nq).double(), sp(ck, Nk).double()) * float(aq.delta * ak.delta) * scale
+    cp = codes(torch.softmax(s.float(), -1), aw)
+    ref = (torch.einsum("bhij,bhjd->bhid", cp.double(), sp(cv, Nk).double()) * float(aw.delta * av.delta)).permute(0, 2, 1, 3).reshape(B * Nq, hd).float()
+    one_code = 128.0 * float(aw.delta * av.delta)                     # one probability code x the largest value code
+    for name, other in (("torch on the codes", ref), ("three-kernel path", run(False))):
+        diff = (out - other).abs()
+        frac = float((diff > 1e-6).float().mean())
+        print("B=%d heads=%d d=%d Nq=%d Nk=%d vs %s: %.4f %% of outputs differ, max %.2f codes" % (B, heads, d, Nq, Nk, name, 100 * frac,
+                                                                                                  float(diff.max()) / one_code))
+        assert frac < 5e-3 and float(diff.max()) <= 2.0 * one_code + 1e-6
+    # the consumer's int8 operand straight from the epilogue = quantising the fp32 output
+    oqp = ops.qp_tensor([(0.037, 131.0, 255.0)], dev)
+    got = run(True, out_qp=oqp)
+    want = ops.quant_i8(out, oqp)
+    assert got.dtype == torch.int8 and float((got != want).float().mean()) < 1e-3
+    # legacy layout: one [rows][heads x (q|k|v) x d] tensor (openaimodel.py:390-393), Nq == Nk
+    if Nq == Nk:
+        qkv = torch.stack([q.reshape(-1, heads, d), k.reshape(-1, heads, d), v.reshape(-1, heads, d)], 2).reshape(-1, 3 * hd).contiguous()
+        eng = Engine.__new__(Engine)
+        eng.dev, eng._attn_cache, eng.fused_attention = dev, {}, True
+        leg = eng.attention(qkv, qkv, qkv, B, Nq, Nk, heads, d, aq, ak, av, aw, scale, qcols=[h * 3 * d for h in range(heads)],
+                            kcols=[h * 3 * d + d for h in range(heads)], vcols=[h * 3 * d + 2 * d for h in range(heads)])
+        assert torch.equal(leg, out)
