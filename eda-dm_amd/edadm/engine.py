@@ -107,6 +107,20 @@ class FrozenLayer:
         self.K = sum(s["K"] for s in self.segs)
 
 
+def packed_w4(seg):
+    """(nibbles [N][K/2] uint8, zp4 [N]) of an int8 weight segment whose every row spans at most 16 codes -- what a 4-bit
+    quantiser leaves -- or None.  Cached on the segment; load_frozen() puts the file's own arrays there."""
+    if "w4" not in seg:
+        w = seg["w"]
+        seg["w4"] = None
+        if w.dtype == torch.int8 and w.dim() == 2 and w.shape[1] % 32 == 0:
+            lo = w.amin(dim=1).float()
+            if bool(((w.amax(dim=1).float() - lo) <= 15).all()):
+                zp = (-lo).contiguous()
+                seg["w4"] = (ops.pack_w4(w, zp), zp)
+    return seg["w4"]
+
+
 class Engine:
     def __init__(self, qnn):
         self.qnn = qnn
@@ -123,6 +137,7 @@ class Engine:
         self.fuse_skip_quant = True      # skip-convolution operand written by the GroupNorm apply pass
         self.fuse_rowadd_ln = True       # broadcast add + norm3 in one pass
         self.cfg_shared_prefix = True    # a guidance pair evaluates the context-independent prefix once
+        self.w4_gemm_max_rows = 2048     # dense 4-bit layers at M <= this read their weights as packed nibbles (K4w); 0: never
         self.fused_attention = True      # K6f for heads of d <= 160 (False: the three-kernel path with the scores in memory;
                                          # the two differ only in the order of the fp32 row sum, i.e. in rare +-1 probability codes)
         # classifier-free guidance evaluates [x, x] with contexts [uncond, cond]: the two halves are identical until the first
@@ -217,11 +232,14 @@ class Engine:
             for i, sg in enumerate(L.segs):
                 p = "%s/seg%d/" % (k, i)
                 sg["scale"] = torch.as_tensor(np.asarray(state[p + "scale"]), device=self.dev).contiguous()
+                sg.pop("w4", None)
                 if p + "w4" in state:
                     rows, cols = (int(v) for v in np.asarray(state[p + "shape"]))
                     packed = torch.as_tensor(np.asarray(state[p + "w4"]), device=self.dev)
                     zp = torch.as_tensor(np.asarray(state[p + "w4_zp"]), device=self.dev).float()
                     sg["w"] = ops.unpack_w4(packed, zp, rows, cols)
+                    if cols % 32 == 0:
+                        sg["w4"] = (packed.reshape(rows, cols // 2).contiguous(), zp.contiguous())   # the file's own nibbles feed K4w
                 else:
                     sg["w"] = torch.as_tensor(np.asarray(state[p + "w"]), device=self.dev).contiguous()
         self.graph = None
@@ -296,6 +314,20 @@ class Engine:
             return run()
         out = torch.empty(M, L.N, dtype=torch.float32, device=self.dev)
         fn = ops.qgemm_i8 if L.mode == "i8" else ops.qgemm_f16
+        if geom is None and L.mode == "i8" and len(L.segs) == 1 and 0 < M <= self.w4_gemm_max_rows and a.stride(0) % 16 == 0:
+            w4 = packed_w4(L.segs[0])
+            if w4 is not None:
+                # few rows: the weights are the traffic -- read them as the 4-bit codes they are (same bits as the int8 kernel)
+                s0 = L.segs[0]
+
+                def run():
+                    ops.qgemm_w4(a, w4[0], w4[1], M, L.N, s0["K"], s0["scale"], L.bias, out, lda=a.stride(0), rowadd=rowadd,
+                                 rows_per_batch=rpb, residual=residual)
+                if self.prof is not None:
+                    self.prof.append(("w4", L.name, M, L.N, L.K, 2.0 * M * L.N * L.K, run,
+                                      self._alg_bytes(L, a, M, 4.0 * M * L.N, residual, "dense")))
+                run()
+                return out
         if geom is not None:
             s = L.segs[0]
 

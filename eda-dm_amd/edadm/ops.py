@@ -464,6 +464,14 @@ def qgemm_i8(A, Wt, M, N, K, scale, bias, out, geom=None, lda=None, ldw=None, ro
     return out
 
 
+def qgemm_w4(A, W4, zp4, M, N, K, scale, bias, out, lda=None, rowadd=None, rows_per_batch=1, residual=None):
+    """edadm_qgemm_w4: int8 activations x packed 4-bit weights (nibbles expanded in registers), fp32 out [M][N]"""
+    lib.call("edadm_qgemm_w4", ctypes.c_void_p(A.data_ptr()), int(K if lda is None else lda), ctypes.c_void_p(W4.data_ptr()), _pf(zp4),
+             int(M), int(N), int(K), _pf(scale), _pf(bias), _pf(rowadd), int(rows_per_batch), _pf(residual), int(N), _pf(out), int(N),
+             _stream())
+    return out
+
+
 def conv3_direct_ok(B, H, W, Cin, N):
     return bool(lib.load().edadm_conv3_direct_ok(int(B), int(H), int(W), int(Cin), int(N)))
 

@@ -342,6 +342,13 @@ int edadm_conv2d_f32_nhwc(const float* x, const float* w, const float* bias, con
                           int64_t B, int64_t H, int64_t W, int64_t C, int64_t Ho, int64_t Wo, int64_t N, int KH, int KW,
                           int stride, int pad, int ups, void* stream);
 int edadm_softmax_f32(const float* s, float* out, int64_t rows, int64_t cols, void* stream);
+/* K4w: the int8 x int4 GEMM on PACKED weights (two 4-bit codes per byte as edadm_pack_w4 writes them, row n at byte n*K/2, code -
+ * zp4[n] = the int8 operand): nibbles expanded in registers into the int8 MFMA, zero points taken off through the row sums of A --
+ * the bits of edadm_qgemm_i8 on the unpacked weights at half the weight bytes.  For few-row layers (M <= ~2048: time-embedding
+ * tables, one-token context branches) where the weights are the traffic.  K % 32 == 0.  quant_layer.py:406-437. */
+int edadm_qgemm_w4(const int8_t* A, int64_t lda, const uint8_t* W4, const float* zp4, int64_t M, int64_t N, int64_t K,
+                   const float* scale, const float* bias, const float* rowadd, int64_t rows_per_batch,
+                   const float* residual, int64_t ldr, float* out, int64_t ldo, void* stream);
 int edadm_unpack_w4(const uint8_t* packed, const float* zp, int8_t* out, int64_t rows, int64_t cols,
                     void* stream);
 int edadm_pack_w4(const int8_t* w, const float* zp, uint8_t* packed, int64_t rows, int64_t cols, void* stream);

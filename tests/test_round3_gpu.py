@@ -535,3 +535,50 @@ def test_fused_attention_against_torch_on_the_same_codes(B, heads, d, Nq, Nk):
         leg = eng.attention(qkv, qkv, qkv, B, Nq, Nk, heads, d, aq, ak, av, aw, scale, qcols=[h * 3 * d for h in range(heads)],
                             kcols=[h * 3 * d + d for h in range(heads)], vcols=[h * 3 * d + 2 * d for h in range(heads)])
         assert torch.equal(leg, out)
+
+
+@pytest.mark.parametrize("M,N,K", [(100, 384, 768), (2000, 768, 192), (2000, 1920, 768), (64, 64, 32), (37, 200, 96), (2048, 576, 512)])
+def test_w4_gemm_reads_nibbles_bit_identical_to_int8(M, N, K):
+    """K4w (csrc/w4.hip, edadm_qgemm_w4): the few-row layers read their 4-bit weights as packed nibbles (the frozen file's own
+    format, edadm_pack_w4) and expand them in registers; integer arithmetic -> the bits of edadm_qgemm_i8 on the unpacked int8
+    copy, with bias, per-image row add and residual (quant_layer.py:406-437 at inference)."""
+    from edadm import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randint(-128, 128, (M, K), generator=g, dtype=torch.int8).cuda()
+    codes = torch.randint(0, 16, (N, K), generator=g)
+    zp = torch.randint(0, 16, (N,), generator=g).float()
+    W = (codes - zp[:, None].long()).to(torch.int8).cuda()
+    zp = zp.cuda()
+    scale, bias = (torch.rand(N, generator=g) * 1e-3 + 1e-4).cuda(), torch.randn(N, generator=g).cuda()
+    rpb = 50 if M % 50 == 0 else M
+    rowadd, res = torch.randn(M // rpb, N, generator=g).cuda(), torch.randn(M, N, generator=g).cuda()
+    packed = ops.pack_w4(W, zp)
+    assert torch.equal(ops.unpack_w4(packed, zp, N, K), W)
+    for kw in ({}, dict(rowadd=rowadd, rows_per_batch=rpb), dict(residual=res), dict(rowadd=rowadd, rows_per_batch=rpb, residual=res)):
+        want = ops.qgemm_i8(A, W, M, N, K, scale, bias, torch.empty(M, N, device="cuda"), **kw)
+        got = ops.qgemm_w4(A, packed, zp, M, N, K, scale, bias, torch.full((M, N), float("nan"), device="cuda"), **kw)
+        assert torch.equal(got, want), (kw.keys(), float((got - want).abs().max()))
+
+
+def test_engine_few_row_layers_take_the_nibble_path(golden):
+    """The frozen executor routes its few-row dense 4-bit layers (time embedding, one-token context branches) through K4w and the
+    network output keeps its bits; a frozen file's packed arrays feed the kernel directly after load_frozen()."""
+    from helpers import build_ldm, quantize_like_reference
+    g = golden("g13_ldm_imagenet")
+    qnn, (x, t, ctx), _ = quantize_like_reference(build_ldm(g), g, "ldm")
+    qnn.set_quant_state(True, True)
+    eng = qnn.freeze()
+    eng.prof = []
+    with torch.no_grad():
+        out_w4 = eng(x, t, ctx).clone()
+    modes = [p[0] for p in eng.prof]
+    eng.prof = None
+    assert modes.count("w4") >= 10, modes
+    eng.w4_gemm_max_rows = 0
+    with torch.no_grad():
+        out_i8 = eng(x, t, ctx)
+    assert torch.equal(out_w4, out_i8)
+    eng.w4_gemm_max_rows = 2048
+    eng.load_frozen(eng.export_frozen())
+    with torch.no_grad():
+        assert torch.equal(eng(x, t, ctx), out_i8)
