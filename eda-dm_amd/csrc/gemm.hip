@@ -1929,9 +1929,13 @@ __global__ void k_conv3_pack_w(const int8_t* __restrict__ w, int8_t* __restrict_
         reinterpret_cast<uint4*>(out)[i] = *reinterpret_cast<const uint4*>(w + src);
     }
 }
+// output-channel block of the direct kernel for a layer: 192 (the 192-multiples of LDM-4 / LDM-8), else 128 (the 128-multiples of
+// the DDPM UNet and of Stable Diffusion's 640 / 1280-channel levels); 0: neither divides N
+static int conv3_bn(int64_t N) { return N % 192 == 0 ? 192 : N % 128 == 0 ? 128 : 0; }
 extern "C" int edadm_conv3_pack_w(const int8_t* w, int8_t* out, int64_t N, int64_t Cin, void* stream) {
-    if (!w || !out || N <= 0 || Cin <= 0 || N % 192 || Cin % 64 || ((uintptr_t)w & 15) || ((uintptr_t)out & 15)) return EDADM_EINVAL;
-    hipLaunchKernelGGL(k_conv3_pack_w, dim3(edadm_grid(N * 9 * Cin / 16, 256)), dim3(256), 0, (hipStream_t)stream, w, out, N, Cin, 192);
+    const int bn = conv3_bn(N);
+    if (!w || !out || N <= 0 || Cin <= 0 || !bn || Cin % 64 || ((uintptr_t)w & 15) || ((uintptr_t)out & 15)) return EDADM_EINVAL;
+    hipLaunchKernelGGL(k_conv3_pack_w, dim3(edadm_grid(N * 9 * Cin / 16, 256)), dim3(256), 0, (hipStream_t)stream, w, out, N, Cin, bn);
     return edadm_launch_status();
 }
 // the tile the kernel takes for a shape: 256 or 128 output pixels (0: not a shape for it)
@@ -1943,7 +1947,8 @@ static int conv3_tile_fits(int64_t B, int64_t H, int64_t W, int64_t BMt) {
     return ppw >= 1 && ppw <= 4;
 }
 extern "C" int edadm_conv3_direct_tile(int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t N) {
-    if (B <= 0 || H <= 0 || W <= 0 || Cin % 64 || N % 192 || Cin < 64) return 0;
+    const int bn = conv3_bn(N);
+    if (B <= 0 || H <= 0 || W <= 0 || Cin % 64 || !bn || Cin < 64) return 0;
     if (W != 8 && W != 16 && W != 32 && W != 64) return 0;
     if (H & (H - 1)) return 0;                              // the kernel's tile arithmetic is shifts: H * W a power of two
     if (B * H * W * Cin >= (1ll << 31)) return 0;
@@ -1951,7 +1956,7 @@ extern "C" int edadm_conv3_direct_tile(int64_t B, int64_t H, int64_t W, int64_t 
     static const int64_t small = EDADM_TUNE_I("EDADM_CONV3_TILE128_BELOW", 200);
     // 256-pixel tiles unless they do not even fill one round of the 256 CUs (the 8x8 level: 125 workgroups -> 250 half-size
     // ones, 88 -> 68 us; at 300 workgroups, the 16x16 level, both tile sizes take the same time)
-    if (f128 && (!f256 || (B * H * W / 256) * (N / 192) <= small)) return 128;
+    if (f128 && (!f256 || (B * H * W / 256) * (N / bn) <= small)) return 128;
     return f256 ? 256 : 0;
 }
 extern "C" int edadm_conv3_direct_ok(int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t N) {
@@ -1970,14 +1975,18 @@ extern "C" int edadm_qconv3_i8_direct(const int8_t* A, const int8_t* Wdc, int64_
     const int64_t M = B * H * W;
     if (!rowadd) rows_per_batch = M;
     ensure_pad_rows((hipStream_t)stream);
-    if (tile == 256)
-        hipLaunchKernelGGL((k_conv3_direct<3, 2>), dim3((unsigned)(N / 192), (unsigned)(M / 256)), dim3(512), 0, (hipStream_t)stream,
-                           (const uint8_t*)A, (const uint8_t*)Wdc, M, N, (int)B, (int)H, (int)W, (int)Cin, padval, ups ? 1 : 0, scale, bias,
-                           rowadd, rows_per_batch, residual, ldr, out, ldo, gn_ws);
-    else
-        hipLaunchKernelGGL((k_conv3_direct<3, 1>), dim3((unsigned)(N / 192), (unsigned)(M / 128)), dim3(512), 0, (hipStream_t)stream,
-                           (const uint8_t*)A, (const uint8_t*)Wdc, M, N, (int)B, (int)H, (int)W, (int)Cin, padval, ups ? 1 : 0, scale, bias,
-                           rowadd, rows_per_batch, residual, ldr, out, ldo, gn_ws);
+#define CONV3_LAUNCH(TN_, TM_)                                                                                                     \
+    hipLaunchKernelGGL((k_conv3_direct<TN_, TM_>), dim3((unsigned)(N / (64 * TN_)), (unsigned)(M / (128 * TM_))), dim3(512), 0,        \
+                       (hipStream_t)stream, (const uint8_t*)A, (const uint8_t*)Wdc, M, N, (int)B, (int)H, (int)W, (int)Cin, padval,    \
+                       ups ? 1 : 0, scale, bias, rowadd, rows_per_batch, residual, ldr, out, ldo, gn_ws)
+    if (conv3_bn(N) == 192) {
+        if (tile == 256) CONV3_LAUNCH(3, 2);
+        else CONV3_LAUNCH(3, 1);
+    } else {
+        if (tile == 256) CONV3_LAUNCH(2, 2);
+        else CONV3_LAUNCH(2, 1);
+    }
+#undef CONV3_LAUNCH
     return edadm_launch_status();
 }
 #endif

@@ -114,7 +114,9 @@ def test_qgemm_transposed_f16_output(ops, B, Nk, N, K):
 # 256-pixel tiles at that level, (6, 8, 8, ...) fits 128-pixel tiles only (two images each)
 @pytest.mark.parametrize("B,H,W,Cin,N", [(3, 64, 64, 192, 192), (5, 32, 32, 384, 384), (6, 16, 16, 576, 192), (8, 8, 8, 960, 384),
                                           (2, 64, 64, 64, 192), (4, 32, 32, 1152, 384), (2, 16, 16, 128, 576),
-                                          (100, 16, 16, 128, 960), (6, 8, 8, 192, 192), (3, 16, 32, 64, 192)])
+                                          (100, 16, 16, 128, 960), (6, 8, 8, 192, 192), (3, 16, 32, 64, 192),
+                                          (4, 32, 32, 128, 128), (3, 16, 16, 256, 256), (2, 32, 32, 640, 640), (8, 8, 8, 1280, 1280),
+                                          (2, 64, 64, 320, 640)])
 def test_direct_conv3_equals_the_implicit_gemm_bit_for_bit(ops, B, H, W, Cin, N):
     """edadm_qconv3_i8_direct (input patch of a 256-pixel tile resident in LDS, weights streamed) against edadm_qgemm_i8's
     implicit-GEMM gather on the same operands: integer accumulation, same epilogue arithmetic -> identical fp32 bits, with
@@ -149,7 +151,8 @@ def test_direct_conv3_equals_the_implicit_gemm_bit_for_bit(ops, B, H, W, Cin, N)
         assert torch.equal(a, b), (ra is not None, rs is not None, float((a - b).abs().max()))
 
 
-@pytest.mark.parametrize("B,Hin,Cin,N", [(3, 32, 384, 384), (5, 16, 576, 192), (8, 4, 960, 192), (2, 8, 128, 384)])
+@pytest.mark.parametrize("B,Hin,Cin,N", [(3, 32, 384, 384), (5, 16, 576, 192), (8, 4, 960, 192), (2, 8, 128, 384), (4, 16, 1280, 1280),
+                                         (2, 16, 128, 128)])
 def test_direct_conv3_over_the_folded_upsample(ops, B, Hin, Cin, N):
     """The Upsample convolution (openaimodel.py:110-118): 3x3 over the nearest-2x upsampled tensor, which neither kernel
     writes -- the direct kernel's patch loader and the implicit GEMM's gather both read pixel (y / 2, x / 2); same bits."""
@@ -172,7 +175,7 @@ def test_direct_conv3_over_the_folded_upsample(ops, B, Hin, Cin, N):
     assert torch.equal(got.double(), ref)
 
 
-@pytest.mark.parametrize("B,H,Cin,N", [(24, 64, 192, 192), (6, 16, 576, 576), (8, 8, 960, 384)])
+@pytest.mark.parametrize("B,H,Cin,N", [(24, 64, 192, 192), (6, 16, 576, 576), (8, 8, 960, 384), (4, 32, 128, 256), (8, 8, 640, 1280)])
 def test_direct_conv3_groupnorm_partials(ops, B, H, Cin, N):
     """edadm_qconv3_i8_direct with gn_ws: per-channel (sum, sum of squares) of every 64-row slab of the output, summed in
     the epilogue's registers (128-pixel tiles -- the last two cases -- split a slab over two waves, which add up in the same
