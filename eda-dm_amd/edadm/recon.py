@@ -161,6 +161,13 @@ GRAPH_WARMUP = 2
 # runs (bench.py) in which a sample is drawn less than twice
 FP_FEAT_GB = 56.0
 FP_FEAT_FORCE = False
+# The two quantised forwards of a block iteration (block_recon.py:154 for the block-output loss, :167 for the per-module outputs,
+# each with fresh quantizer masks) take the SAME inputs: they run as ONE forward over the batch [x | x] -- the counter RNG gives
+# the two halves independent masks, rows are independent everywhere in these graphs -- so every weight-side pass (AdaRound, the
+# filters' f16 expansion, the weight-gradient GEMM) runs once instead of twice and the small levels launch half as many, twice
+# as large kernels.  Units whose wrapper checkpoints (QuantAttentionBlock; ResBlocks / transformer blocks with the flag on) keep
+# the two separate forwards: the reference recomputes only the first of them in backward (see edadm/nets/ldm_unet.py).
+BATCH_FORWARDS = True
 # parity tests: a callable (cur_inp) -> uniforms that replace the in-kernel RNG of the input mix (block_recon.py:141-145), the
 # counterpart of UniformAffineQuantizer.injected_uniform; None = the counter RNG keyed by (seed, element)
 INJECT_MIX_UNIFORM = None
@@ -273,6 +280,10 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
     graph = None
     t_first = GRAPH_WARMUP + 1 if use_graph else 1
 
+    batched = BATCH_FORWARDS and is_block and bool(hooks) and not any(
+        (type(m).__name__ == "QuantAttentionBlock") or (type(m).__name__ == "QuantResBlock" and m.use_checkpoint)
+        or (type(m).__name__ == "QuantBasicTransformerBlock" and m.checkpoint) for m in unit.modules())
+
     def body():
         idx_t = idx_buf
         cur_out = cached_outs[idx_t]
@@ -293,7 +304,12 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
             if o:
                 o.zero_grad()
         args_q = (cur_inp, temb_inp) if resblock else (cur_inp,)
-        out_quant = unit(*args_q)
+        nb = cur_out.shape[0]
+        if batched:
+            out_quant = unit(*(torch.cat([a, a]) for a in args_q))[:nb]
+            module_q = [h.out[nb:] for h in hooks]
+        else:
+            out_quant = unit(*args_q)
         m_loss = 0.0
         if is_block and hooks:
             if feats is not None:
@@ -305,8 +321,9 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
                     unit(*args_fp)
                 module_r = [h.out for h in hooks]
                 unit.set_quant_state(True, act_quant)
-            unit(*args_q)
-            module_q = [h.out for h in hooks]
+            if not batched:
+                unit(*args_q)
+                module_q = [h.out for h in hooks]
             for j in range(len(module_r) - 1):
                 m_loss = m_loss + lp_loss(module_q[j], module_r[j], p=2)
         loss = loss_func(out_quant, cur_out) + add_loss * m_loss

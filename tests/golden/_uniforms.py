@@ -31,3 +31,12 @@ class Replay:
         self.counts[key] = c + 1
         self.log.append((owner, phase, c, tuple(int(s) for s in shape)))
         return uniform(owner, phase, c, shape)
+
+    def draw_calls(self, owner, phase, shape, batch):
+        """A product call over the batch [x | x] (edadm/recon.py BATCH_FORWARDS: the two quantised forwards of a block iteration
+        as one) stands for TWO calls of the reference, in its order: the first half takes the earlier draw."""
+        shape = tuple(int(s) for s in shape)
+        if shape[0] == 2 * batch:
+            half = (batch,) + shape[1:]
+            return np.concatenate([self.draw(owner, phase, half), self.draw(owner, phase, half)])
+        return self.draw(owner, phase, shape)

@@ -44,6 +44,9 @@ def main(fixture, unit_name, ks):
         counters = {}
 
         def draw(owner, shape, per_iter):
+            shape = tuple(int(v) for v in shape)
+            if per_iter == 2 and shape[0] == 32:          # the product's batched [x | x] forward = the reference's two calls
+                return np.concatenate([draw(owner, (16,) + shape[1:], 2), draw(owner, (16,) + shape[1:], 2)])
             c = counters.get(owner, 0)
             counters[owner] = c + 1
             return _uniforms.uniform(owner, "iter", k * per_iter + c, shape)
