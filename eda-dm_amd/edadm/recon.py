@@ -168,6 +168,7 @@ FP_FEAT_FORCE = False
 # as large kernels.  Units whose wrapper checkpoints (QuantAttentionBlock; ResBlocks / transformer blocks with the flag on) keep
 # the two separate forwards: the reference recomputes only the first of them in backward (see edadm/nets/ldm_unet.py).
 BATCH_FORWARDS = True
+STATE = {"batched": False}           # whether the unit being reconstructed runs the batched form (read by the parity tests' mask replay)
 # parity tests: a callable (cur_inp) -> uniforms that replace the in-kernel RNG of the input mix (block_recon.py:141-145), the
 # counterpart of UniformAffineQuantizer.injected_uniform; None = the counter RNG keyed by (seed, element)
 INJECT_MIX_UNIFORM = None
@@ -283,6 +284,8 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
     batched = BATCH_FORWARDS and is_block and bool(hooks) and not any(
         (type(m).__name__ == "QuantAttentionBlock") or (type(m).__name__ == "QuantResBlock" and m.use_checkpoint)
         or (type(m).__name__ == "QuantBasicTransformerBlock" and m.checkpoint) for m in unit.modules())
+
+    STATE["batched"] = batched
 
     def body():
         idx_t = idx_buf

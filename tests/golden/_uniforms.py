@@ -34,9 +34,10 @@ class Replay:
 
     def draw_calls(self, owner, phase, shape, batch):
         """A product call over the batch [x | x] (edadm/recon.py BATCH_FORWARDS: the two quantised forwards of a block iteration
-        as one) stands for TWO calls of the reference, in its order: the first half takes the earlier draw."""
+        as one) stands for TWO calls of the reference, in its order: the first half takes the earlier draw.  batch: truthy when the
+        unit runs batched (edadm.recon.STATE["batched"])."""
         shape = tuple(int(s) for s in shape)
-        if shape[0] == 2 * batch:
-            half = (batch,) + shape[1:]
+        if batch and shape[0] % 2 == 0 and batch > 0:
+            half = (shape[0] // 2,) + shape[1:]
             return np.concatenate([self.draw(owner, phase, half), self.draw(owner, phase, half)])
         return self.draw(owner, phase, shape)

@@ -56,7 +56,8 @@ def test_recon_loop_index_space_reference_scales_caches_masks(golden, fixture):
             # (quant_block.py:436-441): a per-tensor quantiser, same codes -- the mask element of (i, j) is the reference's (j, i)
             tr = name.endswith(".act_quantizer_w") and isinstance(mods[name.rsplit(".", 1)[0]], QuantAttnBlock)
             m.injected_uniform = (lambda nm, tr: lambda xx: torch.from_numpy(
-                rep.draw_calls(nm, "iter", xx.shape, 16).transpose(0, 2, 1).copy() if tr else rep.draw_calls(nm, "iter", xx.shape, 16)).to(xx.device))(name, tr)
+                rep.draw_calls(nm, "iter", xx.shape, recon.STATE["batched"]).transpose(0, 2, 1).copy() if tr
+                else rep.draw_calls(nm, "iter", xx.shape, recon.STATE["batched"])).to(xx.device))(name, tr)
     cur = {"name": None}
     recon.INJECT_MIX_UNIFORM = lambda xx: torch.from_numpy(rep.draw("input_mix:" + cur["name"], "iter", xx.shape)).to(xx.device)
 
@@ -268,7 +269,7 @@ def test_church_config3_unconditional_walk_with_shipped_masks(golden):
     names = {m: nme for nme, m in qnn.named_modules()}
     for name, m in qnn.named_modules():
         if isinstance(m, UniformAffineQuantizer) and m.leaf_param:
-            m.injected_uniform = (lambda nm: lambda xx: torch.from_numpy(rep.draw_calls(nm, cur["phase"], xx.shape, 16)).to(xx.device))(name)
+            m.injected_uniform = (lambda nm: lambda xx: torch.from_numpy(rep.draw_calls(nm, cur["phase"], xx.shape, recon.STATE["batched"] and cur["phase"] == "iter")).to(xx.device))(name)
     recon.INJECT_MIX_UNIFORM = lambda xx: torch.from_numpy(rep.draw("input_mix:" + cur["name"], "iter", xx.shape)).to(xx.device)
     order, traj, idx_log = [], {}, {}
     import qdiff.block_recon as brm
@@ -318,7 +319,7 @@ def test_church_config3_unconditional_walk_with_shipped_masks(golden):
         assert np.array_equal(np.asarray(idx_log[k]), g["idx/" + k]), k
     ref_log = sorted(l for l in g["rand/log"] if "|iter|" in l)
     got_log = sorted("%s|%s|%d|%s" % (o, p, c, "x".join(map(str, s))) for o, p, c, s in rep.log if p == "iter")
-    assert got_log == ref_log
+    assert got_log == ref_log, (sorted(set(got_log) - set(ref_log))[:6], sorted(set(ref_log) - set(got_log))[:6])
     cached_units = sorted({k.split("/")[1] for k in g.files if k.startswith("cache/")}, key=len, reverse=True)
     for u in [o.split(":")[1] for o in order]:
         cached = u in cached_units

@@ -42,11 +42,17 @@ def main(fixture, unit_name, ks):
 
         # draw c of iteration k of an owner: 1 draw per iteration for layers / the input mix, 2 for a block's quantizers
         counters = {}
+        doubled = [False]                  # True while the PRODUCT runs a batched unit
 
         def draw(owner, shape, per_iter):
             shape = tuple(int(v) for v in shape)
-            if per_iter == 2 and shape[0] == 32:          # the product's batched [x | x] forward = the reference's two calls
-                return np.concatenate([draw(owner, (16,) + shape[1:], 2), draw(owner, (16,) + shape[1:], 2)])
+            if per_iter == 2 and doubled[0]:              # the product's batched [x | x] forward = the reference's two calls
+                doubled[0] = False
+                try:
+                    half = (shape[0] // 2,) + shape[1:]
+                    return np.concatenate([draw(owner, half, 2), draw(owner, half, 2)])
+                finally:
+                    doubled[0] = True
             c = counters.get(owner, 0)
             counters[owner] = c + 1
             return _uniforms.uniform(owner, "iter", k * per_iter + c, shape)
@@ -83,11 +89,13 @@ def main(fixture, unit_name, ks):
         osample = random.sample
         random.sample = lambda pop, n: idx
         try:
+            doubled[0] = kind == "block" and recon.BATCH_FORWARDS
             recon.reconstruct(qnn, getattr(qnn.model, unit_name), (cu(g["x"]), cu(g["t"])), is_block=(kind == "block"),
                               save_fn=save_fn, iters=1, act_quant=True, asym=True, opt_mode="mse", lr_a=1e-3, lr_w=5e-2, p=2.0,
                               weight=0.0001, b_range=(20, 2), warmup=0.2, batch_size=16, input_prob=input_prob, add_loss=0.8,
                               recon_w=True, recon_a=True)
         finally:
+            doubled[0] = False
             recon.FusedAdam.__init__, recon.FusedAdam.launch = oinit, olaunch
             recon.INJECT_MIX_UNIFORM = None
         # ---------------- oracle
