@@ -24,11 +24,12 @@ F16X3 = True
 # Executed fp32-equivalent flops (2 M N K per product: forward, input gradient, weight gradient), counted on the host as
 # the products are issued -- bench.py reads the counter around one captured reconstruction iteration for H1's roofline
 FLOPS = [0.0]
+F16X3_MIN_NK = 512 * 512      # smallest weight matrix (N x K) whose linear product takes the three-product f16 path
 
 
 def _f16x3_linear(M, N, K):
     """worth the two conversion passes: enough output columns per converted operand byte"""
-    return F16X3 and K % 16 == 0 and N >= 256 and N * K >= 512 * 512 and M >= 2048
+    return F16X3 and K % 16 == 0 and N >= 256 and N * K >= F16X3_MIN_NK and M >= 2048
 
 
 def _split(M, O, K):
