@@ -46,7 +46,11 @@ def _calibrate(world_rank=None):
     res, ci, co = save_inp_oup_data(qnn, qnn.model.rb, cali, True, True, batch_size=16, input_prob=True)
     random.seed(99)
     seed_mask_rng(99)
-    block_reconstruction(qnn, qnn.model.rb, cali_data=cali, iters=6, act_quant=True, asym=True, opt_mode="mse", lr_a=1e-4,
+    # iterations >= GRAPH_MIN_ITERS: from the third one on the iteration is captured into a HIP graph and replayed WHILE the
+    # process group of the two ranks is alive (capture in thread-local error mode, edadm/recon.py)
+    import edadm.recon as recon
+    recon.GRAPH_MIN_ITERS = 4
+    block_reconstruction(qnn, qnn.model.rb, cali_data=cali, iters=8, act_quant=True, asym=True, opt_mode="mse", lr_a=1e-4,
                          lr_w=5e-2, p=2.0, weight=0.0001, b_range=(20, 2), warmup=0.2, batch_size=16, input_prob=0.5,
                          add_loss=0.8, recon_w=True, recon_a=True)
     torch.cuda.synchronize()
