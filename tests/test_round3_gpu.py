@@ -583,3 +583,61 @@ def test_engine_few_row_layers_take_the_nibble_path(golden):
     eng.load_frozen(eng.export_frozen())
     with torch.no_grad():
         assert torch.equal(eng(x, t, ctx), out_i8)
+
+
+def _run_harness(mod, common, calib_args, sample_args, tmp_path, capsys, batches):
+    import json
+    out = str(tmp_path / "calib")
+    mod.main(["calibrate", "--out", out] + calib_args + common)
+    line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert line["job"] == "calibrate" and line["units"] > 5 and line["frozen_bytes"] > 0 and line["reconstruction_s"] > 0
+    saves = [str(tmp_path / "a"), str(tmp_path / "b")]
+    for save in saves:
+        mod.main(["sample", "--state", out, "--save", save] + sample_args + common)
+        line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+        assert line["job"] == "sample" and line["ranks"] == 1 and line["batches_this_rank"] == batches
+    for i in range(batches):
+        a, b = np.load("%s/batch_%06d.npy" % (saves[0], i)), np.load("%s/batch_%06d.npy" % (saves[1], i))
+        assert np.isfinite(a).all() and np.array_equal(a, b), i
+    assert not np.array_equal(np.load(saves[0] + "/batch_000000.npy"), np.load(saves[0] + "/batch_000001.npy"))
+    return line
+
+
+def test_task_harness_cifar_ddim(golden, tmp_path, capsys):
+    """scripts/sample_diffusion_ddim.py (the flow of the reference's script of that name, :265-323; BASELINE configs 1 / 2) on a
+    fixture-sized DDPM UNet: TDAC_cifar set -> scale init -> recon_block_Qmodel -> state + frozen model -> load -> DDIM sampling on
+    the int8 executor, twice with the same result."""
+    import json
+    from scripts import sample_diffusion_ddim as H
+    base = golden("g13_cifar_unet")
+    model = dict(type="simple", in_channels=3, out_ch=3, ch=int(base["cfg/ch"]), ch_mult=[int(v) for v in base["cfg/ch_mult"]],
+                 num_res_blocks=int(base["cfg/nres"]), attn_resolutions=[int(v) for v in base["cfg/attn"]], dropout=0.0,
+                 resamp_with_conv=True, image_size=int(base["cfg/res"]))
+    common = ["--model", json.dumps(model), "--timesteps", "20"]
+    _run_harness(H, common, ["--calib_num_samples", "32", "--batch_samples", "32", "--iters", "2"],
+                 ["--max_images", "16", "--n_batch", "8"], tmp_path, capsys, 2)
+
+
+def test_task_harness_church_ldm(golden, tmp_path, capsys):
+    """scripts/sample_diffusion_ldm_church.py (reference :256-311; BASELINE config 3): TDAC_church -> set_*_quantize_params_LDM ->
+    Change_LDM_model_attnblock -> unconditional walk -> state -> load (attention blocks wrapped again) -> unguided DDIM sampling."""
+    import json
+    from scripts import sample_diffusion_ldm_church as H
+    base = golden("g13_ldm_church")
+    kw = {k[4:]: (base[k].tolist() if base[k].ndim else base[k].item()) for k in base.files if k.startswith("cfg/")}
+    common = ["--unet", json.dumps(kw), "--custom_steps", "20"]
+    _run_harness(H, common, ["--calib_num_samples", "32", "--batch_samples", "8", "--iters", "2"],
+                 ["--n_samples", "8", "--batch_size", "4"], tmp_path, capsys, 2)
+
+
+def test_task_harness_txt2img_sd(golden, tmp_path, capsys):
+    """scripts/sample_txt2img.py (reference :154-283; BASELINE config 5) on a Stable-Diffusion-shaped fixture UNet (8 heads, 77-token
+    context): TDAC_coco through the PLMS sampler with guidance -> set_*_quantize_params_Stable -> conditional walk at batch 2 ->
+    state -> load -> PLMS + CFG sampling on the int8 executor (fused attention K6f on the 77-key cross-attention)."""
+    import json
+    from scripts import sample_txt2img as H
+    base = golden("g13_ldm_sd")
+    kw = {k[4:]: (base[k].tolist() if base[k].ndim else base[k].item()) for k in base.files if k.startswith("cfg/")}
+    common = ["--unet", json.dumps(kw), "--custom_steps", "30", "--H", "64", "--W", "64"]
+    _run_harness(H, common, ["--calib_num_samples", "8", "--batch_samples", "2", "--iters", "2"],
+                 ["--n_samples", "4", "--n_batch", "2"], tmp_path, capsys, 2)
