@@ -116,6 +116,22 @@ class FusedAdam:
         b1, b2 = self.betas
         self.hyper.copy_(torch.tensor([lr / (1 - b1 ** self.t), math.sqrt(1 - b2 ** self.t), b1, b2]))
 
+    def schedule(self, iters):
+        """the hyper vectors of the next `iters` steps as one device table [iters][4] (one host-to-device copy per unit): the loop
+        then feeds a step with an asynchronous device-to-device row copy and never blocks on the stream"""
+        rows = []
+        b1, b2 = self.betas
+        for k in range(iters):
+            t = self.t + k
+            lr = self.lr0 * (1 + math.cos(math.pi * t / self.t_max)) / 2
+            rows.append([lr / (1 - b1 ** (t + 1)), math.sqrt(1 - b2 ** (t + 1)), b1, b2])
+        self.table, self.t0 = torch.tensor(rows, dtype=torch.float32).to(self.hyper.device), self.t
+        return self.table
+
+    def prepare_row(self):
+        self.hyper.copy_(self.table[self.t - self.t0], non_blocking=True)
+        self.t += 1
+
     def launch(self):
         """device half: gradients into the slab (one multi-tensor copy), one kernel over the flat slab (capturable: reads
         the hyper vector from device memory)"""
@@ -337,15 +353,22 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
         for h in hooks:                       # tensors of this iteration must not outlive it (they would pin the autograd
             h.out = h.feature = None          # graph of a captured iteration past the end of the capture)
 
+    # Everything the host contributes to an iteration -- the minibatch draw, the step's learning rate and bias corrections -- is
+    # drawn / computed for ALL iterations up front (same `random.sample` sequence) and sits in device tables: an iteration is two
+    # or three asynchronous device-to-device row copies + one graph replay, the host runs ahead and the stream never drains
+    # between iterations (a pageable host-to-device copy per iteration blocked on the previous replay).
+    idx_all = torch.tensor([random.sample(range(sz), batch_size) for _ in range(iters)], dtype=torch.long).to(idx_buf.device)
+    for o in (w_opt, a_opt):
+        if o:
+            o.schedule(iters)
     for it in range(iters):
         if TIMING is not None and it == t_first:           # steady-state iterations only (bench.py): the first ones carry
             torch.cuda.synchronize()                       # allocator warm-up, lazy initialisation and the graph capture
             _t_steady = time.time()
-        idx = random.sample(range(sz), batch_size)
-        idx_buf.copy_(torch.tensor(idx))
+        idx_buf.copy_(idx_all[it], non_blocking=True)
         for o in (w_opt, a_opt):
             if o:
-                o.prepare()
+                o.prepare_row()
         if graph is not None:
             graph.replay()
             continue
