@@ -184,6 +184,7 @@ FP_FEAT_FORCE = False
 # as large kernels.  Units whose wrapper checkpoints (QuantAttentionBlock; ResBlocks / transformer blocks with the flag on) keep
 # the two separate forwards: the reference recomputes only the first of them in backward (see edadm/nets/ldm_unet.py).
 BATCH_FORWARDS = True
+BATCH_FORWARDS_BELOW_PIXELS = 4096
 STATE = {"batched": False}           # whether the unit being reconstructed runs the batched form (read by the parity tests' mask replay)
 # parity tests: a callable (cur_inp) -> uniforms that replace the in-kernel RNG of the input mix (block_recon.py:141-145), the
 # counterpart of UniformAffineQuantizer.injected_uniform; None = the counter RNG keyed by (seed, element)
@@ -301,6 +302,10 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
         (type(m).__name__ == "QuantAttentionBlock") or (type(m).__name__ == "QuantResBlock" and m.use_checkpoint)
         or (type(m).__name__ == "QuantBasicTransformerBlock" and m.checkpoint) for m in unit.modules())
 
+    # ... and only below 64 x 64: there the doubled activations (and their concatenation) cost more than the halved weight-side
+    # work and launches save (measured on LDM-4: 8x8 units 7.5 -> 5.2 ms per iteration, 16x16 and 32x32 8.9 -> 7.4, but 64x64 7.5 -> 9.2)
+    if batched and cached_outs.dim() == 4 and cached_outs.shape[-1] * cached_outs.shape[-2] >= BATCH_FORWARDS_BELOW_PIXELS:
+        batched = False
     STATE["batched"] = batched
 
     def body():
