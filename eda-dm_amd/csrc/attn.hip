@@ -9,7 +9,7 @@
 // in ONE kernel: the score matrix never exists in memory (the three-kernel path writes heads x Nq x Nk fp32 scores and reads
 // them back: 4.3 GB per 64x64 self-attention of Stable Diffusion at 8 rows, the dominant cost of configs 3 and 5).  The
 // probability codes need the FINAL row maximum and row sum before the first one can be rounded, so the kernel walks the keys
-// three times -- (A) row maximum, (B) sum of exp(s - max), (C) codes and Pc Vc -- recomputing S on the f16 MFMA each time
+// twice -- (1) row maximum and sum of exp(s - max) in the online form, (2) codes and Pc Vc -- recomputing S on the f16 MFMA each time
 // (the head dimension is small: the products are cheap; the kernel is VALU-bound on the exponentials and the rounding, which is
 // why both are the lean forms: hardware exp2, reciprocal multiply with an exact fallback next to a rounding boundary).  All
 // integer products are exact in fp32 (|Qc Kc| summed over d <= 160 stays below 2^24; codes of a probability row sum to ~255), so
@@ -53,8 +53,8 @@ k_attn_fused(const __half* __restrict__ Q, int64_t ldq, int64_t sQ, int64_t hQ, 
     constexpr int KROW = DP + 8;                  // LDS row of a key (halfs): +16 bytes spreads the banks
     constexpr int VROW = ATT_BK + 8;              // LDS row of V^T (one output dimension, ATT_BK keys)
     constexpr int DVP = DVB * 32;
-    __shared__ __half lk[ATT_BK * KROW];
-    __shared__ __half lv[DVP * VROW];
+    __shared__ __half lk_[2][ATT_BK * KROW];               // two buffers: the next block is written while this one is read,
+    __shared__ __half lv_[2][DVP * VROW];                  // one barrier per block
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 31, fh = lane >> 5;
     const int h = blockIdx.y;
@@ -90,7 +90,9 @@ k_attn_fused(const __half* __restrict__ Q, int64_t ldq, int64_t sQ, int64_t hQ, 
             if (with_v) rv[i] = ok ? *reinterpret_cast<const half8*>(Vb + (int64_t)(k0 + key) * ldv + ch * 8) : zero8;
         }
     };
-    auto lstore = [&](bool with_v) {
+    auto lstore = [&](int buf, bool with_v) {
+        __half* lk = lk_[buf];
+        __half* lv = lv_[buf];
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
             const int idx = tid + i * 256;
@@ -106,7 +108,7 @@ k_attn_fused(const __half* __restrict__ Q, int64_t ldq, int64_t sQ, int64_t hQ, 
     };
     // S^T of one staged block for this wave: 2 sub-blocks of 32 keys x this lane's query; register r of sub-block sb is key
     // 32 sb + 8 (r / 4) + 4 fh + (r % 4)
-    auto scores = [&](float16v (&acc)[2]) {
+    auto scores = [&](const __half* lk, float16v (&acc)[2]) {
 #pragma unroll
         for (int sb = 0; sb < 2; ++sb) {
             float16v c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -119,53 +121,62 @@ k_attn_fused(const __half* __restrict__ Q, int64_t ldq, int64_t sQ, int64_t hQ, 
         }
     };
     auto key_of = [&](int kb, int sb, int r) { return kb * ATT_BK + sb * 32 + 8 * (r >> 2) + 4 * fh + (r & 3); };
-    // one walk over the keys: stage block kb (loaded during block kb - 1), request block kb + 1, compute
+    // one walk over the keys: block kb is computed from LDS buffer kb & 1 while block kb + 1 (loaded from L2 during block kb - 1)
+    // is written into the other buffer and block kb + 2 is requested: one barrier per block
     auto walk = [&](bool with_v, auto&& body) {
         gload(0, with_v);
+        lstore(0, with_v);
+        __syncthreads();
+        if (nkb > 1) gload(1, with_v);
         for (int kb = 0; kb < nkb; ++kb) {
-            __syncthreads();                                      // the previous block's fragments have been read
-            lstore(with_v);
-            __syncthreads();
-            if (kb + 1 < nkb) gload(kb + 1, with_v);
             float16v acc[2];
-            scores(acc);
-            body(kb, acc, (kb + 1) * ATT_BK <= Nk);
+            scores(lk_[kb & 1], acc);
+            body(kb, acc, (kb + 1) * ATT_BK <= Nk, lv_[kb & 1]);
+            if (kb + 1 < nkb) lstore((kb + 1) & 1, with_v);
+            __syncthreads();
+            if (kb + 2 < nkb) gload(kb + 2, with_v);
         }
     };
 
-    // ---- pass A: row maximum (of the raw integer products: alpha_qk > 0)
-    float mx = -INFINITY;
-    walk(false, [&](int kb, float16v (&acc)[2], bool full) {
-#pragma unroll
-        for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (full || key_of(kb, sb, r) < Nk) mx = fmaxf(mx, acc[sb][r]);
-    });
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    // exp(alpha s - alpha max) as exp2(c s - c max), c = alpha log2(e), on the hardware exponential (v_exp_f32, 1 ulp): the accuracy
-    // class of the device exp a GPU softmax runs on; what it can move is a probability code that sits on a rounding boundary
+    // ---- walk 1: row maximum and row sum together (online form): the running sum is rescaled when the running maximum of the
+    // raw integer products (alpha_qk > 0) grows.  exp(alpha s - alpha max) is exp2(c s - c max), c = alpha log2(e), on the hardware
+    // exponential (v_exp_f32, 1 ulp): the accuracy class of the device exp a GPU softmax runs on
     const float cexp = alpha_qk * 1.44269504088896340736f;
-    const float cmax = mx * cexp;
-    // ---- pass B: row sum of exp(s - max)
-    float sum = 0.f;
-    walk(false, [&](int kb, float16v (&acc)[2], bool full) {
+    float mx = -INFINITY, sum = 0.f;
+    walk(false, [&](int kb, float16v (&acc)[2], bool full, const __half*) {
+        float bm = mx;
 #pragma unroll
         for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f(fmaf(acc[sb][r], cexp, -cmax));
-                sum += (full || key_of(kb, sb, r) < Nk) ? e : 0.f;
+                if (!full && key_of(kb, sb, r) >= Nk) acc[sb][r] = -INFINITY;
+                bm = fmaxf(bm, acc[sb][r]);
             }
+        if (bm == -INFINITY) return;                               // nothing valid yet for this lane (only past the last key)
+        sum *= __builtin_amdgcn_exp2f((mx - bm) * cexp);           // mx = -inf the first time: exp2(-inf) = 0, sum is 0 anyway
+        mx = bm;
+        const float cmax = mx * cexp;
+        float part = 0.f;
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part += __builtin_amdgcn_exp2f(fmaf(acc[sb][r], cexp, -cmax));
+        sum += part;
     });
-    sum += __shfl_xor(sum, 32, 64);
+    {   // the two lanes of a query (16 keys of every 32 each) combine
+        const float mo = __shfl_xor(mx, 32, 64), so = __shfl_xor(sum, 32, 64);
+        const float m = fmaxf(mx, mo);
+        sum = sum * __builtin_amdgcn_exp2f((mx - m) * cexp) + so * __builtin_amdgcn_exp2f((mo - m) * cexp);
+        mx = m;
+    }
+    const float cmax = mx * cexp;
     const float inv = 1.0f / (sum * pw.d);                         // e / sum / delta ~ e * inv; boundary cases redo both divisions
     const bool z0 = pw.z == 0.f;                                   // always_zero quantisers (every softmax quantiser of the reference)
-    // ---- pass C: probability codes and O^T = V^T P^T
+    // ---- walk 2: probability codes and O^T = V^T P^T
     float16v o[DVB];
 #pragma unroll
     for (int j = 0; j < DVB; ++j) o[j] = float16v{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    walk(true, [&](int kb, float16v (&acc)[2], bool full) {
+    walk(true, [&](int kb, float16v (&acc)[2], bool full, const __half* lv) {
 #pragma unroll
         for (int sb = 0; sb < 2; ++sb) {
             float r_[16];
