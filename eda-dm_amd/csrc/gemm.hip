@@ -1888,6 +1888,10 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
             }
         }
     }
+    // N a multiple of 64 but not of BN (Stable Diffusion's 320 channels on the 128-column tile): the last tile is padded with zero
+    // filters and the waves whose 32 TN columns lie beyond N have nothing to store (a terminated wave leaves the workgroup's
+    // barrier count: the TM = 1 hand-over barrier below only joins waves of the same column half)
+    if (n0 + wn * (TN * 32) >= N) return;
     EpiRegs<TN> er;
     load_epi_regs<TN, BN>(er, ec, lane, m0, m0 + wm * (TM * 32), wn * (TN * 32), rows_per_batch);
     // gn_ws [M / (32 TM)][N][2]: per-channel (sum, sum of squares) of each wave-slab of this output (64 rows, 32 with 128-pixel
@@ -1914,7 +1918,8 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
 // Weight layout of k_conv3_direct from the engine's [N][ky][kx][ci] int8 filter: [N / BN][Cin / 64][ky][kx][BN][64] with
 // the 16-byte chunks of a row at physical position chunk ^ ((n >> 2) & 3) (n = row inside the BN block).
 __global__ void k_conv3_pack_w(const int8_t* __restrict__ w, int8_t* __restrict__ out, int64_t N, int64_t Cin, int BN) {
-    const int64_t total = N * 9 * Cin / 16;                 // 16-byte chunks
+    const int64_t Np = (N + BN - 1) / BN * BN;              // the last block is padded with zero filters
+    const int64_t total = Np * 9 * Cin / 16;                // 16-byte chunks
     const int64_t NC = Cin / 64;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         // destination coordinates
@@ -1926,16 +1931,22 @@ __global__ void k_conv3_pack_w(const int8_t* __restrict__ w, int8_t* __restrict_
         const int64_t c = r % NC, nt = r / NC;
         const int lc = pc ^ ((n >> 2) & 3);
         const int64_t src = (((nt * BN + n) * 3 + ky) * 3 + kx) * Cin + c * 64 + lc * 16;
-        reinterpret_cast<uint4*>(out)[i] = *reinterpret_cast<const uint4*>(w + src);
+        reinterpret_cast<uint4*>(out)[i] = nt * BN + n < N ? *reinterpret_cast<const uint4*>(w + src) : make_uint4(0u, 0u, 0u, 0u);
     }
 }
 // output-channel block of the direct kernel for a layer: 192 (the 192-multiples of LDM-4 / LDM-8), else 128 (the 128-multiples of
 // the DDPM UNet and of Stable Diffusion's 640 / 1280-channel levels); 0: neither divides N
-static int conv3_bn(int64_t N) { return N % 192 == 0 ? 192 : N % 128 == 0 ? 128 : 0; }
+// 64-multiples above 128 that neither divides (SD's 320) take the 128-column tile with a padded last block
+static int conv3_bn(int64_t N) { return N % 192 == 0 ? 192 : N % 128 == 0 ? 128 : (N % 64 == 0 && N > 128) ? 128 : 0; }
+extern "C" int64_t edadm_conv3_packed_rows(int64_t N) {
+    const int bn = conv3_bn(N);
+    return bn ? (N + bn - 1) / bn * bn : 0;
+}
 extern "C" int edadm_conv3_pack_w(const int8_t* w, int8_t* out, int64_t N, int64_t Cin, void* stream) {
     const int bn = conv3_bn(N);
     if (!w || !out || N <= 0 || Cin <= 0 || !bn || Cin % 64 || ((uintptr_t)w & 15) || ((uintptr_t)out & 15)) return EDADM_EINVAL;
-    hipLaunchKernelGGL(k_conv3_pack_w, dim3(edadm_grid(N * 9 * Cin / 16, 256)), dim3(256), 0, (hipStream_t)stream, w, out, N, Cin, bn);
+    hipLaunchKernelGGL(k_conv3_pack_w, dim3(edadm_grid(edadm_conv3_packed_rows(N) * 9 * Cin / 16, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       out, N, Cin, bn);
     return edadm_launch_status();
 }
 // the tile the kernel takes for a shape: 256 or 128 output pixels (0: not a shape for it)
@@ -1956,7 +1967,7 @@ extern "C" int edadm_conv3_direct_tile(int64_t B, int64_t H, int64_t W, int64_t 
     static const int64_t small = EDADM_TUNE_I("EDADM_CONV3_TILE128_BELOW", 200);
     // 256-pixel tiles unless they do not even fill one round of the 256 CUs (the 8x8 level: 125 workgroups -> 250 half-size
     // ones, 88 -> 68 us; at 300 workgroups, the 16x16 level, both tile sizes take the same time)
-    if (f128 && (!f256 || (B * H * W / 256) * (N / bn) <= small)) return 128;
+    if (f128 && (!f256 || (B * H * W / 256) * ((N + bn - 1) / bn) <= small)) return 128;
     return f256 ? 256 : 0;
 }
 extern "C" int edadm_conv3_direct_ok(int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t N) {
@@ -1976,7 +1987,7 @@ extern "C" int edadm_qconv3_i8_direct(const int8_t* A, const int8_t* Wdc, int64_
     if (!rowadd) rows_per_batch = M;
     ensure_pad_rows((hipStream_t)stream);
 #define CONV3_LAUNCH(TN_, TM_)                                                                                                     \
-    hipLaunchKernelGGL((k_conv3_direct<TN_, TM_>), dim3((unsigned)(N / (64 * TN_)), (unsigned)(M / (128 * TM_))), dim3(512), 0,        \
+    hipLaunchKernelGGL((k_conv3_direct<TN_, TM_>), dim3((unsigned)((N + 64 * TN_ - 1) / (64 * TN_)), (unsigned)(M / (128 * TM_))), dim3(512), 0, \
                        (hipStream_t)stream, (const uint8_t*)A, (const uint8_t*)Wdc, M, N, (int)B, (int)H, (int)W, (int)Cin, padval,    \
                        ups ? 1 : 0, scale, bias, rowadd, rows_per_batch, residual, ldr, out, ldo, gn_ws)
     if (conv3_bn(N) == 192) {

@@ -484,7 +484,8 @@ def conv3_direct_tile(B, H, W, Cin, N):
 
 def conv3_pack_w(w_i8, N, Cin):
     """[N][3][3][Cin] int8 filter -> the layout of edadm_qconv3_i8_direct ([N/192][Cin/64][3][3][192][64], chunks swizzled)."""
-    out = torch.empty(N * 9 * Cin, dtype=torch.int8, device=w_i8.device)
+    rows = int(lib.load().edadm_conv3_packed_rows(int(N)))
+    out = torch.empty(rows * 9 * Cin, dtype=torch.int8, device=w_i8.device)
     lib.call("edadm_conv3_pack_w", _p(w_i8, torch.int8), _p(out, torch.int8), int(N), int(Cin), _stream())
     return out
 

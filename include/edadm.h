@@ -371,6 +371,9 @@ int edadm_rng_epoch(uint64_t value, int add, void* stream);
  * gn_ws (or NULL): [M / 64][N][2] per-channel (sum, sum of squares) of every 64-row slab of the output, written from the
  * epilogue's registers in an order that does not depend on the tile -- the partials edadm_groupnorm_final_cat reduces
  * (H * W % 64 == 0). */
+/* rows of the packed filter edadm_conv3_pack_w writes for N output channels (N rounded up to the kernel's 192- or 128-column
+ * block; the padding rows are zero filters): the caller allocates rows * 9 * Cin bytes.  0: no direct kernel for this N. */
+int64_t edadm_conv3_packed_rows(int64_t N);
 int edadm_conv3_pack_w(const int8_t* w, int8_t* out, int64_t N, int64_t Cin, void* stream);
 int edadm_conv3_direct_ok(int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t N);
 int edadm_conv3_direct_tile(int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t N);

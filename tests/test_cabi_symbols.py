@@ -33,8 +33,8 @@ def test_bad_arguments_return_errno_not_crash():
 
 def test_direct_conv_shape_gate():
     """edadm_conv3_direct_ok (host only): the shapes the direct 3x3 kernel takes -- 64-channel chunks, 192-column blocks (LDM-4 /
-    LDM-8) or 128-column ones (the DDPM UNet, Stable Diffusion's 640 / 1280-channel levels; its 320-channel level stays on the
-    implicit GEMM), widths 8 .. 64, power-of-two heights (its tile arithmetic is shifts), whole tiles of 256 or 128 pixels."""
+    LDM-8) or 128-column ones (the DDPM UNet, Stable Diffusion's 640 / 1280-channel levels; its 320-channel level takes the
+    128-column tile with a zero-padded last block), widths 8 .. 64, power-of-two heights (its tile arithmetic is shifts), whole tiles of 256 or 128 pixels."""
     from edadm import lib
     ok = lib.load().edadm_conv3_direct_ok
     for B, H, W, Cin, N, want in ((100, 64, 64, 192, 192, 1), (100, 8, 8, 960, 960, 1), (4, 16, 16, 576, 192, 1),
@@ -42,7 +42,7 @@ def test_direct_conv_shape_gate():
                                   (6, 8, 8, 960, 960, 1),       # ... 6 fill 128-pixel ones
                                   (2, 96, 64, 64, 192, 0),      # height no power of two
                                   (2, 64, 48, 64, 192, 0), (2, 64, 64, 96, 192, 0), (2, 64, 64, 64, 128, 1),
-                                  (8, 32, 32, 640, 640, 1), (8, 16, 16, 2560, 1280, 1), (8, 64, 64, 320, 320, 0), (500, 32, 32, 128, 128, 1),
+                                  (8, 32, 32, 640, 640, 1), (8, 16, 16, 2560, 1280, 1), (8, 64, 64, 320, 320, 1), (8, 64, 64, 320, 96, 0), (500, 32, 32, 128, 128, 1),
                                   (2, 64, 64, 64, 64, 0)):
         assert ok(B, H, W, Cin, N) == want, (B, H, W, Cin, N)
     tile = lib.load().edadm_conv3_direct_tile

@@ -116,7 +116,8 @@ def test_qgemm_transposed_f16_output(ops, B, Nk, N, K):
                                           (2, 64, 64, 64, 192), (4, 32, 32, 1152, 384), (2, 16, 16, 128, 576),
                                           (100, 16, 16, 128, 960), (6, 8, 8, 192, 192), (3, 16, 32, 64, 192),
                                           (4, 32, 32, 128, 128), (3, 16, 16, 256, 256), (2, 32, 32, 640, 640), (8, 8, 8, 1280, 1280),
-                                          (2, 64, 64, 320, 640)])
+                                          (2, 64, 64, 320, 640), (2, 64, 64, 320, 320), (1, 16, 16, 320, 320), (2, 32, 32, 640, 320),
+                                          (4, 8, 8, 64, 192)])
 def test_direct_conv3_equals_the_implicit_gemm_bit_for_bit(ops, B, H, W, Cin, N):
     """edadm_qconv3_i8_direct (input patch of a 256-pixel tile resident in LDS, weights streamed) against edadm_qgemm_i8's
     implicit-GEMM gather on the same operands: integer accumulation, same epilogue arithmetic -> identical fp32 bits, with
@@ -175,7 +176,7 @@ def test_direct_conv3_over_the_folded_upsample(ops, B, Hin, Cin, N):
     assert torch.equal(got.double(), ref)
 
 
-@pytest.mark.parametrize("B,H,Cin,N", [(24, 64, 192, 192), (6, 16, 576, 576), (8, 8, 960, 384), (4, 32, 128, 256), (8, 8, 640, 1280)])
+@pytest.mark.parametrize("B,H,Cin,N", [(24, 64, 192, 192), (6, 16, 576, 576), (8, 8, 960, 384), (4, 32, 128, 256), (8, 8, 640, 1280), (2, 32, 320, 320), (4, 16, 640, 320)])
 def test_direct_conv3_groupnorm_partials(ops, B, H, Cin, N):
     """edadm_qconv3_i8_direct with gn_ws: per-channel (sum, sum of squares) of every 64-row slab of the output, summed in
     the epilogue's registers (128-pixel tiles -- the last two cases -- split a slab over two waves, which add up in the same
