@@ -49,10 +49,14 @@ def _calibrate(world_rank=None):
     # iterations >= GRAPH_MIN_ITERS: from the third one on the iteration is captured into a HIP graph and replayed WHILE the
     # process group of the two ranks is alive (capture in thread-local error mode, edadm/recon.py)
     import edadm.recon as recon
+    old = recon.GRAPH_MIN_ITERS
     recon.GRAPH_MIN_ITERS = 4
-    block_reconstruction(qnn, qnn.model.rb, cali_data=cali, iters=8, act_quant=True, asym=True, opt_mode="mse", lr_a=1e-4,
-                         lr_w=5e-2, p=2.0, weight=0.0001, b_range=(20, 2), warmup=0.2, batch_size=16, input_prob=0.5,
-                         add_loss=0.8, recon_w=True, recon_a=True)
+    try:
+        block_reconstruction(qnn, qnn.model.rb, cali_data=cali, iters=8, act_quant=True, asym=True, opt_mode="mse", lr_a=1e-4,
+                             lr_w=5e-2, p=2.0, weight=0.0001, b_range=(20, 2), warmup=0.2, batch_size=16, input_prob=0.5,
+                             add_loss=0.8, recon_w=True, recon_a=True)
+    finally:
+        recon.GRAPH_MIN_ITERS = old
     torch.cuda.synchronize()
     return {"inp_q": ci[0][0].cpu().numpy(), "temb_q": ci[0][1].cpu().numpy(), "inp_fp": ci[1][0].cpu().numpy(),
             "out_fp": co.cpu().numpy(), "alpha": qnn.model.rb.conv1.weight_quantizer.alpha.detach().cpu().numpy(),
