@@ -54,19 +54,20 @@ for args in ((2, 1, 32, 16, 16), (2, 2, 16, 16, 16), (2, 2, 16, 16, 7), (2, 8, 8
     case(*args)
 
 
-def timing(B, heads, d, N, label):
+def timing(B, heads, d, N, label, Nk=None):
     """fused K6f vs the three-kernel path on coded f16 operands"""
     import time
     g = torch.Generator().manual_seed(1)
     hd = heads * d
-    mk = lambda: torch.randint(-120, 120, (B * N, hd), generator=g).to(dev).half()
-    qh, kh, vh = mk(), mk(), mk()
+    Nk = Nk or N
+    mk = lambda n: torch.randint(-120, 120, (B * n, hd), generator=g).to(dev).half()
+    qh, kh, vh = mk(N), mk(Nk), mk(Nk)
     aq, ak, av, aw = q_(0.03, 128), q_(0.031, 127), q_(0.029, 128), q_(1 / 255.0, 0)
     res = {}
     for fused in (True, False):
         eng = Engine.__new__(Engine)
         eng.dev, eng._attn_cache, eng.fused_attention = dev, {}, fused
-        f = lambda: eng.attention(qh, kh, vh, B, N, N, heads, d, aq, ak, av, aw, d ** -0.5, coded=True)
+        f = lambda: eng.attention(qh, kh, vh, B, N, Nk, heads, d, aq, ak, av, aw, d ** -0.5, coded=True)
         out = f()
         torch.cuda.synchronize()
         t0 = time.time()
@@ -84,3 +85,4 @@ timing(8, 8, 40, 4096, "SD 64x64 self-attention (8 rows, 8 heads x 40, 4096 keys
 timing(8, 8, 80, 1024, "SD 32x32 self-attention (8 rows, 8 heads x 80, 1024 keys)")
 timing(100, 8, 24, 1024, "Church 32x32 attention (100 rows, 8 heads x 24, 1024 keys)")
 timing(100, 8, 48, 256, "Church 16x16 attention (100 rows, 8 heads x 48, 256 keys)")
+timing(8, 8, 40, 4096, "SD 64x64 cross-attention (8 rows, 8 heads x 40, 4096 queries x 77 keys)", Nk=77)
