@@ -67,10 +67,29 @@ class DecoderEngine:
         N = H * W
         h = self.gn(blk.norm, x, False)
         q, k, v = (self.conv(m, h).reshape(B, N, C) for m in (blk.q, blk.k, blk.v))
-        s = ops.gemm_f32_nt(q, k, N, N, C, alpha=int(C) ** (-0.5), batch=B, strideA=N * C, strideB=N * C, strideC=N * N)
-        p = ops.softmax_f32(s.reshape(B * N, N)).reshape(B, N, N)
         vt = ops.nhwc_to_nchw(v.reshape(B, N, 1, C)).reshape(B, C, N)                  # [B][C][N]: B operand of p . v
-        o = ops.gemm_f32_nt(p, vt, N, C, N, batch=B, strideA=N * N, strideB=C * N, strideC=N * C)
+        if F16X3 and C % 16 == 0 and N % 16 == 0 and N >= 1024:
+            # the two products of a 4096-token, 512-channel attention are 17 GFLOP each per image: on the three-product f16 path
+            # (fp32-grade, section 4 of DESIGN.md) like the convolutions, per image through edadm_qgemm_f16x3 on pre-expanded
+            # operands; the probabilities lie in [0, 1], so their expansion needs no maximum scan
+            ka, inv_k, _ = ops.split_f16(k.reshape(B * N, C), B * N, 1, C, 2, False)
+            qa, _, comb = ops.split_f16(q.reshape(B * N, C), B * N, 1, C, 2, False, other=inv_k, N=N)
+            comb = comb * (int(C) ** (-0.5))
+            s = torch.empty(B, N, N, dtype=torch.float32, device=x.device)
+            for i in range(B):
+                ops.qgemm_f16x3_pre(qa[i * N:(i + 1) * N], 2 * C, ka[i * N:(i + 1) * N], 2 * C, N, N, 2 * C, comb, s[i])
+            p = ops.softmax_f32(s.reshape(B * N, N))
+            if ("one", x.device) not in self._wc:
+                self._wc[("one", x.device)] = torch.ones(1024, dtype=torch.float32, device=x.device)
+            vta, inv_v, _ = ops.split_f16(vt.reshape(B * C, N), B * C, 1, N, 2, False)
+            pa, _, comb2 = ops.split_f16(p, B * N, 1, N, 2, False, other=inv_v, N=C, amax=self._wc[("one", x.device)])
+            o = torch.empty(B, N, C, dtype=torch.float32, device=x.device)
+            for i in range(B):
+                ops.qgemm_f16x3_pre(pa[i * N:(i + 1) * N], 2 * N, vta[i * C:(i + 1) * C], 2 * N, N, C, 2 * N, comb2, o[i])
+        else:
+            s = ops.gemm_f32_nt(q, k, N, N, C, alpha=int(C) ** (-0.5), batch=B, strideA=N * C, strideB=N * C, strideC=N * N)
+            p = ops.softmax_f32(s.reshape(B * N, N)).reshape(B, N, N)
+            o = ops.gemm_f32_nt(p, vt, N, C, N, batch=B, strideA=N * N, strideB=C * N, strideC=N * C)
         return self.conv(blk.proj_out, o.reshape(B, H, W, C), residual=x)
 
     def nearest_code(self, z_nhwc):

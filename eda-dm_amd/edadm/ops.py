@@ -693,6 +693,14 @@ def matmul_f16x3_nt(a2d, w2d, bias=None, residual=None, amax=None):
     return out
 
 
+def qgemm_f16x3_pre(xa, lda, wb, ldw, M, N, K2, comb, out, residual=None):
+    """edadm_qgemm_f16x3 on operands that are ALREADY two-term expansions (edadm_split_f16 order 2): out[M][N] = comb[n] * xa . wb^T
+    (+ residual), three f16 products per K-slice.  xa / wb may be row views of larger expansions (pointer offsets)."""
+    lib.call("edadm_qgemm_f16x3", ctypes.c_void_p(xa.data_ptr()), int(lda), ctypes.c_void_p(wb.data_ptr()), int(ldw), int(M), int(N),
+             int(K2), None, _pf(comb), None, _pf(residual), int(N), _pf(out), int(N), _stream())
+    return out
+
+
 def gemm_f16x3_nt(A, lda, strideA, Bm, ldb, strideB, batch, M, N, K2):
     """C[z] = A[z] . B[z]^T over order-2 expansions (edadm_gemm_f16x3_nt): the weight gradient's split-K slabs."""
     out = torch.empty(batch, M, N, dtype=torch.float32, device=A.device)
