@@ -822,6 +822,192 @@ extern "C" int edadm_split_f16(const float* x, int64_t R, int64_t T, int64_t C, 
     return edadm_launch_status();
 }
 
+// ---- GroupNorm (+ swish) of an NHWC fp32 tensor written straight as the order-2 expansion (first-stage decoder) ----
+// The stand-alone route is four passes over the normalised tensor y (apply: write; maximum scan: read; expansion: read, write).
+// The power-of-two scale of the expansion only needs max|y|, and y = a_c x + b_c is monotone in x per channel: with the
+// per-channel MINIMUM and MAXIMUM of x next to the (sum, sum of squares) partials, the extremes of y are the images of the
+// extremes of x -- max|y| is known before y is formed (under swish: the images of the end points, and the constant minimum
+// -0.2785 of z sigmoid(z) when the range straddles it).  Passes: partials (read x), apply + expansion (read x, write f16).
+// ws: [B][nchunk][C][4] partials | [B][G][2] stats | 1024 bound slots
+static int gnx_chunks_h(int64_t B, int64_t HW) {
+    int64_t n = HW / 32, cap = 4096 / (B < 1 ? 1 : B);
+    if (cap < 1) cap = 1;
+    if (n > cap) n = cap;
+    return (int)(n < 1 ? 1 : n);
+}
+__global__ void __launch_bounds__(256) k_gnx_partial(const float* __restrict__ x, float* __restrict__ ws, int64_t HW, int64_t C,
+                                                     int nchunk) {
+    extern __shared__ float sm[];                                     // [RS][C][4]
+    const int64_t b = blockIdx.y;
+    const int chunk = blockIdx.x;
+    const int64_t r0 = HW * chunk / nchunk, r1 = HW * (chunk + 1) / nchunk;
+    const int Q = (int)(C >> 2), RS = 256 / Q;
+    const int q = threadIdx.x % Q, rs = threadIdx.x / Q;
+    const float4* xa = reinterpret_cast<const float4*>(x) + b * HW * Q;
+    float s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0}, mn[4] = {INFINITY, INFINITY, INFINITY, INFINITY},
+          mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    auto acc = [&](const float4 v) {
+        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s[j] += e[j];
+            ss[j] += e[j] * e[j];
+            mn[j] = fminf(mn[j], e[j]);
+            mx[j] = fmaxf(mx[j], e[j]);
+        }
+    };
+    if (rs < RS) {
+        int64_t r = r0 + rs;
+        for (; r + 3 * RS < r1; r += 4 * RS) {                        // four 16-byte loads in flight per lane
+            const float4 v0 = xa[r * Q + q], v1 = xa[(r + RS) * Q + q], v2 = xa[(r + 2 * RS) * Q + q], v3 = xa[(r + 3 * RS) * Q + q];
+            acc(v0); acc(v1); acc(v2); acc(v3);
+        }
+        for (; r < r1; r += RS) acc(xa[r * Q + q]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float* o = sm + ((int64_t)rs * C + q * 4 + j) * 4;
+            o[0] = s[j]; o[1] = ss[j]; o[2] = mn[j]; o[3] = mx[j];
+        }
+    }
+    __syncthreads();
+    float* wb = ws + ((b * nchunk + chunk) * C) * 4;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = 0.f, bq = 0.f, lo = INFINITY, hi = -INFINITY;
+        for (int r = 0; r < RS; ++r) {
+            const float* o = sm + ((int64_t)r * C + c) * 4;
+            a += o[0]; bq += o[1]; lo = fminf(lo, o[2]); hi = fmaxf(hi, o[3]);
+        }
+        reinterpret_cast<float4*>(wb)[c] = make_float4(a, bq, lo, hi);
+    }
+}
+__global__ void __launch_bounds__(64) k_gnx_final(const float* __restrict__ ws, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, float* __restrict__ stats,
+                                                  float* __restrict__ bound, int64_t HW, int64_t C, int64_t G, int nchunk,
+                                                  float eps, int silu) {
+    const int64_t b = blockIdx.y, g = blockIdx.x;
+    const int cpg = (int)(C / G);
+    const int items = nchunk * cpg;
+    const float4* w4 = reinterpret_cast<const float4*>(ws);
+    double s = 0.0, ss = 0.0;
+    for (int i = threadIdx.x; i < items; i += 64) {
+        const int ch = i / cpg, c = (int)(g * cpg) + i % cpg;
+        const float4 p = w4[(b * nchunk + ch) * C + c];
+        s += (double)p.x;
+        ss += (double)p.y;
+    }
+    s = wave_sum_d(s);
+    ss = wave_sum_d(ss);
+    const double n = (double)HW * cpg;
+    const double mean_d = s / n;
+    double var = ss / n - mean_d * mean_d;
+    if (var < 0) var = 0;
+    const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (threadIdx.x == 0) {
+        stats[(b * G + g) * 2] = mean;
+        stats[(b * G + g) * 2 + 1] = rstd;
+    }
+    float m = 0.f;
+    for (int i = threadIdx.x; i < items; i += 64) {
+        const int ch = i / cpg, c = (int)(g * cpg) + i % cpg;
+        const float4 p = w4[(b * nchunk + ch) * C + c];
+        const float a = rstd * gamma[c], bb = beta[c] - mean * a;
+        float z1 = p.z * a + bb, z2 = p.w * a + bb;      // k_gn_apply's arithmetic (this file is built with contraction off)
+        if (!(p.z <= p.w)) continue;                                   // a chunk without rows
+        if (silu) {
+            const float lo = fminf(z1, z2), hi = fmaxf(z1, z2);
+            if (lo < -1.2785f && hi > -1.2785f) m = fmaxf(m, 0.2785f);
+            z1 = silu_rcp(z1);
+            z2 = silu_rcp(z2);
+        }
+        m = fmaxf(m, fmaxf(fabsf(z1), fabsf(z2)));
+    }
+    m = wave_max(m);
+    const int64_t slot = b * G + g;
+    if (threadIdx.x == 0) bound[slot] = m;
+    // consumers scan all EDADM_RED_BLOCKS slots: the first block clears the ones no (image, group) owns
+    if (slot == 0)
+        for (int64_t i = (int64_t)gridDim.x * gridDim.y + threadIdx.x; i < EDADM_RED_BLOCKS; i += 64) bound[i] = 0.f;
+}
+__global__ void __launch_bounds__(256) k_gnx_apply_split(const float* __restrict__ x, const float* __restrict__ stats,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* __restrict__ bound, int64_t HW, int64_t C, int64_t G,
+                                                         int nchunk, int silu, uint2* __restrict__ out, float* __restrict__ inv,
+                                                         const float* __restrict__ other, int64_t n_other,
+                                                         float* __restrict__ comb, int64_t N) {
+    __shared__ float sm[4];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < EDADM_RED_BLOCKS; i += 256) m = fmaxf(m, bound[i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    float sc, iv;
+    split_scale(fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3])), sc, iv);
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        if (threadIdx.x == 0) inv[0] = iv;
+        if (comb)
+            for (int64_t n = threadIdx.x; n < N; n += 256) comb[n] = iv * other[n_other == 1 ? 0 : n];
+    }
+    const int64_t b = blockIdx.y;
+    const int chunk = blockIdx.x;
+    const int64_t r0 = HW * chunk / nchunk, r1 = HW * (chunk + 1) / nchunk;
+    const int Q = (int)(C >> 2), RS = 256 / Q;
+    const int q = threadIdx.x % Q, rs = threadIdx.x / Q;
+    if (rs >= RS) return;
+    const int cpg = (int)(C / G);
+    float a[4], bb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = q * 4 + j, g = c / cpg;
+        const float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
+        a[j] = rstd * gamma[c];
+        bb[j] = beta[c] - mean * a[j];
+    }
+    const float4* xa = reinterpret_cast<const float4*>(x) + b * HW * Q;
+    uint2* ob = out + b * HW * 2 * Q + (q >> 2) * 8 + (q & 3);
+    auto one = [&](const float4 v, int64_t r) {
+        float y[4] = {v.x * a[0] + bb[0], v.y * a[1] + bb[1], v.z * a[2] + bb[2], v.w * a[3] + bb[3]};
+        if (silu) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = silu_rcp(y[j]);
+        }
+        uint2 hi, lo;
+        split4(make_float4(y[0], y[1], y[2], y[3]), sc, hi, lo);
+        uint2* o = ob + r * 2 * Q;
+        o[0] = hi;
+        o[4] = lo;
+    };
+    int64_t r = r0 + rs;
+    for (; r + 3 * RS < r1; r += 4 * RS) {
+        const float4 v0 = xa[r * Q + q], v1 = xa[(r + RS) * Q + q], v2 = xa[(r + 2 * RS) * Q + q], v3 = xa[(r + 3 * RS) * Q + q];
+        one(v0, r); one(v1, r + RS); one(v2, r + 2 * RS); one(v3, r + 3 * RS);
+    }
+    for (; r < r1; r += RS) one(xa[r * Q + q], r);
+}
+extern "C" int64_t edadm_gn_split_ws_floats(int64_t B, int64_t HW, int64_t C, int64_t G) {
+    return B * gnx_chunks_h(B, HW) * C * 4 + B * G * 2 + EDADM_RED_BLOCKS;
+}
+extern "C" int edadm_gn_split_f16(const float* x, int64_t B, int64_t HW, int64_t C, int64_t G, float eps, const float* gamma,
+                                  const float* beta, int silu, void* out, float* inv, const float* other, int64_t n_other,
+                                  float* comb, int64_t N, float* ws, void* stream) {
+    if (!x || !gamma || !beta || !out || !inv || !ws || B <= 0 || HW <= 0 || C <= 0 || G <= 0 || (C % G) || (C & 15) || C > 1024 ||
+        B * G > EDADM_RED_BLOCKS || B > 65535)
+        return EDADM_EINVAL;
+    if (comb && (!other || N <= 0 || (n_other != 1 && n_other != N))) return EDADM_EINVAL;
+    if (((uintptr_t)x & 15) || ((uintptr_t)out & 7) || ((uintptr_t)ws & 15)) return EDADM_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int nchunk = gnx_chunks_h(B, HW);
+    const int Q = (int)(C >> 2), RS = 256 / Q;
+    float* stats = ws + B * nchunk * C * 4;
+    float* bound = stats + B * G * 2;
+    hipLaunchKernelGGL(k_gnx_partial, dim3(nchunk, (unsigned)B), dim3(256), (size_t)RS * C * 4 * sizeof(float), st, x, ws, HW, C,
+                       nchunk);
+    hipLaunchKernelGGL(k_gnx_final, dim3((unsigned)G, (unsigned)B), dim3(64), 0, st, ws, gamma, beta, stats, bound, HW, C, G, nchunk,
+                       eps, silu);
+    hipLaunchKernelGGL(k_gnx_apply_split, dim3(nchunk, (unsigned)B), dim3(256), 0, st, x, stats, gamma, beta, bound, HW, C, G, nchunk,
+                       silu, (uint2*)out, inv, other, n_other, comb, N);
+    return edadm_launch_status();
+}
+
 // Weight-gradient operands: dW[o][k] = sum_m dY[m][o] X[m][k] reduces over the ROW index of both row-major operands,
 // so the NT GEMM wants them transposed, and the split-K form wants the reduction cut into S slabs of L rows.  One pass
 // does both and the f16 expansion: in [R][C] fp32 -> out [C][S][3][L] f16 (R = S L), i.e. slab s of output row c is the

@@ -5,7 +5,9 @@
                                  the same launch.  Large layers: edadm_split_f16 + edadm_qgemm_f16 (fp32 operands as
                                  two-term f16 expansions, three products on the f16 MFMA, fp32-grade result); the
                                  rest: edadm_conv2d_f32_nhwc (exact-fp32 MFMA)
-    GroupNorm (+ swish) ....... edadm_groupnorm_stats / _apply  (K5)
+    GroupNorm (+ swish) ....... edadm_gn_split_f16: normalise + swish + the f16 expansion the next convolution reads, in two
+                                 passes over the input (the normalised tensor is never stored); edadm_groupnorm_stats /
+                                 _apply (K5) in front of the exact-fp32 layers
     attention block ........... edadm_gemm_f32_nt (q k^T, p v) + edadm_softmax_f32
     layout .................... NCHW <-> NHWC once at the boundary
 
@@ -32,6 +34,7 @@ class DecoderEngine:
         self.codebook = None if codebook is None else codebook.detach().float().contiguous()
         self.chunk_pixels = chunk_pixels            # output pixels per batch chunk: keeps every activation under the gather's 2 GiB (32-bit byte offsets) and bounds the attention scores
         self._wc = {}
+        self.fuse_gn_split = True                   # norm -> swish -> conv: the conv's f16 operand straight from the GroupNorm pass
 
     def w(self, conv):
         if id(conv) not in self._wc:
@@ -42,7 +45,7 @@ class DecoderEngine:
         w, b = self.w(conv)
         if x.shape[-1] != w.shape[-1]:                          # latent channels (3) -> 4
             x = torch.nn.functional.pad(x, (0, w.shape[-1] - x.shape[-1])).contiguous()
-        if F16X3 and ops.f16x3_conv_ok(x, w) and x.shape[0] * x.shape[1] * x.shape[2] * (4 if ups else 1) >= 16384:
+        if self._f16x3(conv, x, ups):
             key = ("h", id(conv))
             if key not in self._wc:                              # the filter's two-term f16 expansion, once
                 self._wc[key] = ops.split_f16(w, w.shape[0], w.shape[1] * w.shape[2], w.shape[3], 2, True)[:2]
@@ -50,17 +53,35 @@ class DecoderEngine:
                                          presplit=self._wc[key])
         return ops.conv2d_f32_nhwc(x, w, b, residual=residual, stride=1, pad=conv.padding[0], ups=ups)
 
+    def _f16x3(self, conv, x, ups=False):
+        w, _ = self.w(conv)
+        return (F16X3 and x.shape[-1] == w.shape[-1] and ops.f16x3_conv_ok(x, w)
+                and x.shape[0] * x.shape[1] * x.shape[2] * (4 if ups else 1) >= 16384)
+
+    def gn_conv(self, norm, x, silu, conv, residual=None):
+        """conv(swish(norm(x))) (+ residual).  When the convolution runs on the three-product path its operand is the f16
+        expansion of the normalised tensor: edadm_gn_split_f16 writes that expansion from x directly (two passes over x instead
+        of four over the normalised tensor, which is never stored)."""
+        if not (self.fuse_gn_split and self._f16x3(conv, x) and ops.gn_split_ok(x, norm.num_groups)):
+            return self.conv(conv, self.gn(norm, x, silu), residual=residual)
+        w, b = self.w(conv)
+        key = ("h", id(conv))
+        if key not in self._wc:
+            self._wc[key] = ops.split_f16(w, w.shape[0], w.shape[1] * w.shape[2], w.shape[3], 2, True)[:2]
+        wb, inv_b = self._wc[key]
+        xa, comb = ops.gn_split_f16(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu, inv_b, w.shape[0])
+        return ops.conv2d_f16x3_pre(xa, comb, x.shape, w.shape, wb, b, residual=residual, stride=1, pad=conv.padding[0])
+
     def gn(self, norm, x, silu):
         st = ops.groupnorm_stats(x, norm.num_groups, norm.eps)
         y, _ = ops.groupnorm_apply(x, st, norm.weight, norm.bias, norm.num_groups, silu, want_f32=True)
         return y
 
     def res(self, blk, x):
-        h = self.conv(blk.conv1, self.gn(blk.norm1, x, True))
-        a = self.gn(blk.norm2, h, True)
+        h = self.gn_conv(blk.norm1, x, True, blk.conv1)
         if blk.in_channels != blk.out_channels:
             x = self.conv(blk.conv_shortcut if blk.use_conv_shortcut else blk.nin_shortcut, x)
-        return self.conv(blk.conv2, a, residual=x)
+        return self.gn_conv(blk.norm2, h, True, blk.conv2, residual=x)
 
     def attn(self, blk, x):
         B, H, W, C = x.shape
@@ -118,7 +139,7 @@ class DecoderEngine:
                 h = self.conv(up.upsample.conv, h, ups=True) if up.upsample.with_conv else ops.upsample2_nhwc(h)
         if d.give_pre_end:
             return h
-        h = self.conv(d.conv_out, self.gn(d.norm_out, h, True))
+        h = self.gn_conv(d.norm_out, h, True, d.conv_out)
         return torch.tanh(h) if d.tanh_out else h
 
     @torch.no_grad()

@@ -681,6 +681,39 @@ def conv2d_f16x3_nhwc(x, w, bias=None, residual=None, stride=1, pad=1, ups=False
     return out
 
 
+def gn_split_f16(x, gamma, beta, G, eps, silu, other, N):
+    """GroupNorm (+ swish) of x [B][H][W][C] written straight as the order-2 expansion a three-product convolution reads
+    (edadm_gn_split_f16): (planes [B H W][2 C] f16, comb [N]) with comb = this operand's inverse scale x other (the filter's)."""
+    B, H, W, C = x.shape
+    xa = torch.empty(B * H * W, 2 * C, dtype=torch.float16, device=x.device)
+    inv = torch.empty(1, dtype=torch.float32, device=x.device)
+    comb = torch.empty(N, dtype=torch.float32, device=x.device)
+    ws = workspace(x.device, lib.load().edadm_gn_split_ws_floats(B, H * W, C, int(G)))
+    lib.call("edadm_gn_split_f16", _pf(x), B, H * W, C, int(G), float(eps), _pf(gamma), _pf(beta), 1 if silu else 0,
+             ctypes.c_void_p(xa.data_ptr()), _pf(inv), _pf(other), int(other.numel()), _pf(comb), int(N), _pf(ws), _stream())
+    return xa, comb
+
+
+def gn_split_ok(x, G):
+    B, H, W, C = x.shape
+    return C % 16 == 0 and C <= 1024 and C % G == 0 and B * G <= 1024 and B <= 65535
+
+
+def conv2d_f16x3_pre(xa, comb, shape, w_shape, wb, bias=None, residual=None, stride=1, pad=1, ups=False):
+    """conv2d_f16x3_nhwc on an activation that is already expanded (gn_split_f16): shape = (B, H, W, C) of the fp32 tensor."""
+    B, H, W, C = shape
+    N, KH, KW, _ = w_shape
+    Hl, Wl = (2 * H, 2 * W) if ups else (H, W)
+    Ho, Wo = (Hl + 2 * pad - KH) // stride + 1, (Wl + 2 * pad - KW) // stride + 1
+    out = torch.empty(B, Ho, Wo, N, dtype=torch.float32, device=xa.device)
+    geom = (ctypes.c_int32 * 12)(1, B, H, W, 2 * C, Ho, Wo, KH, KW, stride, pad, 1 if ups else 0)
+    K2 = KH * KW * 2 * C
+    lib.call("edadm_qgemm_f16x3", ctypes.c_void_p(xa.data_ptr()), int(K2), ctypes.c_void_p(wb.data_ptr()), int(K2),
+             int(B * Ho * Wo), int(N), int(K2), ctypes.cast(geom, ctypes.c_void_p), _pf(comb), _pf(bias), _pf(residual),
+             int(N), _pf(out), int(N), _stream())
+    return out
+
+
 def matmul_f16x3_nt(a2d, w2d, bias=None, residual=None, amax=None):
     """[M][K] . [N][K]^T (+bias) (+residual) through the same expansion (K % 16 == 0)."""
     M, K = a2d.shape

@@ -292,6 +292,17 @@ int edadm_absmax_parts(const float* x, int64_t n, float* parts, void* stream);
 int edadm_split_f16(const float* x, int64_t R, int64_t T, int64_t C, int order, int per_row, const float* amax_parts,
                     void* out, float* inv, const float* other, int64_t n_other, float* comb, int64_t N, float* ws,
                     void* stream);
+/* GroupNorm (+ swish) of x [B][HW][C] fp32 NHWC written DIRECTLY as the order-2 expansion out [B HW][C / 16][2][16] f16 (what
+ * edadm_groupnorm_stats + _apply + edadm_absmax_parts + edadm_split_f16 produce in four passes over the normalised tensor, in
+ * two over x): the expansion's power-of-two scale comes from a bound on max|y| computed from per-channel minima / maxima of x
+ * gathered next to the moment partials (y is monotone in x per channel) -- the same exponent as the scan of y unless the two
+ * straddle a power of two.  The first-stage decoder's norm -> nonlinearity -> conv chain (reference:
+ * ldm/modules/diffusionmodules/model.py:124-136 ResnetBlock.forward norm1/norm2 -> swish -> conv, :566-568 Decoder.forward norm_out).  inv / other / comb as
+ * edadm_split_f16.  C % 16 == 0, C <= 1024, B * G <= 1024; ws = edadm_gn_split_ws_floats(B, HW, C, G) floats, 16-byte aligned. */
+int64_t edadm_gn_split_ws_floats(int64_t B, int64_t HW, int64_t C, int64_t G);
+int edadm_gn_split_f16(const float* x, int64_t B, int64_t HW, int64_t C, int64_t G, float eps, const float* gamma,
+                       const float* beta, int silu, void* out, float* inv, const float* other, int64_t n_other, float* comb,
+                       int64_t N, float* ws, void* stream);
 /* the weight gradient's operands in one pass: in [R][C] fp32 -> out [C][R / L][3][L] f16 (transposed, the reduction
  * axis R cut into slabs of L rows, each slab the (hi, lo, hi) / (hi, hi, lo) expansion of order 0 / 1 under one
  * power-of-two scale for the tensor; inv[0] = 1 / scale).  R % L == 0, L even, R C % 4 == 0.  The product is
