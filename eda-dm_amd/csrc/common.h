@@ -63,7 +63,18 @@ __device__ __forceinline__ float rng_uniform(uint64_t seed, uint64_t idx) {
 __device__ __forceinline__ float silu_f(float x) { return x * (1.0f / (1.0f + expf(-x))); }
 // the same with the hardware reciprocal (<= 1 ulp) instead of the IEEE division: the fused GroupNorm + SiLU + quantise
 // producers of the sampling path are ALU-bound with the division
-__device__ __forceinline__ float silu_rcp(float x) { return x * __builtin_amdgcn_rcpf(1.0f + expf(-x)); }
+// and the hardware exponential on x * -log2(e): the library expf spends a dozen instructions on a two-term argument reduction
+// that only matters where exp(-x) is either negligible next to 1 or makes the result negligible (|x| > 16); here the
+// argument's rounding moves x * sigmoid(x) by at most 1e-8 absolute -- the size of the reciprocal's own last-bit error.
+// (The producers are VALU-bound with the library form: GroupNorm + swish -> int8 ran at 4.0-4.6 TB/s against 5.1-5.9 without
+// the swish, tools/elem_bw.py.)
+// exp(x) for x <= 0 on the hardware exponential (v_exp_f32 of x * log2(e)): the softmax numerators of the sampling path.  Against the
+// library routine's two-term argument reduction the argument's rounding adds a relative error of 6e-8 |x| -- for every probability
+// that reaches a non-zero 8-bit code (|x| < 6.3) less than the one-ulp error any exponential carries.
+__device__ __forceinline__ float exp_hw(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float silu_rcp(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
+}
 
 // erf to < 1 ulp, branch-free: two minimax fits (|x| <= 475/512: odd polynomial; else 1 - exp(-p(|x|))) evaluated
 // for every lane and selected -- cheaper on a 64-wide wavefront than the library routine's divergent cases.

@@ -812,7 +812,7 @@ __global__ void __launch_bounds__(256) k_softmax_q_v4(const float* __restrict__ 
     for (int j = 0; j < SM_MAXV4; ++j) {
         const int c = j * 64 + lane;
         if (c < Q) {
-            v[j].x = expf(v[j].x - mx); v[j].y = expf(v[j].y - mx); v[j].z = expf(v[j].z - mx); v[j].w = expf(v[j].w - mx);
+            v[j].x = exp_hw(v[j].x - mx); v[j].y = exp_hw(v[j].y - mx); v[j].z = exp_hw(v[j].z - mx); v[j].w = exp_hw(v[j].w - mx);
             sum += (v[j].x + v[j].y) + (v[j].z + v[j].w);
         }
     }
@@ -862,10 +862,10 @@ __global__ void __launch_bounds__(256) k_softmax_q(const float* __restrict__ s, 
     for (int64_t c = lane; c < cols; c += 64) mx = fmaxf(mx, sr[c]);
     mx = wave_max(mx);
     float sum = 0.f;
-    for (int64_t c = lane; c < cols; c += 64) sum += expf(sr[c] - mx);
+    for (int64_t c = lane; c < cols; c += 64) sum += exp_hw(sr[c] - mx);
     sum = wave_sum(sum);
     for (int64_t c = lane; c < cols; c += 64) {
-        const float p = expf(sr[c] - mx) / sum;
+        const float p = exp_hw(sr[c] - mx) / sum;
         const float code = q_code_f(p, q);
         out[row * ldo + c] = __float2half(code - q.z);
     }
