@@ -505,6 +505,16 @@ extern "C" int edadm_groupnorm_apply(const float* x, const float* stats, const f
 #define LN_MAXV4 8
 // C % 4 == 0 (every layer of the UNets): a lane owns float4 chunks lane, lane+64, ... -> 16-byte loads, one packed
 // dword per quantised output
+// sum over the LPR lanes that share a row (LPR = 64: the wave; 32: each half on its own)
+template <int LPR>
+__device__ __forceinline__ float row_sum(float v) {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// LPR lanes per row: 64 = one row per wave; 32 = two rows per wave, one per half -- a 384-wide row is 96 chunks: 3 x 32 lanes
+// exactly, against 2 x 64 with a quarter of the lanes idle (and twice the bytes in flight per wave)
+template <int LPR>
 __global__ void __launch_bounds__(256) k_ln_quant_v4(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, int64_t rows, int64_t C,
                                                      float eps, float* __restrict__ out_f32, int8_t* __restrict__ q0,
@@ -514,9 +524,11 @@ __global__ void __launch_bounds__(256) k_ln_quant_v4(const float* __restrict__ x
                                                      int64_t xrows, float* __restrict__ sum_out) {
     // radd: the input of the norm is x[row] + radd[row / rows_per_batch] (edadm_add_rowbcast folded in: the sum is
     // written to sum_out, the updated residual stream); xrows > 0: x has xrows < rows rows, read periodically
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    constexpr int RPW = 64 / LPR;                        // rows per wave
+    const int lane = threadIdx.x & (LPR - 1);
+    const int64_t row_ = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + ((threadIdx.x & 63) / LPR);
+    const bool live = row_ < rows;                       // a dead half still takes part in the shuffles of its wave
+    const int64_t row = live ? row_ : rows - 1;
     QP qa = qp ? qp_load(qp, 0) : QP{1, 0, 255, 1}, qb = (qp && nq > 1) ? qp_load(qp, 1) : qa, qc = (qp && nq > 2) ? qp_load(qp, 2) : qa;
     const int Q = (int)(C >> 2);
     const float4* xr = reinterpret_cast<const float4*>(x + (xrows > 0 ? row % xrows : row) * C);
@@ -526,11 +538,11 @@ __global__ void __launch_bounds__(256) k_ln_quant_v4(const float* __restrict__ x
         const float4* rr = reinterpret_cast<const float4*>(radd + (row / rows_per_batch) * C);
 #pragma unroll
         for (int j = 0; j < LN_MAXV4; ++j) {
-            const int c = j * 64 + lane;
+            const int c = j * LPR + lane;
             if (c < Q) {
                 const float4 a = xr[c], b = rr[c];
                 v[j] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
-                reinterpret_cast<float4*>(sum_out)[row * Q + c] = v[j];
+                if (live) reinterpret_cast<float4*>(sum_out)[row * Q + c] = v[j];
             } else {
                 v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
@@ -538,27 +550,27 @@ __global__ void __launch_bounds__(256) k_ln_quant_v4(const float* __restrict__ x
     } else {
 #pragma unroll
         for (int j = 0; j < LN_MAXV4; ++j) {
-            const int c = j * 64 + lane;
+            const int c = j * LPR + lane;
             v[j] = c < Q ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
 #pragma unroll
     for (int j = 0; j < LN_MAXV4; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
-    const float mean = wave_sum(s) / (float)C;
+    const float mean = row_sum<LPR>(s) / (float)C;
     float ss = 0.f;
 #pragma unroll
     for (int j = 0; j < LN_MAXV4; ++j) {
-        const int c = j * 64 + lane;
+        const int c = j * LPR + lane;
         if (c < Q) {
             const float d0 = v[j].x - mean, d1 = v[j].y - mean, d2 = v[j].z - mean, d3 = v[j].w - mean;
             ss += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
         }
     }
-    const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)C + eps);
+    const float rstd = 1.0f / sqrtf(row_sum<LPR>(ss) / (float)C + eps);
 #pragma unroll
     for (int j = 0; j < LN_MAXV4; ++j) {
-        const int c = j * 64 + lane;
-        if (c < Q) {
+        const int c = j * LPR + lane;
+        if (c < Q && live) {
             const float4 g4 = reinterpret_cast<const float4*>(gamma)[c], b4 = reinterpret_cast<const float4*>(beta)[c];
             float4 y;
             y.x = (v[j].x - mean) * rstd * g4.x + b4.x;
@@ -619,6 +631,11 @@ __global__ void __launch_bounds__(256) k_ln_quant(const float* __restrict__ x, c
         }
     }
 }
+// two rows per wave when 32-lane rows leave fewer idle lane slots than 64-lane rows (C = 384: 0 against 32 of 128)
+static bool ln_half_rows(int64_t C) {
+    const int64_t Q = C >> 2;
+    return Q <= 32 * LN_MAXV4 && (Q + 31) / 32 * 32 - Q < (Q + 63) / 64 * 64 - Q;
+}
 extern "C" int edadm_layernorm_quant(const float* x, const float* gamma, const float* beta, int64_t rows, int64_t C,
                                      float eps, float* out_f32, int8_t* q0, int8_t* q1, int8_t* q2, const float* qp,
                                      int nq, void* stream) {
@@ -626,11 +643,16 @@ extern "C" int edadm_layernorm_quant(const float* x, const float* gamma, const f
     if ((q0 || q1 || q2) && !qp) return EDADM_EINVAL;
     const bool al = !(((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)out_f32) & 15) &&
                     !(((uintptr_t)q0 | (uintptr_t)q1 | (uintptr_t)q2) & 3);
-    if ((C & 3) == 0 && C <= 256 * LN_MAXV4 && al)
-        hipLaunchKernelGGL(k_ln_quant_v4, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma,
-                           beta, rows, C, eps, out_f32, q0, q1, q2, (const QP*)qp, nq, (const float*)nullptr, (int64_t)1,
-                           (int64_t)0, (float*)nullptr);
-    else
+    if ((C & 3) == 0 && C <= 256 * LN_MAXV4 && al) {
+        if (ln_half_rows(C))
+            hipLaunchKernelGGL(k_ln_quant_v4<32>, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, (hipStream_t)stream, x, gamma,
+                               beta, rows, C, eps, out_f32, q0, q1, q2, (const QP*)qp, nq, (const float*)nullptr, (int64_t)1,
+                               (int64_t)0, (float*)nullptr);
+        else
+            hipLaunchKernelGGL(k_ln_quant_v4<64>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma,
+                               beta, rows, C, eps, out_f32, q0, q1, q2, (const QP*)qp, nq, (const float*)nullptr, (int64_t)1,
+                               (int64_t)0, (float*)nullptr);
+    } else
         hipLaunchKernelGGL(k_ln_quant, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma,
                            beta, rows, C, eps, out_f32, q0, q1, q2, (const QP*)qp, nq);
     return edadm_launch_status();
@@ -649,9 +671,14 @@ extern "C" int edadm_layernorm_quant_radd(const float* x, int64_t xrows, const f
     if ((((uintptr_t)x | (uintptr_t)radd | (uintptr_t)sum_out | (uintptr_t)gamma | (uintptr_t)beta) & 15) ||
         (((uintptr_t)q0 | (uintptr_t)q1 | (uintptr_t)q2) & 3))
         return EDADM_EINVAL;
-    hipLaunchKernelGGL(k_ln_quant_v4, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
-                       rows, C, eps, (float*)nullptr, q0, q1, q2, (const QP*)qp, nq, radd, rows_per_batch,
-                       xrows == rows ? (int64_t)0 : xrows, sum_out);
+    if (ln_half_rows(C))
+        hipLaunchKernelGGL(k_ln_quant_v4<32>, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
+                           rows, C, eps, (float*)nullptr, q0, q1, q2, (const QP*)qp, nq, radd, rows_per_batch,
+                           xrows == rows ? (int64_t)0 : xrows, sum_out);
+    else
+        hipLaunchKernelGGL(k_ln_quant_v4<64>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
+                           rows, C, eps, (float*)nullptr, q0, q1, q2, (const QP*)qp, nq, radd, rows_per_batch,
+                           xrows == rows ? (int64_t)0 : xrows, sum_out);
     return edadm_launch_status();
 }
 
