@@ -33,11 +33,16 @@ def _f16x3_linear(M, N, K):
 
 
 def _split(M, O, K):
-    """Number of slabs along the reduction (row) axis for the weight gradient: enough workgroups for the
-    256 CUs, slab length a multiple of 16 floats."""
+    """Number of slabs along the reduction (row) axis for the weight gradient.  Slabs of ~2048 rows: the [128 + 192][2 x 2048] f16
+    operand slabs of the workgroups that run together then share one L2 (4 MiB per XCD) instead of streaming 4-8 MiB slabs past
+    it -- measured best or within 5 % of best on every unit shape of the LDM-4 walk (tools/wgrad_split.py: 131072 x 192 x 3456
+    1107 -> 774 us, 8192 x 576 x 10368 555 -> 409); more slabs while the launch has fewer workgroups than the 256 CUs hold."""
     tiles = ((O + 127) // 128) * ((K + 127) // 128)
+    ok = lambda s: s <= 64 and M % (s * 16) == 0 and M // s >= 256
     s = 1
-    while tiles * s < 256 and s < 64 and M % (s * 2 * 16) == 0 and M // (s * 2) >= 256:
+    while M // (s * 2) >= 2048 and ok(s * 2):
+        s *= 2
+    while tiles * s < 256 and ok(s * 2):
         s *= 2
     return s
 
