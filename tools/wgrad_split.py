@@ -32,7 +32,7 @@ for (M, O, K) in shapes:
         continue
     cur = contract._split(M, O, K)
     res = []
-    for S in (1, 2, 4, 8, 16, 32, 64):
+    for S in (1, 2, 4, 8, 16, 32, 64, 128):
         if M % (S * 16) or M // S < 128:
             continue
         Ms = M // S
