@@ -142,6 +142,204 @@ extern "C" int edadm_gn_bwd_nchw(const float* dy, const float* x, const float* g
     return edadm_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------ GroupNorm (+ SiLU), NHWC
+// The same forward / input gradient over x [B][HW][C] (C % 4 == 0, C <= 1024): the layout the contraction kernels compute in,
+// so that a reconstruction iteration of a convolutional unit runs without layout conversions between its operators (the
+// NCHW form costs four conversion passes per convolution: operand in, result out, gradient in, gradient out).  A group's
+// elements are strided here, so both directions are chunked reductions: per (image, chunk of rows) per-CHANNEL partial sums
+// (a lane owns four channels down the chunk), a per-(image, group) reduction of the partials in fp64, then the apply pass.
+//   MODE 0  partials (sum x, sum x^2)             -> stats (mean, rstd)      -> y  = [silu](x ga' + be')
+//   MODE 1  partials (sum t, sum t xhat), t = dy [silu'] gamma  -> (m1, m2)  -> dx = rstd (t - m1 - xhat m2)
+// ws: [B][nchunk][C][2] floats.
+static int gnt_chunks(int64_t B, int64_t HW) {
+    int64_t n = HW / 32, cap = 4096 / (B < 1 ? 1 : B);
+    if (cap < 1) cap = 1;
+    if (n > cap) n = cap;
+    return (int)(n < 1 ? 1 : n);
+}
+struct GntCh { float mean, rstd, ga, be; };
+__device__ __forceinline__ float gnt_t(float xv, float dv, const GntCh& c, int silu, float& xhat) {
+    xhat = (xv - c.mean) * c.rstd;
+    float d = dv;
+    if (silu) {
+        const float z = fmaf(xhat, c.ga, c.be), sg = sigmoid_f(z);
+        d *= sg * (1.0f + z * (1.0f - sg));
+    }
+    return d * c.ga;
+}
+template <int MODE>
+__global__ void __launch_bounds__(256) k_gnt_partial(const float* __restrict__ x, const float* __restrict__ dy,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     const float* __restrict__ stats, float* __restrict__ ws, int64_t HW,
+                                                     int64_t C, int G, int nchunk, int silu) {
+    extern __shared__ float sm[];                                     // [RS][C][2]
+    const int64_t b = blockIdx.y;
+    const int chunk = blockIdx.x;
+    const int64_t r0 = HW * chunk / nchunk, r1 = HW * (chunk + 1) / nchunk;
+    const int Q = (int)(C >> 2), RS = 256 / Q;
+    const int q = threadIdx.x % Q, rs = threadIdx.x / Q;
+    const float4* xa = reinterpret_cast<const float4*>(x) + b * HW * Q;
+    const float4* da = reinterpret_cast<const float4*>(dy) + b * HW * Q;
+    float s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+    GntCh ch[4];
+    if (MODE == 1) {
+        const int cg = (int)(C / G);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = q * 4 + j, g = c / cg;
+            ch[j] = GntCh{stats[(b * G + g) * 2], stats[(b * G + g) * 2 + 1], gamma[c], beta[c]};
+        }
+    }
+    if (rs < RS) {
+        for (int64_t r = r0 + rs; r < r1; r += RS) {
+            const float4 v = xa[r * Q + q];
+            const float e[4] = {v.x, v.y, v.z, v.w};
+            if (MODE == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { s[j] += e[j]; ss[j] += e[j] * e[j]; }
+            } else {
+                const float4 dv = da[r * Q + q];
+                const float d[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float xh;
+                    const float t = gnt_t(e[j], d[j], ch[j], silu, xh);
+                    s[j] += t;
+                    ss[j] += t * xh;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sm[((int64_t)rs * C + q * 4 + j) * 2] = s[j];
+            sm[((int64_t)rs * C + q * 4 + j) * 2 + 1] = ss[j];
+        }
+    }
+    __syncthreads();
+    float* wb = ws + ((b * nchunk + chunk) * C) * 2;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = 0.f, bq = 0.f;
+        for (int r = 0; r < RS; ++r) { a += sm[((int64_t)r * C + c) * 2]; bq += sm[((int64_t)r * C + c) * 2 + 1]; }
+        wb[2 * c] = a;
+        wb[2 * c + 1] = bq;
+    }
+}
+template <int MODE>
+__global__ void __launch_bounds__(64) k_gnt_final(const float* __restrict__ ws, float* __restrict__ out2, int64_t HW, int64_t C,
+                                                  int G, int nchunk, float eps) {
+    const int64_t b = blockIdx.y, g = blockIdx.x;
+    const int cg = (int)(C / G);
+    const int items = nchunk * cg;
+    double s = 0.0, ss = 0.0;
+    for (int i = threadIdx.x; i < items; i += 64) {
+        const int chk = i / cg, c = (int)(g * cg) + i % cg;
+        const float* p = ws + ((b * nchunk + chk) * C + c) * 2;
+        s += (double)p[0];
+        ss += (double)p[1];
+    }
+    s = wave_sum_d(s);
+    ss = wave_sum_d(ss);
+    if (threadIdx.x == 0) {
+        const double n = (double)HW * cg;
+        if (MODE == 0) {
+            const double mean = s / n;
+            double var = ss / n - mean * mean;
+            if (var < 0) var = 0;
+            out2[(b * G + g) * 2] = (float)mean;
+            out2[(b * G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        } else {
+            out2[(b * G + g) * 2] = (float)(s / n);
+            out2[(b * G + g) * 2 + 1] = (float)(ss / n);
+        }
+    }
+}
+template <int MODE>
+__global__ void __launch_bounds__(256) k_gnt_apply(const float* __restrict__ x, const float* __restrict__ dy,
+                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                   const float* __restrict__ stats, const float* __restrict__ m12,
+                                                   float* __restrict__ out, int64_t HW, int64_t C, int G, int nchunk, int silu) {
+    const int64_t b = blockIdx.y;
+    const int chunk = blockIdx.x;
+    const int64_t r0 = HW * chunk / nchunk, r1 = HW * (chunk + 1) / nchunk;
+    const int Q = (int)(C >> 2), RS = 256 / Q;
+    const int q = threadIdx.x % Q, rs = threadIdx.x / Q;
+    if (rs >= RS) return;
+    const int cg = (int)(C / G);
+    GntCh ch[4];
+    float ga[4], be[4], m1[4], m2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = q * 4 + j, g = c / cg;
+        const float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
+        ch[j] = GntCh{mean, rstd, gamma[c], beta[c]};
+        ga[j] = gamma[c] * rstd;                                      // k_gn_fwd_nchw's arithmetic
+        be[j] = beta[c] - mean * ga[j];
+        if (MODE == 1) { m1[j] = m12[(b * G + g) * 2]; m2[j] = m12[(b * G + g) * 2 + 1]; }
+    }
+    const float4* xa = reinterpret_cast<const float4*>(x) + b * HW * Q;
+    const float4* da = reinterpret_cast<const float4*>(dy) + b * HW * Q;
+    float4* oa = reinterpret_cast<float4*>(out) + b * HW * Q;
+    for (int64_t r = r0 + rs; r < r1; r += RS) {
+        const float4 v = xa[r * Q + q];
+        const float e[4] = {v.x, v.y, v.z, v.w};
+        float o[4];
+        if (MODE == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = fmaf(e[j], ga[j], be[j]);
+                if (silu) o[j] *= sigmoid_f(o[j]);
+            }
+        } else {
+            const float4 dv = da[r * Q + q];
+            const float d[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float xh;
+                const float t = gnt_t(e[j], d[j], ch[j], silu, xh);
+                o[j] = ch[j].rstd * (t - m1[j] - xh * m2[j]);
+            }
+        }
+        oa[r * Q + q] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+extern "C" int64_t edadm_gn_nhwc_ws_floats(int64_t B, int64_t HW, int64_t C, int G) {
+    return B * gnt_chunks(B, HW) * C * 2 + B * G * 2;
+}
+static bool gnt_ok(int64_t B, int64_t C, int64_t HW, int G) {
+    return B > 0 && B <= 65535 && C > 0 && HW > 0 && G > 0 && !(C % G) && !(C & 3) && C <= 1024;
+}
+extern "C" int edadm_gn_fwd_nhwc(const float* x, const float* gamma, const float* beta, float* y, float* stats, float* ws,
+                                 int64_t B, int64_t C, int64_t HW, int G, float eps, int silu, void* stream) {
+    if (!x || !gamma || !beta || !y || !stats || !ws || !gnt_ok(B, C, HW, G)) return EDADM_EINVAL;
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return EDADM_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int nchunk = gnt_chunks(B, HW);
+    const int Q = (int)(C >> 2), RS = 256 / Q;
+    const size_t smem = (size_t)RS * C * 2 * sizeof(float);
+    hipLaunchKernelGGL(k_gnt_partial<0>, dim3(nchunk, (unsigned)B), dim3(256), smem, st, x, (const float*)nullptr, gamma, beta,
+                       (const float*)nullptr, ws, HW, C, G, nchunk, silu);
+    hipLaunchKernelGGL(k_gnt_final<0>, dim3((unsigned)G, (unsigned)B), dim3(64), 0, st, ws, stats, HW, C, G, nchunk, eps);
+    hipLaunchKernelGGL(k_gnt_apply<0>, dim3(nchunk, (unsigned)B), dim3(256), 0, st, x, (const float*)nullptr, gamma, beta, stats,
+                       (const float*)nullptr, y, HW, C, G, nchunk, silu);
+    return edadm_launch_status();
+}
+extern "C" int edadm_gn_bwd_nhwc(const float* dy, const float* x, const float* gamma, const float* beta, const float* stats,
+                                 float* dx, float* ws, int64_t B, int64_t C, int64_t HW, int G, int silu, void* stream) {
+    if (!dy || !x || !gamma || !beta || !stats || !dx || !ws || !gnt_ok(B, C, HW, G)) return EDADM_EINVAL;
+    if (((uintptr_t)x & 15) || ((uintptr_t)dy & 15) || ((uintptr_t)dx & 15)) return EDADM_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int nchunk = gnt_chunks(B, HW);
+    const int Q = (int)(C >> 2), RS = 256 / Q;
+    const size_t smem = (size_t)RS * C * 2 * sizeof(float);
+    float* m12 = ws + B * nchunk * C * 2;
+    hipLaunchKernelGGL(k_gnt_partial<1>, dim3(nchunk, (unsigned)B), dim3(256), smem, st, x, dy, gamma, beta, stats, ws, HW, C, G,
+                       nchunk, silu);
+    hipLaunchKernelGGL(k_gnt_final<1>, dim3((unsigned)G, (unsigned)B), dim3(64), 0, st, ws, m12, HW, C, G, nchunk, 0.f);
+    hipLaunchKernelGGL(k_gnt_apply<1>, dim3(nchunk, (unsigned)B), dim3(256), 0, st, x, dy, gamma, beta, stats, m12, dx, HW, C, G,
+                       nchunk, silu);
+    return edadm_launch_status();
+}
+
 // ------------------------------------------------------------------------------------------------ LayerNorm, [rows][C]
 // one wave per row, the row in registers (C <= 4096): mean, centred variance, apply -- fp32, two-pass on registers
 template <int LN_MAXV>

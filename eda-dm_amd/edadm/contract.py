@@ -25,6 +25,12 @@ F16X3 = True
 # the products are issued -- bench.py reads the counter around one captured reconstruction iteration for H1's roofline
 FLOPS = [0.0]
 F16X3_MIN_NK = 512 * 512      # smallest weight matrix (N x K) whose linear product takes the three-product f16 path
+# Convolutions hand their result (and input gradient) on in the layout they compute in: logical NCHW tensors with NHWC strides
+# (torch channels_last), and take such tensors without a conversion pass.  The element-wise operators of the graph run on memory
+# order (ops.mem_view), GroupNorm has an NHWC form (edadm_gn_fwd_nhwc): a convolutional unit's iteration keeps one layout from
+# its cached inputs to its loss (edadm/recon.py stores those caches in NHWC) instead of converting around every convolution --
+# 29 conversion passes, 10 % of a 64x64 ResBlock iteration.  False: NCHW between operators (tools / A-B tests).
+CHANNELS_LAST = True
 
 
 def _f16x3_linear(M, N, K):
@@ -165,7 +171,7 @@ class _Conv2dFn(torch.autograd.Function):
         B, C, H, W = x.shape
         O, _, KH, KW = weight.shape
         Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
-        xh = ops.nchw_to_nhwc(x.contiguous())
+        xh = x.permute(0, 2, 3, 1) if ops.is_cl(x) else ops.nchw_to_nhwc(x.contiguous())
         if C % 4:                                            # tiny-Cin first layer: pad channels to 4
             Cp = (C + 3) // 4 * 4
             xp = torch.zeros(B, H, W, Cp, dtype=x.dtype, device=x.device)
@@ -195,13 +201,13 @@ class _Conv2dFn(torch.autograd.Function):
         ctx.save_for_backward(xh, w4.reshape(O, KH * KW * Cp))
         ctx.px = px if px is not None else _amax(xh)
         ctx.meta = (B, C, Cp, H, W, O, KH, KW, stride, pad, Ho, Wo, one, bias is not None)
-        return ops.nhwc_to_nchw(out)
+        return out.permute(0, 3, 1, 2) if CHANNELS_LAST else ops.nhwc_to_nchw(out)
 
     @staticmethod
     def backward(ctx, gy):
         xh, w2 = ctx.saved_tensors
         B, C, Cp, H, W, O, KH, KW, stride, pad, Ho, Wo, one, has_bias = ctx.meta
-        gyh = ops.nchw_to_nhwc(gy.contiguous()).reshape(B * Ho * Wo, O)
+        gyh = (gy.permute(0, 2, 3, 1) if ops.is_cl(gy) else ops.nchw_to_nhwc(gy.contiguous())).reshape(B * Ho * Wo, O)
         pg = _amax(gyh)
         gx = gw = gb = None
         FLOPS[0] += 2.0 * B * Ho * Wo * O * KH * KW * C * (int(ctx.needs_input_grad[0]) + int(ctx.needs_input_grad[1]))
@@ -222,7 +228,8 @@ class _Conv2dFn(torch.autograd.Function):
                 w2t, _ = _pad4(ops.transpose_f32(w2))                                 # [K][O]
                 dcols = _matmul_nt(gyp, w2t, amax=pg if gyp is gyh else None)           # [M][K]
                 dxh = dcols.reshape(B, H, W, Cp) if one else ops.col2im_f32(dcols, B, H, W, Cp, KH, KW, stride, pad, Ho, Wo)
-            gx = ops.nhwc_to_nchw(dxh[..., :C].contiguous() if Cp != C else dxh)
+            dxh = dxh[..., :C].contiguous() if Cp != C else dxh
+            gx = dxh.permute(0, 3, 1, 2) if CHANNELS_LAST else ops.nhwc_to_nchw(dxh)
         if ctx.needs_input_grad[1]:
             if one:
                 gw2 = _wgrad(gyh, xh.reshape(B * H * W, Cp), amax_g=pg, amax_a=ctx.px)

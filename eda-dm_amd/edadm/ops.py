@@ -31,6 +31,33 @@ def _pf(t):
     return _p(t, torch.float32)
 
 
+def is_cl(x):
+    """a dense 4-D tensor whose memory order is NHWC (torch channels_last) and not also NCHW"""
+    return x.dim() == 4 and (not x.is_contiguous()) and x.is_contiguous(memory_format=torch.channels_last)
+
+
+def mem_view(x):
+    """(x as a contiguous tensor in its own memory order, whether that order is NHWC): elementwise kernels run on memory order,
+    so a channels_last tensor needs no conversion -- the calibration graph keeps convolutional units in NHWC end to end.  A
+    CHANNEL SLICE of a channels_last tensor (the two halves of a skip concatenation, each with its own quantiser) is NHWC-ordered
+    too: it is gathered into a dense NHWC tensor (a strided row copy, no transposition)."""
+    if x.is_contiguous():
+        return x, False
+    if x.dim() == 4 and x.stride(1) == 1 and x.shape[1] > 1:
+        return x.permute(0, 2, 3, 1).contiguous(), True          # no copy when x is dense channels_last
+    return x.contiguous(), False
+
+
+def mem_like(t, cl):
+    """a logical-NCHW tensor `t` laid out like mem_view's first result (cl: NHWC order)"""
+    return t.permute(0, 2, 3, 1).contiguous() if cl else t.contiguous()
+
+
+def mem_restore(y, cl):
+    """the logical NCHW view of a result computed in NHWC memory order"""
+    return y.permute(0, 3, 1, 2) if cl else y
+
+
 def workspace(device, floats=None):
     n = int(lib.load().edadm_reduce_ws_floats()) if floats is None else int(floats)
     # one buffer per (device, stream): launches on different streams may run concurrently (a decoder on a side stream next to
@@ -153,17 +180,18 @@ def minmax(x):
 
 
 # ------------------------------------------------------------------------------ K7 / K8 / K9 / K10
-def lp_loss_fwd(pred, tgt):
+def lp_loss_fwd(pred, tgt, C=None):
+    """C: size of the summed (channel) dimension when it is not dimension 1 (an NHWC memory-order view)"""
     loss = torch.empty(1, dtype=torch.float32, device=pred.device)
-    inv = 1.0 / (pred.numel() / pred.shape[1])
+    inv = 1.0 / (pred.numel() / (pred.shape[1] if C is None else C))
     lib.call("edadm_lp_loss_fwd", _pf(pred), _pf(tgt), pred.numel(), inv, _pf(loss), _pf(workspace(pred.device)),
              _stream())
     return loss
 
 
-def lp_loss_bwd(pred, tgt, gscale):
+def lp_loss_bwd(pred, tgt, gscale, C=None):
     g = torch.empty_like(pred)
-    inv = 1.0 / (pred.numel() / pred.shape[1])
+    inv = 1.0 / (pred.numel() / (pred.shape[1] if C is None else C))
     lib.call("edadm_lp_loss_bwd", _pf(pred), _pf(tgt), pred.numel(), inv, _pf(gscale), _pf(g), _stream())
     return g
 

@@ -191,6 +191,45 @@ STATE = {"batched": False}           # whether the unit being reconstructed runs
 INJECT_MIX_UNIFORM = None
 
 
+class RowsNHWC:
+    """Calibration rows of a feature map [N, C, H, W] kept in NHWC memory order (edadm/contract.py CHANNELS_LAST): a minibatch
+    gather `rows[idx]` comes out as a channels_last tensor, the layout the unit's convolutions, GroupNorms and element-wise
+    kernels run in -- no layout pass between the cache and the loss."""
+
+    def __init__(self, t=None, store=None):
+        self.t = store if store is not None else t.permute(0, 2, 3, 1).contiguous()     # a view when t already is channels_last
+
+    def __getitem__(self, idx):
+        return self.t[idx].permute(0, 3, 1, 2)
+
+    @property
+    def shape(self):
+        n, h, w, c = self.t.shape
+        return torch.Size((n, c, h, w))
+
+    def size(self, d):
+        return self.shape[d]
+
+    def dim(self):
+        return 4
+
+    @property
+    def is_cuda(self):
+        return self.t.is_cuda
+
+    @property
+    def device(self):
+        return self.t.device
+
+
+def _rows(t):
+    from . import contract
+    if contract.CHANNELS_LAST and torch.is_tensor(t) and t.dim() == 4 and t.is_cuda and t.dtype == torch.float32 \
+            and t.shape[1] % 4 == 0:
+        return RowsNHWC(t)
+    return t
+
+
 def fp_features(unit, hooks, cached_inps, resblock, sz, chunk, budget_bytes):
     """The FP feature maps of the fine-grained loss (block_recon.py:170-178: an FP forward of the block on `cur_sym`
     every iteration) are a pure function of the calibration sample, and each of the `sz` cached samples is drawn
@@ -211,10 +250,13 @@ def fp_features(unit, hooks, cached_inps, resblock, sz, chunk, budget_bytes):
                 per_row = sum(o[0].numel() * o.element_size() for o in outs)
                 if per_row * sz > budget_bytes:
                     return None
-                feats = [torch.empty((sz,) + tuple(o.shape[1:]), dtype=o.dtype, device=o.device) for o in outs]
-            for f, o in zip(feats, outs):
-                f[lo:hi] = o
-    return feats
+                from . import contract
+                nhwc = [contract.CHANNELS_LAST and o.dim() == 4 and o.shape[1] % 4 == 0 for o in outs]
+                feats = [torch.empty((sz, o.shape[2], o.shape[3], o.shape[1]) if cl else (sz,) + tuple(o.shape[1:]), dtype=o.dtype,
+                                     device=o.device) for o, cl in zip(outs, nhwc)]
+            for f, o, cl in zip(feats, outs, nhwc):
+                (f.permute(0, 3, 1, 2) if cl else f)[lo:hi] = o
+    return [RowsNHWC(store=f) if cl else f for f, cl in zip(feats, nhwc)]
 
 
 def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000, weight=0.01, opt_mode='mse',
@@ -270,6 +312,12 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
 
     resblock, cached_inps, cached_outs = save_fn(model, unit, cali_data, asym, act_quant, batch_size=cache_batch,
                                                  input_prob=True, keep_gpu=keep_gpu)
+    # feature-map caches go to NHWC memory order once; minibatch gathers then feed the unit channels_last tensors
+    cached_outs = _rows(cached_outs)
+    if resblock:
+        cached_inps = tuple((_rows(pair[0]), pair[1]) for pair in cached_inps)
+    else:
+        cached_inps = tuple(_rows(c) for c in cached_inps)
     sz = cached_outs.size(0)
     model.block_count = model.block_count + 1
     # a frozen int8 executor was compiled from the pre-reconstruction parameters: drop it (freeze() again after the walk)
@@ -317,11 +365,13 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
         else:
             cur_inp, cur_sym = cached_inps[0][idx_t], cached_inps[1][idx_t]
         if input_prob < 1.0:
+            inp_m, cl = ops.mem_view(cur_inp)                # element-wise: in the rows' memory order
             if INJECT_MIX_UNIFORM is not None:
-                cur_inp = ops.mix_where(cur_inp.contiguous(), cur_sym.contiguous(), input_prob,
-                                        u=INJECT_MIX_UNIFORM(cur_inp).contiguous())
+                mixed = ops.mix_where(inp_m, ops.mem_like(cur_sym, cl), input_prob,
+                                      u=ops.mem_like(INJECT_MIX_UNIFORM(cur_inp), cl))
             else:
-                cur_inp = ops.mix_where(cur_inp.contiguous(), cur_sym.contiguous(), input_prob, seed=_mask_rng.getrandbits(62))
+                mixed = ops.mix_where(inp_m, ops.mem_like(cur_sym, cl), input_prob, seed=_mask_rng.getrandbits(62))
+            cur_inp = ops.mem_restore(mixed, cl)
         elif is_block:
             cur_inp = cur_sym                 # block_recon.py:144-145 (the layer loop keeps cur_inp)
         for o in (w_opt, a_opt):

@@ -17,28 +17,47 @@ from .ops import _pf, _stream
 class _GroupNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, G, eps, silu):
-        x = x.contiguous().float()
+        x = x.float()
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
         B, C = x.shape[0], x.shape[1]
         HW = x.numel() // (B * C)
-        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
-        y = torch.empty_like(x)
         stats = torch.empty(B * G, 2, dtype=torch.float32, device=x.device)
+        cl = ops.is_cl(x) and C % 4 == 0 and C <= 1024 and B <= 65535
+        if cl:
+            # NHWC memory order (the convolutions' own layout, edadm/contract.py CHANNELS_LAST): chunked per-channel partials
+            xm = x.permute(0, 2, 3, 1)
+            y = torch.empty_like(xm)
+            ws = ops.workspace(x.device, lib.load().edadm_gn_nhwc_ws_floats(B, HW, C, int(G)))
+            lib.call("edadm_gn_fwd_nhwc", _pf(xm), _pf(g), _pf(b), _pf(y), _pf(stats), _pf(ws), B, C, HW, int(G), float(eps),
+                     1 if silu else 0, _stream())
+            ctx.save_for_backward(xm, g, b, stats)
+            ctx.meta = (B, C, HW, int(G), bool(silu), True)
+            return y.permute(0, 3, 1, 2)
+        x = x.contiguous()
+        y = torch.empty_like(x)
         lib.call("edadm_gn_fwd_nchw", _pf(x), _pf(g), _pf(b), _pf(y), _pf(stats), B, C, HW, int(G), float(eps), 1 if silu else 0,
                  _stream())
         ctx.save_for_backward(x, g, b, stats)
-        ctx.meta = (B, C, HW, int(G), bool(silu))
+        ctx.meta = (B, C, HW, int(G), bool(silu), False)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, g, b, stats = ctx.saved_tensors
-        B, C, HW, G, silu = ctx.meta
+        B, C, HW, G, silu, cl = ctx.meta
         dx = None
         if ctx.needs_input_grad[0]:
-            dy = dy.contiguous()
             dx = torch.empty_like(x)
-            lib.call("edadm_gn_bwd_nchw", _pf(dy), _pf(x), _pf(g), _pf(b), _pf(stats), _pf(dx), B, C, HW, G, 1 if silu else 0,
-                     _stream())
+            if cl:
+                dym = ops.mem_like(dy, True)                 # no copy when the gradient arrives in NHWC order
+                ws = ops.workspace(x.device, lib.load().edadm_gn_nhwc_ws_floats(B, HW, C, G))
+                lib.call("edadm_gn_bwd_nhwc", _pf(dym), _pf(x), _pf(g), _pf(b), _pf(stats), _pf(dx), _pf(ws), B, C, HW, G,
+                         1 if silu else 0, _stream())
+                dx = dx.permute(0, 3, 1, 2)
+            else:
+                dy = dy.contiguous()
+                lib.call("edadm_gn_bwd_nchw", _pf(dy), _pf(x), _pf(g), _pf(b), _pf(stats), _pf(dx), B, C, HW, G, 1 if silu else 0,
+                         _stream())
         return dx, None, None, None, None, None
 
 
@@ -106,16 +125,17 @@ def geglu(h):
 class _SiluFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
-        x = x.contiguous().float()
+        x, cl = ops.mem_view(x.float())
         ctx.save_for_backward(x)
-        return ops.silu(x)
+        ctx.cl = cl
+        return ops.mem_restore(ops.silu(x), cl)
 
     @staticmethod
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
         dx = torch.empty_like(x)
-        lib.call("edadm_silu_bwd", _pf(dy.contiguous()), _pf(x), _pf(dx), x.numel(), _stream())
-        return dx
+        lib.call("edadm_silu_bwd", _pf(ops.mem_like(dy, ctx.cl)), _pf(x), _pf(dx), x.numel(), _stream())
+        return ops.mem_restore(dx, ctx.cl)
 
 
 def silu(x):

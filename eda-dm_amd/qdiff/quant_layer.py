@@ -43,14 +43,18 @@ def round_ste(x):
 class _LpLoss2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, tgt):
-        pred, tgt = pred.contiguous(), tgt.contiguous()
+        # a sum over all elements: evaluated in pred's memory order (NHWC inside a convolutional unit, edadm/contract.py)
+        pred, cl = ops.mem_view(pred)
+        tgt = ops.mem_like(tgt, cl)
         ctx.save_for_backward(pred, tgt)
-        return ops.lp_loss_fwd(pred, tgt).reshape(())
+        ctx.cl = cl
+        return ops.lp_loss_fwd(pred, tgt, C=pred.shape[3] if cl else None).reshape(())
 
     @staticmethod
     def backward(ctx, g):
         pred, tgt = ctx.saved_tensors
-        return ops.lp_loss_bwd(pred, tgt, g.reshape(1).contiguous().float()), None
+        g = ops.lp_loss_bwd(pred, tgt, g.reshape(1).contiguous().float(), C=pred.shape[3] if ctx.cl else None)
+        return ops.mem_restore(g, ctx.cl), None
 
 
 def lp_loss(pred, tgt, p=2.0, reduction='none'):
@@ -63,22 +67,27 @@ def lp_loss(pred, tgt, p=2.0, reduction='none'):
 
 # ----------------------------------------------------------------------------- K1
 class _FakeQuantTensor(torch.autograd.Function):
-    """Per-tensor delta (activations): x and delta receive gradients."""
+    """Per-tensor delta (activations): x and delta receive gradients.  Elementwise with one step size: runs on x's memory order
+    (NHWC inside a convolutional unit); an injected uniform tensor (logical layout) is brought to the same order."""
 
     @staticmethod
     def forward(ctx, x, delta, zp, qmax, prob, seed, u):
-        x = x.contiguous()
+        x, cl = ops.mem_view(x)
+        if u is not None:
+            u = ops.mem_like(u, cl)
         d1, z1 = delta.detach().reshape(1).contiguous(), zp.detach().reshape(1).float().contiguous()
         ctx.save_for_backward(x, d1, z1, u)
-        ctx.meta = (qmax, prob, seed, delta.shape)
-        return ops.fake_quant_fwd(x, d1, z1, qmax, u=u, prob=prob, seed=seed)
+        ctx.meta = (qmax, prob, seed, delta.shape, cl)
+        return ops.mem_restore(ops.fake_quant_fwd(x, d1, z1, qmax, u=u, prob=prob, seed=seed), cl)
 
     @staticmethod
     def backward(ctx, gy):
         x, d1, z1, u = ctx.saved_tensors
-        qmax, prob, seed, dshape = ctx.meta
-        gx, gd = ops.fake_quant_bwd(gy.contiguous(), x, d1, z1, qmax, u=u, prob=prob, seed=seed,
+        qmax, prob, seed, dshape, cl = ctx.meta
+        gx, gd = ops.fake_quant_bwd(ops.mem_like(gy, cl), x, d1, z1, qmax, u=u, prob=prob, seed=seed,
                                     need_gx=ctx.needs_input_grad[0])
+        if gx is not None:
+            gx = ops.mem_restore(gx, cl)
         return gx, gd.reshape(dshape) if ctx.needs_input_grad[1] else None, None, None, None, None, None
 
 

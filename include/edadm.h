@@ -399,6 +399,14 @@ int edadm_qconv3_i8_direct(const int8_t* A, const int8_t* Wdc, int64_t B, int64_
  * softmax gradients (quant_block.py:204-235); a batched [Z][R][C] -> [Z][C][R] transpose for the K-major operands of the
  * attention products' gradients.  The normalisation affines receive no gradient: the loop never trains them
  * (block_recon.py:44-108). */
+/* The same GroupNorm (+ SiLU) forward / input gradient over NHWC x [B][HW][C] (C % 4 == 0, C <= 1024), the layout of the
+ * contraction kernels: a convolutional unit's reconstruction iteration then runs without NCHW <-> NHWC passes between its
+ * operators.  ws = edadm_gn_nhwc_ws_floats(B, HW, C, G) floats (per-chunk per-channel partial sums, reduced in fp64). */
+int64_t edadm_gn_nhwc_ws_floats(int64_t B, int64_t HW, int64_t C, int G);
+int edadm_gn_fwd_nhwc(const float* x, const float* gamma, const float* beta, float* y, float* stats, float* ws, int64_t B,
+                      int64_t C, int64_t HW, int G, float eps, int silu, void* stream);
+int edadm_gn_bwd_nhwc(const float* dy, const float* x, const float* gamma, const float* beta, const float* stats, float* dx,
+                      float* ws, int64_t B, int64_t C, int64_t HW, int G, int silu, void* stream);
 int edadm_gn_fwd_nchw(const float* x, const float* gamma, const float* beta, float* y, float* stats, int64_t B, int64_t C,
                       int64_t HW, int G, float eps, int silu, void* stream);
 int edadm_gn_bwd_nchw(const float* dy, const float* x, const float* gamma, const float* beta, const float* stats, float* dx,

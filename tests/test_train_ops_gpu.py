@@ -40,6 +40,78 @@ def test_group_norm_silu_forward_backward(shape, G, silu):
     close("group_norm%s bwd %s" % ("+silu" if silu else "", shape), gx, x.grad, 5e-5)
 
 
+@pytest.mark.parametrize("shape,G,silu", [((4, 64, 8, 8), 32, True), ((3, 192, 16, 16), 32, False), ((2, 96, 5, 7), 32, True),
+                                           ((2, 384, 32, 32), 32, True), ((64, 576, 16, 16), 32, True), ((2, 1024, 9, 3), 32, False)])
+def test_group_norm_silu_channels_last(shape, G, silu):
+    """The NHWC form (edadm_gn_fwd_nhwc / _bwd_nhwc: chunked per-channel partials) on channels_last tensors, as the calibration
+    graph feeds it between convolutions: against torch, and against the NCHW kernel on the same values (same arithmetic per
+    element; the group moments are summed in another order)."""
+    from edadm import train_ops as T
+    g = torch.Generator().manual_seed(sum(shape) + 1)
+    x0 = (torch.randn(shape, generator=g) * 1.7 + 0.3).cuda()
+    norm = nn.GroupNorm(G, shape[1], eps=1e-6).cuda()
+    with torch.no_grad():
+        norm.weight.copy_(1 + 0.3 * torch.randn(shape[1], generator=g))
+        norm.bias.copy_(0.2 * torch.randn(shape[1], generator=g))
+    gy = torch.randn(shape, generator=g).cuda()
+    res = {}
+    for name, fmt in (("nhwc", torch.channels_last), ("nchw", torch.contiguous_format)):
+        x = x0.clone(memory_format=fmt).requires_grad_(True)
+        y = T.group_norm(x, norm, silu=silu)
+        if name == "nhwc":
+            assert y.is_contiguous(memory_format=torch.channels_last) and not y.is_contiguous()     # stays in the layout
+        (y * gy.contiguous(memory_format=fmt)).sum().backward()
+        res[name] = (y.detach(), x.grad.clone())
+        if name == "nhwc":
+            assert x.grad.is_contiguous(memory_format=torch.channels_last)
+    x = x0.clone().requires_grad_(True)
+    ref = F.group_norm(x, G, norm.weight, norm.bias, 1e-6)
+    if silu:
+        ref = ref * torch.sigmoid(ref)
+    (ref * gy).sum().backward()
+    close("nhwc group_norm fwd %s" % (shape,), res["nhwc"][0], ref.detach(), 2e-5)
+    close("nhwc group_norm bwd %s" % (shape,), res["nhwc"][1], x.grad, 5e-5)
+    close("nhwc vs nchw kernel fwd", res["nhwc"][0], res["nchw"][0], 2e-6)
+    close("nhwc vs nchw kernel bwd", res["nhwc"][1], res["nchw"][1], 5e-6)
+
+
+def test_convolutional_unit_runs_in_one_layout():
+    """contract.CHANNELS_LAST: convolutions hand on channels_last tensors, element-wise kernels and GroupNorm follow the memory order:
+    a ResBlock's forward + backward launches no NCHW <-> NHWC conversion between its operators, and gives the NCHW graph's values."""
+    from torch.profiler import profile, ProfilerActivity
+    from edadm import contract, train_ops as T
+    torch.manual_seed(3)
+    conv1, conv2 = nn.Conv2d(64, 128, 3, padding=1).cuda(), nn.Conv2d(128, 128, 3, padding=1).cuda()
+    n1, n2 = nn.GroupNorm(32, 64).cuda(), nn.GroupNorm(32, 128).cuda()
+    x0 = torch.randn(16, 64, 64, 64, device="cuda")          # large enough for the implicit input-gradient path (no weight transposes)
+
+    def run(x):
+        h = contract.conv2d(T.group_norm(x, n1, silu=True), conv1.weight, conv1.bias, 1, 1)
+        h = contract.conv2d(T.group_norm(h, n2, silu=True), conv2.weight, conv2.bias, 1, 1)
+        return h
+
+    outs = {}
+    for flag in (True, False):
+        contract.CHANNELS_LAST = flag
+        try:
+            x = (x0.clone(memory_format=torch.channels_last) if flag else x0.clone()).requires_grad_(True)
+            run(x).square().sum().backward()                   # warm-up
+            x.grad = None
+            with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                y = run(x)
+                y.square().sum().backward()
+                torch.cuda.synchronize()
+            names = [e.key for e in prof.key_averages()]
+            conv = sum(e.count for e in prof.key_averages() if "k_nchw_to_nhwc" in e.key)
+            outs[flag] = (y.detach().contiguous(), x.grad.contiguous(), conv)
+        finally:
+            contract.CHANNELS_LAST = True
+    assert outs[True][2] == 0, "layout conversions in the channels_last graph"
+    assert outs[False][2] >= 6
+    close("unit output, one layout vs NCHW", outs[True][0], outs[False][0], 2e-6)
+    close("unit input gradient, one layout vs NCHW", outs[True][1], outs[False][1], 5e-6)
+
+
 @pytest.mark.parametrize("rows,C", [(64, 32), (1000, 384), (96, 960), (10, 1280), (33, 2000)])
 def test_layer_norm_forward_backward(rows, C):
     from edadm import train_ops as T
