@@ -24,7 +24,8 @@ F16X3 = True
 # Executed fp32-equivalent flops (2 M N K per product: forward, input gradient, weight gradient), counted on the host as
 # the products are issued -- bench.py reads the counter around one captured reconstruction iteration for H1's roofline
 FLOPS = [0.0]
-F16X3_MIN_NK = 512 * 512      # smallest weight matrix (N x K) whose linear product takes the three-product f16 path
+F16X3_MIN_NK = 256 * 256      # smallest weight matrix (N x K) whose linear product takes the three-product f16 path (tools/recon_time.py: the 384-wide
+                              # layers of the 32x32 transformer blocks 17.5 -> 16.7 ms per iteration; smaller ones are neutral)
 # Convolutions hand their result (and input gradient) on in the layout they compute in: logical NCHW tensors with NHWC strides
 # (torch channels_last), and take such tensors without a conversion pass.  The element-wise operators of the graph run on memory
 # order (ops.mem_view), GroupNorm has an NHWC form (edadm_gn_fwd_nhwc): a convolutional unit's iteration keeps one layout from
