@@ -1559,6 +1559,14 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
     else if (N <= 64) tn = 1;
     int tm = 2;
     if (M <= 64) tm = 1;
+    if constexpr (DT == 3) {
+        // three-product f16 operands, N a multiple of 256 (the first-stage decoder's 256- and 512-channel convolutions):
+        // 256 x 256 tiles on the 8-wave kernel -- 12 fragment reads per 24 MFMAs instead of 8 per 12, and half the A re-reads
+        static const int64_t wide = EDADM_TUNE_I("EDADM_F16X3_WIDE", 1);
+        if (wide && N % 256 == 0 && N % 192 != 0 && batch == 1 && out_mode == 0 && !gn_ws &&
+            ((M + 255) / 256) * (N / 256) >= 224 && Kb >= 2049)
+            tn = 4;
+    }
     {   // few 128-row tiles (the 8x8 level: 250 for 256 CUs with room for two workgroups each): 64-row tiles double the
         // resident workgroups per CU, which is what hides the operand latency there
         static const int64_t thr = EDADM_TUNE_I("EDADM_GEMM_TM1_BELOW", 0);
@@ -1652,6 +1660,9 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
                                (const uint8_t*)Bm, ldb_b, sB, M, N, Kb, g, scale, bias, rowadd, rpb, residual, \
                                ldr, out, ldo, sC, alpha, inner, sAi, sBi, sCi, out_mode, oqp, gn_ws);      \
             return edadm_launch_status();                                                                      \
+        }
+        if constexpr (DT == 3) {
+            EDADM_GEMM8_CASE(4)
         }
         EDADM_GEMM8_CASE(3)
         EDADM_GEMM8_CASE(2)
