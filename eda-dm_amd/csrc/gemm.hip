@@ -1563,8 +1563,8 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
         // three-product f16 operands, N a multiple of 256 (the first-stage decoder's 256- and 512-channel convolutions):
         // 256 x 256 tiles on the 8-wave kernel -- 12 fragment reads per 24 MFMAs instead of 8 per 12, and half the A re-reads
         static const int64_t wide = EDADM_TUNE_I("EDADM_F16X3_WIDE", 1);
-        if (wide && N % 256 == 0 && N % 192 != 0 && batch == 1 && out_mode == 0 && !gn_ws &&
-            ((M + 255) / 256) * (N / 256) >= 224 && Kb >= 2049)
+        if (wide && N % 256 == 0 && N % 192 != 0 && inner == 1 && out_mode == 0 && !gn_ws &&
+            ((M + 255) / 256) * (N / 256) * batch >= 224 && Kb >= 2048)
             tn = 4;
     }
     {   // few 128-row tiles (the 8x8 level: 250 for 256 CUs with room for two workgroups each): 64-row tiles double the
@@ -1614,7 +1614,7 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
     // workgroups per CU overlaps one workgroup's output burst with the other's main loop and wins; longer K amortises
     // the 8-wave tile's smaller operand traffic per flop (tools/gemm_table.py, EDADM_GEMM_FORCE=2 vs 3)
     static const int64_t nt8_min_kb = EDADM_TUNE_I("EDADM_NT8_MIN_KB", 2049);
-    if (force != 2 && EDADM_USE_NT8 && (force == 3 || (tiles8 >= 224 && Kb >= nt8_min_kb)) && nt8_gather_ok &&
+    if (force != 2 && EDADM_USE_NT8 && (force == 3 || (tiles8 >= 224 && (Kb >= nt8_min_kb || tn == 4))) && nt8_gather_ok &&
         !(out_mode == 4 && M % 256)) {
         // Tail re-tiling: one workgroup per CU means the launch runs in rounds of #CU tiles, and a last round that is
         // mostly empty costs a full round (300 tiles on 256 CUs: 2 rounds for 1.17 rounds of work).  The m-tiles that
