@@ -128,3 +128,65 @@ extern "C" int edadm_conv3x3_f32_smalln(const float* x, const float* w, const fl
 #undef SMALLN_CASE
     return EDADM_EINVAL;
 }
+
+// ---- codebook lookup of the VQ first stage: out[r] = codebook[argmin_j |z_r - e_j|^2]  (VQModelInterface.decode -> self.quantize,
+// ldm/models/autoencoder.py:274-277; the quantiser itself is taming's VectorQuantizer2, not vendored by the reference: the rule here is
+// its published one -- d = |z|^2 + |e|^2 - 2 z.e, first minimum -- parity unpinned).  D <= 8 floats per code.  The distance matrix
+// (65536 x 8192 floats for a 16-image chunk of VQ-f4) is never formed: a workgroup stages the codebook through LDS in chunks of 2048
+// codes (+ their squared norms), a thread owns one latent vector and walks the chunk with broadcast reads.
+#define VQ_CHUNK 2048
+template <int D>
+__global__ void __launch_bounds__(256) k_vq_nearest(const float* __restrict__ z, const float* __restrict__ cb, float* __restrict__ out,
+                                                    int64_t* __restrict__ idx, int64_t R, int E) {
+    __shared__ float sc[VQ_CHUNK * D];
+    __shared__ float s2[VQ_CHUNK];
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float v[D];
+    float z2 = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        v[d] = r < R ? z[r * D + d] : 0.f;
+        z2 += v[d] * v[d];
+    }
+    float best = INFINITY;
+    int bi = 0;
+    for (int e0 = 0; e0 < E; e0 += VQ_CHUNK) {
+        const int n = E - e0 < VQ_CHUNK ? E - e0 : VQ_CHUNK;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n * D; i += 256) sc[i] = cb[(int64_t)e0 * D + i];
+        __syncthreads();
+        for (int j = threadIdx.x; j < n; j += 256) {
+            float a = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) a += sc[j * D + d] * sc[j * D + d];
+            s2[j] = a;
+        }
+        __syncthreads();
+        for (int j = 0; j < n; ++j) {
+            float dot = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) dot += v[d] * sc[j * D + d];
+            const float dist = (z2 - 2.0f * dot) + s2[j];
+            if (dist < best) { best = dist; bi = e0 + j; }
+        }
+    }
+    if (r < R) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) out[r * D + d] = cb[(int64_t)bi * D + d];
+        if (idx) idx[r] = bi;
+    }
+}
+extern "C" int edadm_vq_nearest(const float* z, const float* codebook, float* out, int64_t* idx, int64_t R, int64_t D, int64_t E,
+                                void* stream) {
+    if (!z || !codebook || !out || R <= 0 || D <= 0 || D > 8 || E <= 0 || E > 0x7fffffff) return EDADM_EINVAL;
+    const dim3 grid((unsigned)((R + 255) / 256));
+    hipStream_t st = (hipStream_t)stream;
+#define VQ_CASE(D_)                                                                                            \
+    if (D == D_) {                                                                                             \
+        hipLaunchKernelGGL(k_vq_nearest<D_>, grid, dim3(256), 0, st, z, codebook, out, idx, R, (int)E);        \
+        return edadm_launch_status();                                                                          \
+    }
+    VQ_CASE(1) VQ_CASE(2) VQ_CASE(3) VQ_CASE(4) VQ_CASE(5) VQ_CASE(6) VQ_CASE(7) VQ_CASE(8)
+#undef VQ_CASE
+    return EDADM_EINVAL;
+}

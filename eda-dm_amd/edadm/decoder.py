@@ -117,7 +117,10 @@ class DecoderEngine:
         """z -> codebook[argmin ||z - e||^2] (the VectorQuantizer2 lookup); identity when no codebook is attached."""
         if self.codebook is None:
             return z_nhwc
-        flat = z_nhwc.reshape(-1, z_nhwc.shape[-1])
+        flat = z_nhwc.reshape(-1, z_nhwc.shape[-1]).contiguous()
+        if flat.shape[1] <= 8:
+            # edadm_vq_nearest: the codebook staged through LDS, no [pixels][codes] distance matrix (2 GB for 16 VQ-f4 latents)
+            return ops.vq_nearest(flat, self.codebook).reshape(z_nhwc.shape)
         d = (flat * flat).sum(1, keepdim=True) - 2 * flat @ self.codebook.t() + (self.codebook * self.codebook).sum(1)[None]
         return self.codebook[d.argmin(1)].reshape(z_nhwc.shape)
 

@@ -591,6 +591,13 @@ def gemm_f16_nt_q(A, lda, strideA, Bm, ldb, strideB, batch, M, N, K, alpha, out,
     return out
 
 
+def vq_nearest(z2d, codebook):
+    """rows of z2d [R][D] -> their nearest codebook rows (edadm_vq_nearest; D <= 8)"""
+    out = torch.empty_like(z2d)
+    lib.call("edadm_vq_nearest", _pf(z2d), _pf(codebook), _pf(out), None, z2d.shape[0], z2d.shape[1], codebook.shape[0], _stream())
+    return out
+
+
 def conv3x3_f32_smalln(x_nhwc, w, bias):
     B, H, W, C = x_nhwc.shape
     N = w.shape[0]

@@ -338,6 +338,11 @@ int edadm_sum_slabs(const float* slabs, float* out, int64_t n, int64_t S, void* 
  * activation quantizer is disabled, quant_model.py:90-95): x NHWC fp32, w [N][3][3][C] fp32. */
 int edadm_conv3x3_f32_smalln(const float* x, const float* w, const float* bias, float* out, int64_t B,
                              int64_t H, int64_t W, int64_t C, int64_t N, void* stream);
+/* Codebook lookup of the VQ first stage (VQModelInterface.decode -> self.quantize, ldm/models/autoencoder.py:274-277; taming's
+ * VectorQuantizer2 is not vendored by the reference: its published rule, parity unpinned): out[r] = codebook[argmin_j |z_r - e_j|^2],
+ * first minimum, d = |z|^2 + |e|^2 - 2 z.e in fp32.  z, out [R][D], codebook [E][D], D <= 8; idx (optional) [R] int64. */
+int edadm_vq_nearest(const float* z, const float* codebook, float* out, int64_t* idx, int64_t R, int64_t D, int64_t E,
+                     void* stream);
 /* K6: row softmax + quantise to f16 codes (code - zp); rows x cols fp32 in. */
 int edadm_softmax_quant_f16(const float* s, void* out, int64_t rows, int64_t cols, int64_t ldo,
                             const float* qp, void* stream);
