@@ -880,7 +880,7 @@ __global__ void __launch_bounds__(256) k_gnx_partial(const float* __restrict__ x
         reinterpret_cast<float4*>(wb)[c] = make_float4(a, bq, lo, hi);
     }
 }
-__global__ void __launch_bounds__(64) k_gnx_final(const float* __restrict__ ws, const float* __restrict__ gamma,
+__global__ void __launch_bounds__(256) k_gnx_final(const float* __restrict__ ws, const float* __restrict__ gamma,
                                                   const float* __restrict__ beta, float* __restrict__ stats,
                                                   float* __restrict__ bound, int64_t HW, int64_t C, int64_t G, int nchunk,
                                                   float eps, int silu) {
@@ -888,8 +888,10 @@ __global__ void __launch_bounds__(64) k_gnx_final(const float* __restrict__ ws, 
     const int cpg = (int)(C / G);
     const int items = nchunk * cpg;
     const float4* w4 = reinterpret_cast<const float4*>(ws);
+    __shared__ double smd[8];
+    __shared__ float smf[4];
     double s = 0.0, ss = 0.0;
-    for (int i = threadIdx.x; i < items; i += 64) {
+    for (int i = threadIdx.x; i < items; i += 256) {
         const int ch = i / cpg, c = (int)(g * cpg) + i % cpg;
         const float4 p = w4[(b * nchunk + ch) * C + c];
         s += (double)p.x;
@@ -897,6 +899,10 @@ __global__ void __launch_bounds__(64) k_gnx_final(const float* __restrict__ ws, 
     }
     s = wave_sum_d(s);
     ss = wave_sum_d(ss);
+    if ((threadIdx.x & 63) == 0) { smd[(threadIdx.x >> 6) * 2] = s; smd[(threadIdx.x >> 6) * 2 + 1] = ss; }
+    __syncthreads();
+    s = (smd[0] + smd[2]) + (smd[4] + smd[6]);
+    ss = (smd[1] + smd[3]) + (smd[5] + smd[7]);
     const double n = (double)HW * cpg;
     const double mean_d = s / n;
     double var = ss / n - mean_d * mean_d;
@@ -907,7 +913,7 @@ __global__ void __launch_bounds__(64) k_gnx_final(const float* __restrict__ ws, 
         stats[(b * G + g) * 2 + 1] = rstd;
     }
     float m = 0.f;
-    for (int i = threadIdx.x; i < items; i += 64) {
+    for (int i = threadIdx.x; i < items; i += 256) {
         const int ch = i / cpg, c = (int)(g * cpg) + i % cpg;
         const float4 p = w4[(b * nchunk + ch) * C + c];
         const float a = rstd * gamma[c], bb = beta[c] - mean * a;
@@ -922,11 +928,14 @@ __global__ void __launch_bounds__(64) k_gnx_final(const float* __restrict__ ws, 
         m = fmaxf(m, fmaxf(fabsf(z1), fabsf(z2)));
     }
     m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) smf[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(smf[0], smf[1]), fmaxf(smf[2], smf[3]));
     const int64_t slot = b * G + g;
     if (threadIdx.x == 0) bound[slot] = m;
     // consumers scan all EDADM_RED_BLOCKS slots: the first block clears the ones no (image, group) owns
     if (slot == 0)
-        for (int64_t i = (int64_t)gridDim.x * gridDim.y + threadIdx.x; i < EDADM_RED_BLOCKS; i += 64) bound[i] = 0.f;
+        for (int64_t i = (int64_t)gridDim.x * gridDim.y + threadIdx.x; i < EDADM_RED_BLOCKS; i += 256) bound[i] = 0.f;
 }
 __global__ void __launch_bounds__(256) k_gnx_apply_split(const float* __restrict__ x, const float* __restrict__ stats,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -1001,7 +1010,7 @@ extern "C" int edadm_gn_split_f16(const float* x, int64_t B, int64_t HW, int64_t
     float* bound = stats + B * G * 2;
     hipLaunchKernelGGL(k_gnx_partial, dim3(nchunk, (unsigned)B), dim3(256), (size_t)RS * C * 4 * sizeof(float), st, x, ws, HW, C,
                        nchunk);
-    hipLaunchKernelGGL(k_gnx_final, dim3((unsigned)G, (unsigned)B), dim3(64), 0, st, ws, gamma, beta, stats, bound, HW, C, G, nchunk,
+    hipLaunchKernelGGL(k_gnx_final, dim3((unsigned)G, (unsigned)B), dim3(256), 0, st, ws, gamma, beta, stats, bound, HW, C, G, nchunk,
                        eps, silu);
     hipLaunchKernelGGL(k_gnx_apply_split, dim3(nchunk, (unsigned)B), dim3(256), 0, st, x, stats, gamma, beta, bound, HW, C, G, nchunk,
                        silu, (uint2*)out, inv, other, n_other, comb, N);

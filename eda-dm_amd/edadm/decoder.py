@@ -51,6 +51,11 @@ class DecoderEngine:
                 self._wc[key] = ops.split_f16(w, w.shape[0], w.shape[1] * w.shape[2], w.shape[3], 2, True)[:2]
             return ops.conv2d_f16x3_nhwc(x, w, b, residual=residual, stride=1, pad=conv.padding[0], ups=ups,
                                          presplit=self._wc[key])
+        if (w.shape[0] <= 4 and w.shape[1] == 3 and w.shape[2] == 3 and conv.padding[0] == 1 and x.shape[-1] <= 320 and residual is None
+                and not ups and x.shape[0] * x.shape[1] < (1 << 31)):
+            # conv_out: 3 output channels -- a GEMM tile would compute 64 columns for them (edadm_conv3x3_f32_smalln: fp32 FMAs, one
+            # wave per image row, the same kernel as the UNet's last layer)
+            return ops.conv3x3_f32_smalln(x, w, b)
         return ops.conv2d_f32_nhwc(x, w, b, residual=residual, stride=1, pad=conv.padding[0], ups=ups)
 
     def _f16x3(self, conv, x, ups=False):
