@@ -651,6 +651,25 @@ static void ensure_pad_rows(hipStream_t st) {
 // asynchronous, so the launching call cannot report it; edadm_device_status() does, at the caller's next synchronisation.
 static __device__ unsigned int g_error_word;
 
+// Workgroups are dealt round-robin to the 8 XCDs (one 4 MiB L2 each) by their linear index.  With the plain (x = N tile, y = M tile)
+// numbering the N tiles of one M tile -- which read the same activation rows -- land on different XCDs and each L2 fetches its own
+// copy; so do vertically adjacent M tiles of a convolution, which share halo rows.  Remap: XCD k walks the contiguous range of tiles
+// [start_k, start_k + count_k) in (M tile, N tile) order -- a bijection for any tile count.  (gridDim.z == 1 launches only.)
+#ifndef EDADM_XCD_ORDER
+#define EDADM_XCD_ORDER 1
+#endif
+__device__ __forceinline__ void xcd_tile(unsigned& bx, unsigned& by) {
+    bx = blockIdx.x;
+    by = blockIdx.y;
+    if (!EDADM_XCD_ORDER || gridDim.z != 1) return;
+    const unsigned nx = gridDim.x, T = nx * gridDim.y, L = by * nx + bx;
+    if (T < 16) return;
+    const unsigned k = L & 7, j = L >> 3, q = T >> 3, r = T & 7;
+    const unsigned t = k * q + (k < r ? k : r) + j;
+    by = t / nx;
+    bx = t - by * nx;
+}
+
 template <int DT, int TM, int TN>
 __global__ void __launch_bounds__(256, 2)      // two workgroups per CU: at most 256 registers (VGPR + AGPR) per lane
 k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const uint8_t* __restrict__ Bm,
@@ -683,7 +702,9 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
 #ifdef EDADM_STAMPS
     unsigned long long d_wait = 0;
 #endif
-    const int64_t m0 = (int64_t)blockIdx.y * BM + g.r0, n0 = (int64_t)blockIdx.x * BN;   // g.r0: first row of a tail launch
+    unsigned bx_, by_;
+    xcd_tile(bx_, by_);
+    const int64_t m0 = (int64_t)by_ * BM + g.r0, n0 = (int64_t)bx_ * BN;   // g.r0: first row of a tail launch
     {   // batch index z = outer * inner + head: (batch, head) views of [B][N][heads*d] tensors
         const int64_t zo = gridDim.z == 1 ? 0 : (int64_t)(blockIdx.z / (unsigned)inner), zi = gridDim.z == 1 ? 0 : (int64_t)(blockIdx.z % (unsigned)inner);
         A += zo * strideA_b + zi * strideA_i;
@@ -970,7 +991,9 @@ k_gemm_nt8(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, cons
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
     const int wm = wave >> 1, wn = wave & 1;
-    const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+    unsigned bx_, by_;
+    xcd_tile(bx_, by_);
+    const int64_t m0 = (int64_t)by_ * BM, n0 = (int64_t)bx_ * BN;
     {
         const int64_t zo = gridDim.z == 1 ? 0 : (int64_t)(blockIdx.z / (unsigned)inner), zi = gridDim.z == 1 ? 0 : (int64_t)(blockIdx.z % (unsigned)inner);
         A += zo * strideA_b + zi * strideA_i;
@@ -1733,8 +1756,10 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
     const int wm = wave >> 1, wn = wave & 1;
     const int fr = lane & 31, fh = lane >> 5;
-    const int64_t tile = blockIdx.y;
-    const int64_t m0 = tile * BM, n0 = (int64_t)blockIdx.x * BN;
+    unsigned bx_, by_;
+    xcd_tile(bx_, by_);
+    const int64_t tile = by_;
+    const int64_t m0 = tile * BM, n0 = (int64_t)bx_ * BN;
     const int HW = H * W;
     // tile geometry: TR image rows of IMGS images starting at (b0, y0).  W is 8 .. 64 and H * W divides or is a multiple of
     // 256 (edadm_conv3_direct_ok): both are powers of two, every division of the set-up is a shift, and the two by the patch
@@ -1759,7 +1784,7 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
     // ---- weight slab of step s = 3 c + ky: 36 (TN = 3) pieces of 1 KiB, 5 per wave (the last ones repeat piece 35); the
     // source is a scalar base + lane * 16: no vector arithmetic per piece
     constexpr int WP = SLAB_BYTES / 1024, WPW = (WP + 7) / 8;
-    const uint8_t* wbase = Wdc + (int64_t)blockIdx.x * NC * 3 * SLAB_BYTES;
+    const uint8_t* wbase = Wdc + (int64_t)bx_ * NC * 3 * SLAB_BYTES;
     const uint32_t wlane = (uint32_t)lane * 16u;
     auto issue_w = [&](int s) {
         const uint8_t* slab = wbase + (int64_t)s * SLAB_BYTES;
