@@ -1712,8 +1712,9 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
     return EDADM_EINVAL;
 }
 
-#if EDADM_GEMM_DT == 0
-// ---- direct 3x3 convolution (stride 1, pad 1) for the long-K int8 layers.
+#if EDADM_GEMM_DT == 0 || EDADM_GEMM_DT == 3
+// ---- direct 3x3 convolution (stride 1, pad 1) for the long-K int8 layers (and, operand type 3, for the two-term f16 expansions
+// of the calibration graph and the first-stage decoder: the same bytes per pixel and chunk, three MFMAs per 16 k-values).
 // The implicit-GEMM kernels above fetch every int8 activation nine times (once per tap) through L2 into LDS, and at
 // 256 x 192 tiles that intake (44 B/clk/CU), not the MFMA, sets their pace.  Here a workgroup owns 256 consecutive
 // output pixels (whole image rows, or whole images at the 8x8 level) and keeps the INPUT PATCH of one 64-channel
@@ -1735,7 +1736,7 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
 // Integer accumulation: the order of taps and chunks does not change a bit of the result.
 // TM = 2: 256-pixel tiles (a wave owns 64 pixels x 96 columns); TM = 1: 128-pixel tiles (32 x 96 per wave) for the layers whose
 // 256-pixel tiles do not fill the chip -- the 8x8 level is 125 workgroups on 256 CUs; as 250 half-size ones every CU works.
-template <int TN, int TM>
+template <int DT, int TN, int TM>
 __global__ void __launch_bounds__(512)
 k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, int64_t M, int64_t N, int B, int H, int W,
                int Cin, int padval, int ups, const float* __restrict__ scale, const float* __restrict__ bias,
@@ -1869,7 +1870,7 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
         for (int ks = 0; ks < 2; ++ks) boff[j][ks] = (uint32_t)(n * 64 + (((2 * ks + fh) ^ ((n >> 2) & 3)) << 4));
     }
 
-    typename Acc<0>::type acc[TM][TN];
+    typename Acc<DT>::type acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1910,6 +1911,31 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
         const uint8_t* Ws = smem + 2 * PATCH_BYTES + (s & 1) * SLAB_BYTES;
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
+            if constexpr (DT == 3) {
+                // a 64-byte chunk = 16 k-values as [hi x16 | lo x16]: fragment 0 is the hi term, fragment 1 the lo term (as in the
+                // GEMM kernels' pair mode): a_hi b_hi + a_hi b_lo + a_lo b_hi
+                uint4 fa[TM], fb[TN], fl[TN > TM ? TN : TM];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const uint4*>(Ps + aoff[i][kx][0]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const uint4*>(Ws + kx * (BN * 64) + boff[j][0]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) mma_step<DT>(fa[i], fb[j], acc[i][j]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fl[j] = *reinterpret_cast<const uint4*>(Ws + kx * (BN * 64) + boff[j][1]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) mma_step<DT>(fa[i], fl[j], acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fl[i] = *reinterpret_cast<const uint4*>(Ps + aoff[i][kx][1]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) mma_step<DT>(fl[i], fb[j], acc[i][j]);
+            } else {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 uint4 fa[TM], fb[TN];
@@ -1920,7 +1946,8 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) mma_step<0>(fa[i], fb[j], acc[i][j]);
+                    for (int j = 0; j < TN; ++j) mma_step<DT>(fa[i], fb[j], acc[i][j]);
+            }
             }
         }
     }
@@ -1936,7 +1963,7 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
     STAMP(t_main);
     float* gpair = TM == 1 ? reinterpret_cast<float*>(smem + 2 * PATCH_BYTES + 2 * SLAB_BYTES + EC_BYTES) + ((wm >> 1) * 2 + wn) * (TN * 32) * 2
                            : nullptr;
-    gemm_epilogue_direct_gnreg<0, TM, TN>(acc, er, lane, m0 + wm * (TM * 32), n0 + wn * (TN * 32), rowadd != nullptr, residual, ldr,
+    gemm_epilogue_direct_gnreg<DT, TM, TN>(acc, er, lane, m0 + wm * (TM * 32), n0 + wn * (TN * 32), rowadd != nullptr, residual, ldr,
                                           out, ldo, gn_ws, N, gpair);
 #ifdef EDADM_STAMPS
     // slots: 0 prologue (entry -> first barrier passed), 1 waits in front of the other steps (6: their vmcnt part), 2 the rest of
@@ -1951,8 +1978,65 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
 #endif
 }
 
+// output-channel block of the direct kernel for a layer: 192 (the 192-multiples of LDM-4 / LDM-8), else 128 (the 128-multiples of
+// the DDPM UNet and of Stable Diffusion's 640 / 1280-channel levels); 0: neither divides N
+// 64-multiples above 128 that neither divides (SD's 320) take the 128-column tile with a padded last block
+static int conv3_bn(int64_t N) { return N % 192 == 0 ? 192 : N % 128 == 0 ? 128 : (N % 64 == 0 && N > 128) ? 128 : 0; }
+// the tile the kernel takes for a shape: 256 or 128 output pixels (0: not a shape for it)
+static int conv3_tile_fits(int64_t B, int64_t H, int64_t W, int64_t BMt) {
+    const int64_t HW = H * W;
+    if (HW >= BMt ? (HW % BMt != 0) : (BMt % HW != 0 || B % (BMt / HW) != 0)) return 0;
+    const int64_t imgs = HW >= BMt ? 1 : BMt / HW, tr = HW >= BMt ? BMt / W : H;
+    const int64_t pieces = (imgs * (tr + 2) * (W + 2) + 15) / 16, ppw = (pieces + 7) / 8;
+    return ppw >= 1 && ppw <= 4;
+}
+// Cin: BYTES per pixel (int8: channels; f16 pair operands: 4 x channels)
+static int conv3_tile(int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t N) {
+    const int bn = conv3_bn(N);
+    if (B <= 0 || H <= 0 || W <= 0 || Cin % 64 || !bn || Cin < 64) return 0;
+    if (W != 8 && W != 16 && W != 32 && W != 64) return 0;
+    if (H & (H - 1)) return 0;                              // the kernel's tile arithmetic is shifts: H * W a power of two
+    if (B * H * W * Cin >= (1ll << 31)) return 0;
+    const bool f256 = conv3_tile_fits(B, H, W, 256), f128 = conv3_tile_fits(B, H, W, 128);
+    static const int64_t small = EDADM_TUNE_I("EDADM_CONV3_TILE128_BELOW", 200);
+    // 256-pixel tiles unless they do not even fill one round of the 256 CUs (the 8x8 level: 125 workgroups -> 250 half-size
+    // ones, 88 -> 68 us; at 300 workgroups, the 16x16 level, both tile sizes take the same time)
+    if (f128 && (!f256 || (B * H * W / 256) * ((N + bn - 1) / bn) <= small)) return 128;
+    return f256 ? 256 : 0;
+}
+template <int DT>
+static int launch_conv3_direct(const void* A, const void* Wdc, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t N, int padval,
+                               int ups, const float* scale, const float* bias, const float* rowadd, int64_t rows_per_batch,
+                               const float* residual, int64_t ldr, float* out, int64_t ldo, float* gn_ws, void* stream) {
+    const int tile = conv3_tile(B, H, W, Cin, N);
+    if (!A || !Wdc || !out || !scale || !tile) return EDADM_EINVAL;
+    if (gn_ws && (H * W) % 64) return EDADM_EINVAL;         // a 64-row slab must not straddle two images
+    if (((uintptr_t)A & 15) || ((uintptr_t)Wdc & 15)) return EDADM_EINVAL;
+    if (rowadd && rows_per_batch < 64) return EDADM_EINVAL;
+    if (ups && ((H | W) & 1)) return EDADM_EINVAL;
+    const int64_t M = B * H * W;
+    if (!rowadd) rows_per_batch = M;
+    ensure_pad_rows((hipStream_t)stream);
+#define CONV3_LAUNCH(TN_, TM_)                                                                                                     \
+    hipLaunchKernelGGL((k_conv3_direct<DT, TN_, TM_>), dim3((unsigned)((N + 64 * TN_ - 1) / (64 * TN_)), (unsigned)(M / (128 * TM_))), dim3(512), 0, \
+                       (hipStream_t)stream, (const uint8_t*)A, (const uint8_t*)Wdc, M, N, (int)B, (int)H, (int)W, (int)Cin, padval,    \
+                       ups ? 1 : 0, scale, bias, rowadd, rows_per_batch, residual, ldr, out, ldo, gn_ws)
+    if (conv3_bn(N) == 192) {
+        if (tile == 256) CONV3_LAUNCH(3, 2);
+        else CONV3_LAUNCH(3, 1);
+    } else {
+        if (tile == 256) CONV3_LAUNCH(2, 2);
+        else CONV3_LAUNCH(2, 1);
+    }
+#undef CONV3_LAUNCH
+    return edadm_launch_status();
+}
+#endif
+
+#if EDADM_GEMM_DT == 0
 // Weight layout of k_conv3_direct from the engine's [N][ky][kx][ci] int8 filter: [N / BN][Cin / 64][ky][kx][BN][64] with
-// the 16-byte chunks of a row at physical position chunk ^ ((n >> 2) & 3) (n = row inside the BN block).
+// the 16-byte chunks of a row at physical position chunk ^ ((n >> 2) & 3) (n = row inside the BN block).  Byte-wise: the two-term
+// f16 filters of the operand-type-3 form ([N][ky][kx][C / 16][hi x16 | lo x16] = 4 C bytes per tap) pack through the same kernel.
 __global__ void k_conv3_pack_w(const int8_t* __restrict__ w, int8_t* __restrict__ out, int64_t N, int64_t Cin, int BN) {
     const int64_t Np = (N + BN - 1) / BN * BN;              // the last block is padded with zero filters
     const int64_t total = Np * 9 * Cin / 16;                // 16-byte chunks
@@ -1970,10 +2054,6 @@ __global__ void k_conv3_pack_w(const int8_t* __restrict__ w, int8_t* __restrict_
         reinterpret_cast<uint4*>(out)[i] = nt * BN + n < N ? *reinterpret_cast<const uint4*>(w + src) : make_uint4(0u, 0u, 0u, 0u);
     }
 }
-// output-channel block of the direct kernel for a layer: 192 (the 192-multiples of LDM-4 / LDM-8), else 128 (the 128-multiples of
-// the DDPM UNet and of Stable Diffusion's 640 / 1280-channel levels); 0: neither divides N
-// 64-multiples above 128 that neither divides (SD's 320) take the 128-column tile with a padded last block
-static int conv3_bn(int64_t N) { return N % 192 == 0 ? 192 : N % 128 == 0 ? 128 : (N % 64 == 0 && N > 128) ? 128 : 0; }
 extern "C" int64_t edadm_conv3_packed_rows(int64_t N) {
     const int bn = conv3_bn(N);
     return bn ? (N + bn - 1) / bn * bn : 0;
@@ -1985,56 +2065,28 @@ extern "C" int edadm_conv3_pack_w(const int8_t* w, int8_t* out, int64_t N, int64
                        out, N, Cin, bn);
     return edadm_launch_status();
 }
-// the tile the kernel takes for a shape: 256 or 128 output pixels (0: not a shape for it)
-static int conv3_tile_fits(int64_t B, int64_t H, int64_t W, int64_t BMt) {
-    const int64_t HW = H * W;
-    if (HW >= BMt ? (HW % BMt != 0) : (BMt % HW != 0 || B % (BMt / HW) != 0)) return 0;
-    const int64_t imgs = HW >= BMt ? 1 : BMt / HW, tr = HW >= BMt ? BMt / W : H;
-    const int64_t pieces = (imgs * (tr + 2) * (W + 2) + 15) / 16, ppw = (pieces + 7) / 8;
-    return ppw >= 1 && ppw <= 4;
-}
-extern "C" int edadm_conv3_direct_tile(int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t N) {
-    const int bn = conv3_bn(N);
-    if (B <= 0 || H <= 0 || W <= 0 || Cin % 64 || !bn || Cin < 64) return 0;
-    if (W != 8 && W != 16 && W != 32 && W != 64) return 0;
-    if (H & (H - 1)) return 0;                              // the kernel's tile arithmetic is shifts: H * W a power of two
-    if (B * H * W * Cin >= (1ll << 31)) return 0;
-    const bool f256 = conv3_tile_fits(B, H, W, 256), f128 = conv3_tile_fits(B, H, W, 128);
-    static const int64_t small = EDADM_TUNE_I("EDADM_CONV3_TILE128_BELOW", 200);
-    // 256-pixel tiles unless they do not even fill one round of the 256 CUs (the 8x8 level: 125 workgroups -> 250 half-size
-    // ones, 88 -> 68 us; at 300 workgroups, the 16x16 level, both tile sizes take the same time)
-    if (f128 && (!f256 || (B * H * W / 256) * ((N + bn - 1) / bn) <= small)) return 128;
-    return f256 ? 256 : 0;
-}
+extern "C" int edadm_conv3_direct_tile(int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t N) { return conv3_tile(B, H, W, Cin, N); }
 extern "C" int edadm_conv3_direct_ok(int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t N) {
-    return edadm_conv3_direct_tile(B, H, W, Cin, N) != 0;
+    return conv3_tile(B, H, W, Cin, N) != 0;
 }
 extern "C" int edadm_qconv3_i8_direct(const int8_t* A, const int8_t* Wdc, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t N,
                                       int padval, int ups, const float* scale, const float* bias, const float* rowadd,
                                       int64_t rows_per_batch, const float* residual, int64_t ldr, float* out, int64_t ldo,
                                       float* gn_ws, void* stream) {
-    const int tile = edadm_conv3_direct_tile(B, H, W, Cin, N);
-    if (!A || !Wdc || !out || !scale || !tile) return EDADM_EINVAL;
-    if (gn_ws && (H * W) % 64) return EDADM_EINVAL;         // a 64-row slab must not straddle two images
-    if (((uintptr_t)A & 15) || ((uintptr_t)Wdc & 15)) return EDADM_EINVAL;
-    if (rowadd && rows_per_batch < 64) return EDADM_EINVAL;
-    if (ups && ((H | W) & 1)) return EDADM_EINVAL;
-    const int64_t M = B * H * W;
-    if (!rowadd) rows_per_batch = M;
-    ensure_pad_rows((hipStream_t)stream);
-#define CONV3_LAUNCH(TN_, TM_)                                                                                                     \
-    hipLaunchKernelGGL((k_conv3_direct<TN_, TM_>), dim3((unsigned)((N + 64 * TN_ - 1) / (64 * TN_)), (unsigned)(M / (128 * TM_))), dim3(512), 0, \
-                       (hipStream_t)stream, (const uint8_t*)A, (const uint8_t*)Wdc, M, N, (int)B, (int)H, (int)W, (int)Cin, padval,    \
-                       ups ? 1 : 0, scale, bias, rowadd, rows_per_batch, residual, ldr, out, ldo, gn_ws)
-    if (conv3_bn(N) == 192) {
-        if (tile == 256) CONV3_LAUNCH(3, 2);
-        else CONV3_LAUNCH(3, 1);
-    } else {
-        if (tile == 256) CONV3_LAUNCH(2, 2);
-        else CONV3_LAUNCH(2, 1);
-    }
-#undef CONV3_LAUNCH
-    return edadm_launch_status();
+    return launch_conv3_direct<0>(A, Wdc, B, H, W, Cin, N, padval, ups, scale, bias, rowadd, rows_per_batch, residual, ldr, out, ldo,
+                                  gn_ws, stream);
+}
+#endif
+
+#if EDADM_GEMM_DT == 3
+// The same kernel on two-term f16 expansions (edadm_split_f16 order 2): A [B][H][W][C / 16][hi x16 | lo x16] f16, the filter
+// [N][3][3][C / 16][hi x16 | lo x16] f16 packed by edadm_conv3_pack_w as 4 C bytes per tap; out = comb[n] * (three-product sum) + bias
+// (+ residual).  C % 16 == 0; shapes as edadm_conv3_direct_ok(B, H, W, 4 C, N).
+extern "C" int edadm_qconv3_f16x3_direct(const void* A, const void* Wdc, int64_t B, int64_t H, int64_t W, int64_t C, int64_t N, int ups,
+                                         const float* comb, const float* bias, const float* residual, int64_t ldr, float* out,
+                                         int64_t ldo, void* stream) {
+    if (C <= 0 || (C & 15)) return EDADM_EINVAL;
+    return launch_conv3_direct<3>(A, Wdc, B, H, W, 4 * C, N, 0, ups, comb, bias, nullptr, 1, residual, ldr, out, ldo, nullptr, stream);
 }
 #endif
 

@@ -46,17 +46,26 @@ class DecoderEngine:
         if x.shape[-1] != w.shape[-1]:                          # latent channels (3) -> 4
             x = torch.nn.functional.pad(x, (0, w.shape[-1] - x.shape[-1])).contiguous()
         if self._f16x3(conv, x, ups):
-            key = ("h", id(conv))
-            if key not in self._wc:                              # the filter's two-term f16 expansion, once
-                self._wc[key] = ops.split_f16(w, w.shape[0], w.shape[1] * w.shape[2], w.shape[3], 2, True)[:2]
             return ops.conv2d_f16x3_nhwc(x, w, b, residual=residual, stride=1, pad=conv.padding[0], ups=ups,
-                                         presplit=self._wc[key])
+                                         presplit=self._presplit(conv))
         if (w.shape[0] <= 4 and w.shape[1] == 3 and w.shape[2] == 3 and conv.padding[0] == 1 and x.shape[-1] <= 320 and residual is None
                 and not ups and x.shape[0] * x.shape[1] < (1 << 31)):
             # conv_out: 3 output channels -- a GEMM tile would compute 64 columns for them (edadm_conv3x3_f32_smalln: fp32 FMAs, one
             # wave per image row, the same kernel as the UNet's last layer)
             return ops.conv3x3_f32_smalln(x, w, b)
         return ops.conv2d_f32_nhwc(x, w, b, residual=residual, stride=1, pad=conv.padding[0], ups=ups)
+
+    def _presplit(self, conv):
+        """(two-term f16 expansion of the filter, its per-row inverse scales, the same packed for the direct 3x3 kernel or None), once"""
+        key = ("h", id(conv))
+        if key not in self._wc:
+            w, _ = self.w(conv)
+            wb, inv_b = ops.split_f16(w, w.shape[0], w.shape[1] * w.shape[2], w.shape[3], 2, True)[:2]
+            wdc = None
+            if w.shape[1] == 3 and w.shape[2] == 3 and w.shape[3] % 16 == 0 and ops.lib.load().edadm_conv3_packed_rows(int(w.shape[0])):
+                wdc = ops.conv3_f16x3_pack_w(wb, w.shape[0], w.shape[3])
+            self._wc[key] = (wb, inv_b, wdc)
+        return self._wc[key]
 
     def _f16x3(self, conv, x, ups=False):
         w, _ = self.w(conv)
@@ -70,12 +79,9 @@ class DecoderEngine:
         if not (self.fuse_gn_split and self._f16x3(conv, x) and ops.gn_split_ok(x, norm.num_groups)):
             return self.conv(conv, self.gn(norm, x, silu), residual=residual)
         w, b = self.w(conv)
-        key = ("h", id(conv))
-        if key not in self._wc:
-            self._wc[key] = ops.split_f16(w, w.shape[0], w.shape[1] * w.shape[2], w.shape[3], 2, True)[:2]
-        wb, inv_b = self._wc[key]
+        wb, inv_b, wdc = self._presplit(conv)
         xa, comb = ops.gn_split_f16(x, norm.weight, norm.bias, norm.num_groups, norm.eps, silu, inv_b, w.shape[0])
-        return ops.conv2d_f16x3_pre(xa, comb, x.shape, w.shape, wb, b, residual=residual, stride=1, pad=conv.padding[0])
+        return ops.conv2d_f16x3_pre(xa, comb, x.shape, w.shape, wb, b, residual=residual, stride=1, pad=conv.padding[0], wdc=wdc)
 
     def gn(self, norm, x, silu):
         st = ops.groupnorm_stats(x, norm.num_groups, norm.eps)

@@ -697,6 +697,30 @@ def f16x3_conv_ok(x, w, ups=False):
     return C % 16 == 0 and B * H * W * C * 4 < (1 << 31) and w.shape[0] >= 16
 
 
+F16X3_DIRECT = True      # 3x3 / stride 1 / pad 1 three-product convolutions with the input patch resident in LDS (edadm_qconv3_f16x3_direct)
+
+
+def conv3_f16x3_direct_ok(B, H, W, C, N):
+    """shapes edadm_qconv3_f16x3_direct takes (H, W: the dimensions the convolution runs over)"""
+    return F16X3_DIRECT and C % 16 == 0 and bool(lib.load().edadm_conv3_direct_ok(int(B), int(H), int(W), int(4 * C), int(N)))
+
+
+def conv3_f16x3_pack_w(wb, N, C):
+    """order-2 expansion of a 3x3 filter [N][9 * 2 C] f16 -> the direct kernel's layout (edadm_conv3_pack_w on 4 C bytes per tap)"""
+    rows = int(lib.load().edadm_conv3_packed_rows(int(N)))
+    out = torch.empty(rows * 9 * 4 * C, dtype=torch.int8, device=wb.device)
+    lib.call("edadm_conv3_pack_w", ctypes.c_void_p(wb.data_ptr()), _p(out, torch.int8), int(N), int(4 * C), _stream())
+    return out
+
+
+def conv3_f16x3_direct(xa, B, H, W, C, wdc, N, comb, bias=None, residual=None, ups=False):
+    """xa: order-2 expansion of the NHWC activation (stored at [H/2][W/2] with ups); -> fp32 [B][H][W][N]"""
+    out = torch.empty(B, H, W, N, dtype=torch.float32, device=xa.device)
+    lib.call("edadm_qconv3_f16x3_direct", ctypes.c_void_p(xa.data_ptr()), _p(wdc, torch.int8), int(B), int(H), int(W), int(C), int(N),
+             1 if ups else 0, _pf(comb), _pf(bias), _pf(residual), int(N), _pf(out), int(N), _stream())
+    return out
+
+
 def conv2d_f16x3_nhwc(x, w, bias=None, residual=None, stride=1, pad=1, ups=False, presplit=None, amax=None):
     """conv2d_f32_nhwc's contract on the f16 MFMA: both operands as two-term f16 expansions ([hi x16 | lo x16] per 16
     channels), three products per K-slice in one implicit GEMM, fp32 accumulation (fp32-grade result, see csrc/elem.hip
@@ -705,8 +729,11 @@ def conv2d_f16x3_nhwc(x, w, bias=None, residual=None, stride=1, pad=1, ups=False
     N, KH, KW, _ = w.shape
     Hl, Wl = (2 * H, 2 * W) if ups else (H, W)
     Ho, Wo = (Hl + 2 * pad - KH) // stride + 1, (Wl + 2 * pad - KW) // stride + 1
-    wb, inv_b = presplit if presplit is not None else split_f16(w, N, KH * KW, C, 2, True)[:2]   # static weights: split once
+    wb, inv_b = (presplit[0], presplit[1]) if presplit is not None else split_f16(w, N, KH * KW, C, 2, True)[:2]   # static weights: split once
     xa, _, comb = split_f16(x, B * H * W, 1, C, 2, False, other=inv_b, N=N, amax=amax)
+    if KH == 3 and KW == 3 and stride == 1 and pad == 1 and conv3_f16x3_direct_ok(B, Hl, Wl, C, N):
+        wdc = presplit[2] if presplit is not None and len(presplit) > 2 else conv3_f16x3_pack_w(wb, N, C)
+        return conv3_f16x3_direct(xa, B, Hl, Wl, C, wdc, N, comb, bias, residual, ups)
     out = torch.empty(B, Ho, Wo, N, dtype=torch.float32, device=x.device)
     geom = (ctypes.c_int32 * 12)(1, B, H, W, 2 * C, Ho, Wo, KH, KW, stride, pad, 1 if ups else 0)
     K2 = KH * KW * 2 * C
@@ -734,12 +761,15 @@ def gn_split_ok(x, G):
     return C % 16 == 0 and C <= 1024 and C % G == 0 and B * G <= 1024 and B <= 65535
 
 
-def conv2d_f16x3_pre(xa, comb, shape, w_shape, wb, bias=None, residual=None, stride=1, pad=1, ups=False):
-    """conv2d_f16x3_nhwc on an activation that is already expanded (gn_split_f16): shape = (B, H, W, C) of the fp32 tensor."""
+def conv2d_f16x3_pre(xa, comb, shape, w_shape, wb, bias=None, residual=None, stride=1, pad=1, ups=False, wdc=None):
+    """conv2d_f16x3_nhwc on an activation that is already expanded (gn_split_f16): shape = (B, H, W, C) of the fp32 tensor.
+    wdc: the filter packed for the direct kernel (conv3_f16x3_pack_w), used when the shape qualifies."""
     B, H, W, C = shape
     N, KH, KW, _ = w_shape
     Hl, Wl = (2 * H, 2 * W) if ups else (H, W)
     Ho, Wo = (Hl + 2 * pad - KH) // stride + 1, (Wl + 2 * pad - KW) // stride + 1
+    if wdc is not None and KH == 3 and KW == 3 and stride == 1 and pad == 1 and conv3_f16x3_direct_ok(B, Hl, Wl, C, N):
+        return conv3_f16x3_direct(xa, B, Hl, Wl, C, wdc, N, comb, bias, residual, ups)
     out = torch.empty(B, Ho, Wo, N, dtype=torch.float32, device=xa.device)
     geom = (ctypes.c_int32 * 12)(1, B, H, W, 2 * C, Ho, Wo, KH, KW, stride, pad, 1 if ups else 0)
     K2 = KH * KW * 2 * C

@@ -396,6 +396,16 @@ int edadm_conv3_direct_tile(int64_t B, int64_t H, int64_t W, int64_t Cin, int64_
 int edadm_qconv3_i8_direct(const int8_t* A, const int8_t* Wdc, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t N,
                            int padval, int ups, const float* scale, const float* bias, const float* rowadd, int64_t rows_per_batch,
                            const float* residual, int64_t ldr, float* out, int64_t ldo, float* gn_ws, void* stream);
+/* The same kernel on the two-term f16 expansions of fp32 operands (edadm_split_f16 order 2): the 3x3 / stride 1 /
+ * pad 1 convolutions of the calibration graph (quant_layer.py:434 on fake-quantised fp32 operands, forward and input gradient) and
+ * of the first-stage decoder (model.py:465-572) with the input patch resident in LDS -- an activation crosses L2 -> LDS once per
+ * 16-channel chunk instead of nine times.  A [B][H][W][C / 16][hi x16 | lo x16] f16 (with ups = 1: stored at [H/2][W/2]), Wdc = the filter
+ * [N][3][3][C / 16][hi x16 | lo x16] f16 packed by edadm_conv3_pack_w(w, out, N, 4 C) (bytes: rows of 4 C per tap);
+ * out[m][n] = comb[n] * (a_hi b_hi + a_hi b_lo + a_lo b_hi) + bias[n] (+ residual).  C % 16 == 0; shapes: edadm_conv3_direct_ok(B, H, W,
+ * 4 C, N). */
+int edadm_qconv3_f16x3_direct(const void* A, const void* Wdc, int64_t B, int64_t H, int64_t W, int64_t C, int64_t N, int ups,
+                              const float* comb, const float* bias, const float* residual, int64_t ldr, float* out, int64_t ldo,
+                              void* stream);
 
 /* ---- H1 training-graph ops: forward and input-gradient of the non-contraction ops of the calibration graph, fp32, on the
  * reference's layouts (csrc/train_ops.hip).  GroupNorm (+ SiLU) over NCHW, `stats` = [B * G][2] (mean, rstd) written by the
