@@ -1766,20 +1766,25 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
     // 256 (edadm_conv3_direct_ok): both are powers of two, every division of the set-up is a shift, and the two by the patch
     // width / patch size (W + 2 is no power of two) go through an exact float reciprocal (indices < 512) -- the set-up was
     // 3.0 k cycles per tile, most of it integer division sequences
+    // Images wider than 64 pixels (the first-stage decoder's 128^2 and 256^2 levels, operand type 3) are cut into 64-column blocks:
+    // a tile is TR rows x TW = 64 columns at (b0, y0, x0), its patch (TR + 2) x 66 pixels as at W = 64; a wave's 64- (32-) pixel
+    // slab is still one contiguous run of output rows.  W <= 64: TW = W, x0 = 0, the geometry above.
     const int lw = 31 - __builtin_clz((unsigned)W), lhw = 31 - __builtin_clz((unsigned)HW);
+    const int ltw = lw > 6 ? 6 : lw, TW = 1 << ltw, lxb = lw - ltw;     // tile width, log2(column blocks per image row)
     const int IMGS = HW >= BM ? 1 : BM >> lhw;
-    const int TR = HW >= BM ? BM >> lw : H;
+    const int TR = HW >= BM ? BM >> ltw : H;
     const int ltpi = HW >= BM ? lhw - LBM : 0;              // log2(tiles per image)
     const int b0 = (int)(HW >= BM ? tile >> ltpi : tile * IMGS);
-    const int y0 = HW >= BM ? (int)(tile & ((1 << ltpi) - 1)) * TR : 0;
-    const int PR = TR + 2, PW = W + 2;
+    const int ti = HW >= BM ? (int)(tile & ((1 << ltpi) - 1)) : 0;
+    const int y0 = (ti >> lxb) * TR, x0 = (ti & ((1 << lxb) - 1)) << ltw;
+    const int PR = TR + 2, PW = TW + 2;
     const float rPW = 1.0f / (float)PW, rPP = 1.0f / (float)(PR * PW);
     auto div_small = [](int a, float r) { return (int)(((float)a + 0.5f) * r); };   // a / b for 0 <= a < 2^16, r = 1 / b
     const int NP = IMGS * PR * PW;
     const int pieces = (NP + 15) >> 4;
     const int PPW = (pieces + 7) >> 3;                      // 1 .. 4 (checked by the launcher)
     const int NC = Cin >> 6;
-    const int KSH = W >= 32 ? 2 : 1;
+    const int KSH = TW >= 32 ? 2 : 1;
     const uint8_t* pad_row = g_pad_rows + (int)(uint8_t)padval * 64;
 
     // ---- weight slab of step s = 3 c + ky: 36 (TN = 3) pieces of 1 KiB, 5 per wave (the last ones repeat piece 35); the
@@ -1817,7 +1822,7 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
             const int img = div_small(P, rPP), rem = P - img * (PR * PW);
             const int py = div_small(rem, rPW), px = rem - py * PW;
             const int sc = (lane & 3) ^ ((px >> KSH) & 3);
-            const int y = y0 + py - 1, x = px - 1;
+            const int y = y0 + py - 1, x = x0 + px - 1;
             // ups: the convolution runs over the nearest-2x upsampled image (H x W are ITS dimensions); pixel (y, x) of
             // it is pixel (y / 2, x / 2) of the stored tensor -- the upsampled tensor is never written
             if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
@@ -1845,10 +1850,10 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
     int pp[TM], pcol[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int p = wm * (TM * 32) + i * 32 + fr;         // pixel of the tile, NHWC order
-        const int ltw = HW >= BM ? LBM : lhw;               // TR * W = BM or H * W
-        const int img = p >> ltw, rem = p & ((1 << ltw) - 1);
-        const int yl = rem >> lw, x = rem & (W - 1);
+        const int p = wm * (TM * 32) + i * 32 + fr;         // pixel of the tile, row-major over its TR x TW pixels
+        const int lti = HW >= BM ? LBM : lhw;               // TR * TW = BM or H * W
+        const int img = p >> lti, rem = p & ((1 << lti) - 1);
+        const int yl = rem >> ltw, x = rem & (TW - 1);
         pp[i] = (img * PR + yl) * PW + x;
         pcol[i] = x;
     }
@@ -1963,7 +1968,13 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
     STAMP(t_main);
     float* gpair = TM == 1 ? reinterpret_cast<float*>(smem + 2 * PATCH_BYTES + 2 * SLAB_BYTES + EC_BYTES) + ((wm >> 1) * 2 + wn) * (TN * 32) * 2
                            : nullptr;
-    gemm_epilogue_direct_gnreg<DT, TM, TN>(acc, er, lane, m0 + wm * (TM * 32), n0 + wn * (TN * 32), rowadd != nullptr, residual, ldr,
+    // first output row of this wave's slab: m0 + wm * (TM * 32) unless the image is cut into column blocks
+    int64_t row0 = m0 + wm * (TM * 32);
+    if (lxb) {
+        const int ps = wm * (TM * 32);
+        row0 = ((int64_t)b0 * H + y0 + (ps >> ltw)) * W + x0 + (ps & (TW - 1));
+    }
+    gemm_epilogue_direct_gnreg<DT, TM, TN>(acc, er, lane, row0, n0 + wn * (TN * 32), rowadd != nullptr, residual, ldr,
                                           out, ldo, gn_ws, N, gpair);
 #ifdef EDADM_STAMPS
     // slots: 0 prologue (entry -> first barrier passed), 1 waits in front of the other steps (6: their vmcnt part), 2 the rest of
@@ -1984,17 +1995,19 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
 static int conv3_bn(int64_t N) { return N % 192 == 0 ? 192 : N % 128 == 0 ? 128 : (N % 64 == 0 && N > 128) ? 128 : 0; }
 // the tile the kernel takes for a shape: 256 or 128 output pixels (0: not a shape for it)
 static int conv3_tile_fits(int64_t B, int64_t H, int64_t W, int64_t BMt) {
-    const int64_t HW = H * W;
+    const int64_t HW = H * W, tw = W > 64 ? 64 : W;
     if (HW >= BMt ? (HW % BMt != 0) : (BMt % HW != 0 || B % (BMt / HW) != 0)) return 0;
-    const int64_t imgs = HW >= BMt ? 1 : BMt / HW, tr = HW >= BMt ? BMt / W : H;
-    const int64_t pieces = (imgs * (tr + 2) * (W + 2) + 15) / 16, ppw = (pieces + 7) / 8;
+    const int64_t imgs = HW >= BMt ? 1 : BMt / HW, tr = HW >= BMt ? BMt / tw : H;
+    if (tr > H) return 0;
+    const int64_t pieces = (imgs * (tr + 2) * (tw + 2) + 15) / 16, ppw = (pieces + 7) / 8;
     return ppw >= 1 && ppw <= 4;
 }
-// Cin: BYTES per pixel (int8: channels; f16 pair operands: 4 x channels)
-static int conv3_tile(int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t N) {
+// Cin: BYTES per pixel (int8: channels; f16 pair operands: 4 x channels).  wide: images of 128 .. 1024 columns, cut into 64-column
+// blocks (no per-image row-add, no GroupNorm partials: the launcher checks)
+static int conv3_tile(int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t N, bool wide = false) {
     const int bn = conv3_bn(N);
     if (B <= 0 || H <= 0 || W <= 0 || Cin % 64 || !bn || Cin < 64) return 0;
-    if (W != 8 && W != 16 && W != 32 && W != 64) return 0;
+    if (W != 8 && W != 16 && W != 32 && W != 64 && !(wide && (W == 128 || W == 256 || W == 512 || W == 1024))) return 0;
     if (H & (H - 1)) return 0;                              // the kernel's tile arithmetic is shifts: H * W a power of two
     if (B * H * W * Cin >= (1ll << 31)) return 0;
     const bool f256 = conv3_tile_fits(B, H, W, 256), f128 = conv3_tile_fits(B, H, W, 128);
@@ -2008,8 +2021,9 @@ template <int DT>
 static int launch_conv3_direct(const void* A, const void* Wdc, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t N, int padval,
                                int ups, const float* scale, const float* bias, const float* rowadd, int64_t rows_per_batch,
                                const float* residual, int64_t ldr, float* out, int64_t ldo, float* gn_ws, void* stream) {
-    const int tile = conv3_tile(B, H, W, Cin, N);
+    const int tile = conv3_tile(B, H, W, Cin, N, DT == 3);
     if (!A || !Wdc || !out || !scale || !tile) return EDADM_EINVAL;
+    if (W > 64 && (rowadd || gn_ws)) return EDADM_EINVAL;
     if (gn_ws && (H * W) % 64) return EDADM_EINVAL;         // a 64-row slab must not straddle two images
     if (((uintptr_t)A & 15) || ((uintptr_t)Wdc & 15)) return EDADM_EINVAL;
     if (rowadd && rows_per_batch < 64) return EDADM_EINVAL;
@@ -2081,7 +2095,10 @@ extern "C" int edadm_qconv3_i8_direct(const int8_t* A, const int8_t* Wdc, int64_
 #if EDADM_GEMM_DT == 3
 // The same kernel on two-term f16 expansions (edadm_split_f16 order 2): A [B][H][W][C / 16][hi x16 | lo x16] f16, the filter
 // [N][3][3][C / 16][hi x16 | lo x16] f16 packed by edadm_conv3_pack_w as 4 C bytes per tap; out = comb[n] * (three-product sum) + bias
-// (+ residual).  C % 16 == 0; shapes as edadm_conv3_direct_ok(B, H, W, 4 C, N).
+// (+ residual).  C % 16 == 0; shapes: edadm_conv3_f16x3_direct_ok (W up to 1024: images wider than 64 pixels in 64-column blocks).
+extern "C" int edadm_conv3_f16x3_direct_ok(int64_t B, int64_t H, int64_t W, int64_t C, int64_t N) {
+    return C > 0 && !(C & 15) && conv3_tile(B, H, W, 4 * C, N, true) != 0;
+}
 extern "C" int edadm_qconv3_f16x3_direct(const void* A, const void* Wdc, int64_t B, int64_t H, int64_t W, int64_t C, int64_t N, int ups,
                                          const float* comb, const float* bias, const float* residual, int64_t ldr, float* out,
                                          int64_t ldo, void* stream) {

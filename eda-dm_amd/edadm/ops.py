@@ -702,7 +702,7 @@ F16X3_DIRECT = True      # 3x3 / stride 1 / pad 1 three-product convolutions wit
 
 def conv3_f16x3_direct_ok(B, H, W, C, N):
     """shapes edadm_qconv3_f16x3_direct takes (H, W: the dimensions the convolution runs over)"""
-    return F16X3_DIRECT and C % 16 == 0 and bool(lib.load().edadm_conv3_direct_ok(int(B), int(H), int(W), int(4 * C), int(N)))
+    return F16X3_DIRECT and bool(lib.load().edadm_conv3_f16x3_direct_ok(int(B), int(H), int(W), int(C), int(N)))
 
 
 def conv3_f16x3_pack_w(wb, N, C):

@@ -401,8 +401,9 @@ int edadm_qconv3_i8_direct(const int8_t* A, const int8_t* Wdc, int64_t B, int64_
  * of the first-stage decoder (model.py:465-572) with the input patch resident in LDS -- an activation crosses L2 -> LDS once per
  * 16-channel chunk instead of nine times.  A [B][H][W][C / 16][hi x16 | lo x16] f16 (with ups = 1: stored at [H/2][W/2]), Wdc = the filter
  * [N][3][3][C / 16][hi x16 | lo x16] f16 packed by edadm_conv3_pack_w(w, out, N, 4 C) (bytes: rows of 4 C per tap);
- * out[m][n] = comb[n] * (a_hi b_hi + a_hi b_lo + a_lo b_hi) + bias[n] (+ residual).  C % 16 == 0; shapes: edadm_conv3_direct_ok(B, H, W,
- * 4 C, N). */
+ * out[m][n] = comb[n] * (a_hi b_hi + a_hi b_lo + a_lo b_hi) + bias[n] (+ residual).  C % 16 == 0; shapes: edadm_conv3_f16x3_direct_ok --
+ * W in {8 .. 64} as the int8 form, and 128 .. 1024 (the decoder's upper levels: images cut into 64-column blocks). */
+int edadm_conv3_f16x3_direct_ok(int64_t B, int64_t H, int64_t W, int64_t C, int64_t N);
 int edadm_qconv3_f16x3_direct(const void* A, const void* Wdc, int64_t B, int64_t H, int64_t W, int64_t C, int64_t N, int ups,
                               const float* comb, const float* bias, const float* residual, int64_t ldr, float* out, int64_t ldo,
                               void* stream);

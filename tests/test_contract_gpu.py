@@ -95,3 +95,39 @@ def test_f16_three_product_is_fp32_grade(kind):
     back = (p[:, 0].double() + p[:, 1].double()) * float(inv[0])
     err = (back.cpu() - a.double()).abs()
     assert float((err - a.double().abs() * 2.0 ** -21).max()) <= 2.0 ** -24 * float(inv[0])
+
+
+@pytest.mark.parametrize("B,H,W,C,N,ups,res", [(2, 64, 64, 128, 192, False, True), (4, 32, 32, 192, 384, False, False),
+                                                (2, 64, 64, 64, 128, True, True), (8, 16, 16, 576, 576, False, True),
+                                                (16, 8, 8, 960, 960, False, False), (1, 128, 128, 64, 192, False, True),
+                                                (2, 256, 256, 32, 128, False, True), (1, 128, 128, 64, 128, True, False),
+                                                (1, 512, 128, 32, 128, False, False), (3, 64, 64, 64, 320, False, False)])
+def test_direct_three_product_convolution(B, H, W, C, N, ups, res):
+    """edadm_qconv3_f16x3_direct (input patch resident in LDS; images wider than 64 pixels in 64-column blocks; the nearest-2x
+    upsample read in place) against an fp64 convolution and against the implicit-GEMM form of the same three-product contraction:
+    fp32-grade, and the two forms differ by accumulation order only."""
+    import torch.nn.functional as F
+    from edadm import ops
+    torch.manual_seed(B + H + C + N)
+    Hs, Ws = (H // 2, W // 2) if ups else (H, W)
+    x = torch.randn(B, Hs, Ws, C, device="cuda")
+    w = torch.randn(N, 3, 3, C, device="cuda") * 0.05
+    bias = torch.randn(N, device="cuda")
+    r = torch.randn(B, H, W, N, device="cuda") if res else None
+    assert ops.conv3_f16x3_direct_ok(B, H, W, C, N)
+    out = {}
+    for flag in (True, False):
+        ops.F16X3_DIRECT = flag
+        try:
+            out[flag] = ops.conv2d_f16x3_nhwc(x, w, bias, residual=r, stride=1, pad=1, ups=ups)
+        finally:
+            ops.F16X3_DIRECT = True
+    xd = x.double().permute(0, 3, 1, 2)
+    if ups:
+        xd = F.interpolate(xd, scale_factor=2, mode="nearest")
+    ref = F.conv2d(xd, w.double().permute(0, 3, 1, 2), bias.double(), padding=1).permute(0, 2, 3, 1)
+    if res:
+        ref = ref + r.double()
+    sc = ref.abs().max().item()
+    e_d, e_i = ((out[f].double() - ref).abs().max().item() / sc for f in (True, False))
+    assert e_d <= 5e-6 and e_d <= 3 * e_i + 1e-7, (e_d, e_i)

@@ -26,7 +26,10 @@ def timeit(fn, n=10):
 torch.manual_seed(0)
 for (B, H, W, C, N, ups, res) in [(2, 64, 64, 128, 192, False, True), (4, 32, 32, 192, 384, False, False), (2, 64, 64, 64, 128, True, True),
                                   (8, 16, 16, 576, 576, False, True), (16, 8, 8, 960, 960, False, False), (32, 64, 64, 192, 192, False, False),
-                                  (32, 64, 64, 384, 192, False, False), (16, 64, 64, 512, 512, False, True)]:
+                                  (32, 64, 64, 384, 192, False, False), (16, 64, 64, 512, 512, False, True),
+                                  (1, 128, 128, 64, 192, False, True), (2, 256, 256, 32, 128, False, True), (1, 128, 128, 64, 128, True, False),
+                                  (1, 512, 128, 32, 128, False, False), (16, 128, 128, 256, 256, False, True), (16, 128, 128, 512, 512, True, False),
+                                  (16, 256, 256, 128, 128, False, True), (16, 256, 256, 256, 256, True, False)]:
     Hs, Ws = (H // 2, W // 2) if ups else (H, W)
     x = torch.randn(B, Hs, Ws, C, device=dev)
     w = torch.randn(N, 3, 3, C, device=dev) * 0.05
