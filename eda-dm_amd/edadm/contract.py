@@ -32,6 +32,8 @@ F16X3_MIN_NK = 256 * 256      # smallest weight matrix (N x K) whose linear prod
 # its cached inputs to its loss (edadm/recon.py stores those caches in NHWC) instead of converting around every convolution --
 # 29 conversion passes, 10 % of a 64x64 ResBlock iteration.  False: NCHW between operators (tools / A-B tests).
 CHANNELS_LAST = True
+# few-tile 3x3 convolutions (the 8x8 / 16x16 levels) take the direct three-product kernel too instead of im2col + split-K GEMM (+ col2im)
+DIRECT_SMALL = True
 
 
 def _f16x3_linear(M, N, K):
@@ -189,7 +191,9 @@ class _Conv2dFn(torch.autograd.Function):
         M = B * Ho * Wo
         px = None
         FLOPS[0] += 2.0 * M * O * KH * KW * C
-        if ((M + 127) // 128) * ((O + 127) // 128) >= 128:
+        direct = (DIRECT_SMALL and F16X3 and KH == 3 and KW == 3 and stride == 1 and pad == 1 and ops.f16x3_conv_ok(xh, w4)
+                  and ops.conv3_f16x3_direct_ok(B, H, W, Cp, O))
+        if direct or ((M + 127) // 128) * ((O + 127) // 128) >= 128:
             if F16X3 and ops.f16x3_conv_ok(xh, w4):
                 px = _amax(xh)
                 out = ops.conv2d_f16x3_nhwc(xh, w4, bias, stride=stride, pad=pad, amax=px)   # [B][Ho][Wo][O]
@@ -215,6 +219,9 @@ class _Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             M = B * Ho * Wo
             big = ((B * H * W + 127) // 128) * ((Cp + 127) // 128) >= 512      # few tiles: the split-K GEMM + col2im wins
+            if (DIRECT_SMALL and F16X3 and KH == 3 and KW == 3 and stride == 1 and pad == 1 and O % 16 == 0
+                    and ops.conv3_f16x3_direct_ok(B, Ho, Wo, O, Cp)):
+                big = True                                   # the direct kernel does not need many tiles to beat im2col + col2im
             if IMPLICIT_DGRAD and (not one) and stride == 1 and KH == KW and 2 * pad == KH - 1 and O % 4 == 0 and big:
                 # input gradient of a stride-1 "same" convolution = the same convolution of gy with the spatially
                 # flipped, transposed filter: one implicit GEMM, no [M][K] gradient-of-columns matrix, no col2im pass

@@ -10,6 +10,8 @@ qnn, sd, calib = bench.build_quantised_unet(dev, calib_rows=16)
 from qdiff.block_recon import block_reconstruction
 import edadm.recon as er
 from edadm import contract
+if os.environ.get("DIRECT_SMALL"):
+    contract.DIRECT_SMALL = os.environ["DIRECT_SMALL"] != "0"
 if os.environ.get("MIN_NK"):
     contract.F16X3_MIN_NK = int(os.environ["MIN_NK"])
 g = torch.Generator().manual_seed(3)
@@ -20,7 +22,7 @@ qnn.set_quant_state(True, True)
 iters = int(os.environ.get("ITERS", "120"))
 m = qnn.model
 units = (("res 192@64", m.input_blocks[1][0]), ("tf 384@32", m.input_blocks[4][1].transformer_blocks[0]),
-         ("res 384@32", m.input_blocks[5][0]), ("tf 576@16", m.input_blocks[7][1].transformer_blocks[0]),
+         ("res 384@32", m.input_blocks[5][0]), ("res 576@16", m.input_blocks[8][0]), ("tf 576@16", m.input_blocks[7][1].transformer_blocks[0]),
          ("res 960@8", m.middle_block[0]), ("tf 960@8", m.middle_block[1].transformer_blocks[0]),
          ("up 384->192@64", m.output_blocks[9][0]), ("up tf 384@32", m.output_blocks[6][1].transformer_blocks[0]))
 sel = os.environ.get("UNITS")
