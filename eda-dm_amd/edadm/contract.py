@@ -32,8 +32,9 @@ F16X3_MIN_NK = 256 * 256      # smallest weight matrix (N x K) whose linear prod
 # its cached inputs to its loss (edadm/recon.py stores those caches in NHWC) instead of converting around every convolution --
 # 29 conversion passes, 10 % of a 64x64 ResBlock iteration.  False: NCHW between operators (tools / A-B tests).
 CHANNELS_LAST = True
-# few-tile 3x3 convolutions (the 8x8 / 16x16 levels) take the direct three-product kernel too instead of im2col + split-K GEMM (+ col2im)
-DIRECT_SMALL = True
+# few-tile 3x3 convolutions (the 8x8 / 16x16 levels) on the direct three-product kernel too instead of im2col + split-K GEMM (+ col2im):
+# measured neutral at 16x16 and slower at 8x8 (tools/recon_time.py DIRECT_SMALL=1: ResBlock 960 @ 8x8 2.72 -> 2.84 ms) -- off
+DIRECT_SMALL = False
 
 
 def _f16x3_linear(M, N, K):
