@@ -88,6 +88,23 @@ def _matmul_nt(a2d, w2d, bias=None, amax=None):
     return out if bias is None else out.add_(bias)
 
 
+WGRAD_SWAP = True
+
+
+def _wgrad_product(gt, at, S, O, K, Ms):
+    """sum over the S slabs of gt [O][..] . at [K][..]^T -> [O][K].  The 8-wave kernel's tiles are 256 rows x 192 columns: with the
+    outputs as rows, O = 192 fills 75 % of a tile's rows (384: two tiles at 75 %, 576: three) -- when the other orientation wastes
+    less, the product is formed transposed ([K][O]: 256-row tiles over 9 C, O as one or more full 192-column blocks) and the small
+    result turned back."""
+    def waste(rows, cols):
+        return (((rows + 255) // 256) * 256 / rows) * (((cols + 191) // 192) * 192 / cols)
+    if WGRAD_SWAP and waste(K, O) < 0.9 * waste(O, K):
+        slabs = ops.gemm_f16x3_nt(at, at.shape[1], 2 * Ms, gt, gt.shape[1], 2 * Ms, S, K, O, 2 * Ms)
+        return ops.transpose_f32(ops.sum_slabs(slabs) if S > 1 else slabs[0])
+    slabs = ops.gemm_f16x3_nt(gt, gt.shape[1], 2 * Ms, at, at.shape[1], 2 * Ms, S, O, K, 2 * Ms)
+    return ops.sum_slabs(slabs) if S > 1 else slabs[0]
+
+
 def _wgrad(gy2d, a2d, amax_g=None, amax_a=None, conv=None):
     """dW[o][k] = gy2d^T . a2d  (gy2d [M][O], a2d [M][K]).  conv = (x_nhwc, (KH, KW, stride, pad, Ho, Wo)): a2d is the
     im2col of x_nhwc and is never materialised (f16 three-product path only)."""
@@ -100,8 +117,7 @@ def _wgrad(gy2d, a2d, amax_g=None, amax_a=None, conv=None):
             Ms = M // S
             gt, inv_g = ops.transpose_split_f16(gy2d, Ms, 2, amax=amax_g)
             at, inv_a = ops.transpose_split_f16(xh, Ms, 2, amax=amax_a, conv=(KH, KW, stride, pad, Ho, Wo))
-            slabs = ops.gemm_f16x3_nt(gt, gt.shape[1], 2 * Ms, at, at.shape[1], 2 * Ms, S, O, K, 2 * Ms)
-            return (ops.sum_slabs(slabs) if S > 1 else slabs[0]).mul_(inv_g * inv_a)
+            return _wgrad_product(gt, at, S, O, K, Ms).mul_(inv_g * inv_a)
         a2d = ops.im2col_f32(xh, KH, KW, stride, pad, Ho, Wo)
     K = a2d.shape[1]
     if M % 4:
@@ -117,8 +133,7 @@ def _wgrad(gy2d, a2d, amax_g=None, amax_a=None, conv=None):
         # the f16 MFMA; the two power-of-two scales come off after the ordered slab sum
         gt, inv_g = ops.transpose_split_f16(gy2d, Ms, 2, amax=amax_g)    # [O][S][Ms / 16][2][16]
         at, inv_a = ops.transpose_split_f16(a2d, Ms, 2, amax=amax_a)     # [K][S][Ms / 16][2][16]
-        slabs = ops.gemm_f16x3_nt(gt, gt.shape[1], 2 * Ms, at, at.shape[1], 2 * Ms, S, O, K, 2 * Ms)
-        return (ops.sum_slabs(slabs) if S > 1 else slabs[0]).mul_(inv_g * inv_a)
+        return _wgrad_product(gt, at, S, O, K, Ms).mul_(inv_g * inv_a)
     gyT, aT = ops.transpose_f32(gy2d), ops.transpose_f32(a2d)            # [O][M], [K][M]
     if S == 1:
         return ops.gemm_f32_nt(gyT, aT, O, K, M)
