@@ -100,7 +100,7 @@ def _wgrad_product(gt, at, S, O, K, Ms):
         return (((rows + 255) // 256) * 256 / rows) * (((cols + 191) // 192) * 192 / cols)
     if WGRAD_SWAP and waste(K, O) < 0.9 * waste(O, K):
         slabs = ops.gemm_f16x3_nt(at, at.shape[1], 2 * Ms, gt, gt.shape[1], 2 * Ms, S, K, O, 2 * Ms)
-        return ops.transpose_f32(ops.sum_slabs(slabs) if S > 1 else slabs[0])
+        return (ops.sum_slabs(slabs) if S > 1 else slabs[0]).t().contiguous()      # [K][O] -> [O][K]: a weight-sized copy
     slabs = ops.gemm_f16x3_nt(gt, gt.shape[1], 2 * Ms, at, at.shape[1], 2 * Ms, S, O, K, 2 * Ms)
     return ops.sum_slabs(slabs) if S > 1 else slabs[0]
 
