@@ -163,8 +163,14 @@ class DecoderEngine:
         up = 2 ** (self.dec.num_resolutions - 1)
         per = z_nchw.shape[2] * z_nchw.shape[3] * up * up
         nb = max(1, min(B, self.chunk_pixels // per))
-        outs = []
-        for b0 in range(0, B, nb):
-            zc = ops.nchw_to_nhwc(z_nchw[b0:b0 + nb].contiguous().float())
+        # balanced chunks: 50 images under a 16-image cap decode as 13 + 13 + 12 + 12, not 16 + 16 + 16 + 2 (a 2-image chunk leaves the
+        # 64x64 level with 32 tiles for 256 CUs)
+        n_chunks = (B + nb - 1) // nb
+        base, extra = divmod(B, n_chunks)
+        outs, b0 = [], 0
+        for i in range(n_chunks):
+            n = base + (1 if i < extra else 0)
+            zc = ops.nchw_to_nhwc(z_nchw[b0:b0 + n].contiguous().float())
             outs.append(ops.nhwc_to_nchw(self.decode_nhwc(zc)))
-        return torch.cat(outs)
+            b0 += n
+        return torch.cat(outs) if len(outs) > 1 else outs[0]
