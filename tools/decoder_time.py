@@ -6,6 +6,8 @@ import torch
 import bench
 dev = torch.device("cuda", 0)
 dec = bench.make_decoder(dev)
+if os.environ.get("CHUNK"):
+    dec.chunk_pixels = int(os.environ["CHUNK"])
 for fuse in (True, False, True):
     dec.fuse_gn_split = fuse
     r = bench.time_decoder(dec, dev, 50)
