@@ -131,3 +131,28 @@ def test_direct_three_product_convolution(B, H, W, C, N, ups, res):
     sc = ref.abs().max().item()
     e_d, e_i = ((out[f].double() - ref).abs().max().item() / sc for f in (True, False))
     assert e_d <= 5e-6 and e_d <= 3 * e_i + 1e-7, (e_d, e_i)
+
+
+@pytest.mark.parametrize("B,C,H,W,O", [(4, 64, 32, 32, 192), (2, 192, 16, 16, 384), (8, 96, 16, 16, 576)])
+def test_weight_gradient_orientation(B, C, H, W, O):
+    """contract._wgrad_product forms the weight gradient as [9 C][O] when that wastes fewer rows of the 256 x 192 tiles and turns the
+    result back: the same gradient as the [O][9 C] orientation up to the order of the fp32 slab sums, and as torch's in fp64."""
+    from edadm import contract
+    torch.manual_seed(B + C + O)
+    x = torch.randn(B, C, H, W, device="cuda")
+    w = (torch.randn(O, C, 3, 3, device="cuda") * 0.05).requires_grad_(True)
+    gy = torch.randn(B, O, H, W, device="cuda")
+    grads = {}
+    for flag in (True, False):
+        contract.WGRAD_SWAP = flag
+        try:
+            w.grad = None
+            (contract.conv2d(x, w, None, 1, 1) * gy).sum().backward()
+            grads[flag] = w.grad.clone()
+        finally:
+            contract.WGRAD_SWAP = True
+    wd = w.detach().double().requires_grad_(True)
+    (F.conv2d(x.double(), wd, None, 1, 1) * gy.double()).sum().backward()
+    sc = wd.grad.abs().max().item()
+    for flag in (True, False):
+        assert (grads[flag].double() - wd.grad).abs().max().item() <= 3e-6 * sc, flag
