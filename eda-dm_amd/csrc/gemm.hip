@@ -1742,11 +1742,12 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
                int Cin, int padval, int ups, const float* __restrict__ scale, const float* __restrict__ bias,
                const float* __restrict__ rowadd, int64_t rows_per_batch, const float* __restrict__ residual, int64_t ldr,
                float* __restrict__ out, int64_t ldo, float* __restrict__ gn_ws) {
-    constexpr int BM = 128 * TM, BN = 64 * TN, LBM = TM == 2 ? 8 : 7;
+    constexpr int BM = 128 * TM, BN = 64 * TN, LBM = TM == 4 ? 9 : TM == 2 ? 8 : 7;
+    constexpr int PPWMAX = TM == 4 ? 6 : 4;                 // patch pieces per wave and chunk (512-pixel tiles: 10 x 66 pixels = 42 pieces)
     STAMP(t_kernel);
-    constexpr int PATCH_BYTES = 32 * 1024;                  // 8 waves x 4 pieces x 1 KiB >= 16 * ceil(NP / 16) * 64
+    constexpr int PATCH_BYTES = TM == 4 ? 42 * 1024 : 32 * 1024;   // >= 16 * ceil(NP / 16) * 64 (surplus piece slots of a wave repeat the last piece)
     constexpr int SLAB_BYTES = 3 * BN * 64;                 // one filter row of one 64-channel chunk
-    constexpr int RA = BM / 16 + 1;
+    constexpr int RA = TM == 4 ? 1 : BM / 16 + 1;           // 512-pixel tiles take no per-image row-add (launcher)
     constexpr int EC_BYTES = (2 + RA) * BN * 4 + 16;
     constexpr int GP_BYTES = TM == 1 ? 4 * (TN * 32) * 2 * 4 : 0;   // GroupNorm partial hand-over between the two waves of a slab
     constexpr int SMEM_BYTES = 2 * PATCH_BYTES + 2 * SLAB_BYTES + EC_BYTES + GP_BYTES;
@@ -1807,11 +1808,11 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
     // ---- this lane's patch pieces: piece q covers patch pixels 16 q .. 16 q + 15, lane -> pixel 16 q + lane / 4,
     // physical chunk lane % 4 (= logical chunk (lane % 4) ^ ((P >> 2) & 3) of the source pixel)
     // source pointer of each piece for the chunk to be requested next (padding lanes point into g_pad_rows and do not advance)
-    const uint8_t* pptr[4];
-    int pinc[4];
-    uint32_t pdst[4];                                       // LDS byte offset of the piece inside a patch buffer (wave-uniform)
+    const uint8_t* pptr[PPWMAX];
+    int pinc[PPWMAX];
+    uint32_t pdst[PPWMAX];                                       // LDS byte offset of the piece inside a patch buffer (wave-uniform)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < PPWMAX; ++i) {
         int q = wave + 8 * i;
         if (q > pieces - 1) q = pieces - 1;
         const int P = q * 16 + (lane >> 2);
@@ -1838,7 +1839,7 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
         const uint32_t base = lds0 + (uint32_t)(pnext * PATCH_BYTES);
         pnext ^= 1;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < PPWMAX; ++i) {
             if (i < PPW) {
                 glds16(pptr[i], base + pdst[i]);
                 pptr[i] += pinc[i];
@@ -1897,7 +1898,9 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
         STAMP(ts0);
         // B(s) (and patch(c) when ky == 0) have landed once at most the next chunk's patch pieces are still in flight
         if (ky == 1 && c + 1 < NC) {
-            if (PPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (PPW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (PPW == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else if (PPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else if (PPW == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             else if (PPW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
@@ -1968,14 +1971,21 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
     STAMP(t_main);
     float* gpair = TM == 1 ? reinterpret_cast<float*>(smem + 2 * PATCH_BYTES + 2 * SLAB_BYTES + EC_BYTES) + ((wm >> 1) * 2 + wn) * (TN * 32) * 2
                            : nullptr;
-    // first output row of this wave's slab: m0 + wm * (TM * 32) unless the image is cut into column blocks
-    int64_t row0 = m0 + wm * (TM * 32);
-    if (lxb) {
-        const int ps = wm * (TM * 32);
-        row0 = ((int64_t)b0 * H + y0 + (ps >> ltw)) * W + x0 + (ps & (TW - 1));
+    // first output row of a run of this wave's slab: m0 + pixel unless the image is cut into column blocks
+    auto slab_row = [&](int ps) -> int64_t {
+        return lxb ? ((int64_t)b0 * H + y0 + (ps >> ltw)) * W + x0 + (ps & (TW - 1)) : m0 + ps;
+    };
+    if constexpr (TM == 4) {
+        // 128 pixels per wave = two 64-pixel runs (two tile rows when the image is cut into column blocks): the 64-row epilogue twice
+        typedef typename Acc<DT>::type AccHalf[2][TN];
+        gemm_epilogue_direct_gnreg<DT, 2, TN>(*reinterpret_cast<AccHalf*>(&acc[0]), er, lane, slab_row(wm * 128), n0 + wn * (TN * 32), false,
+                                             residual, ldr, out, ldo, nullptr, N, nullptr);
+        gemm_epilogue_direct_gnreg<DT, 2, TN>(*reinterpret_cast<AccHalf*>(&acc[2]), er, lane, slab_row(wm * 128 + 64), n0 + wn * (TN * 32), false,
+                                             residual, ldr, out, ldo, nullptr, N, nullptr);
+    } else {
+        gemm_epilogue_direct_gnreg<DT, TM, TN>(acc, er, lane, slab_row(wm * (TM * 32)), n0 + wn * (TN * 32), rowadd != nullptr, residual, ldr,
+                                              out, ldo, gn_ws, N, gpair);
     }
-    gemm_epilogue_direct_gnreg<DT, TM, TN>(acc, er, lane, row0, n0 + wn * (TN * 32), rowadd != nullptr, residual, ldr,
-                                          out, ldo, gn_ws, N, gpair);
 #ifdef EDADM_STAMPS
     // slots: 0 prologue (entry -> first barrier passed), 1 waits in front of the other steps (6: their vmcnt part), 2 the rest of
     // the main loop, 3 epilogue incl. draining its stores, 4 samples, 5 total.  ONE wave of every eighth workgroup: the atomics
@@ -2000,7 +2010,7 @@ static int conv3_tile_fits(int64_t B, int64_t H, int64_t W, int64_t BMt) {
     const int64_t imgs = HW >= BMt ? 1 : BMt / HW, tr = HW >= BMt ? BMt / tw : H;
     if (tr > H) return 0;
     const int64_t pieces = (imgs * (tr + 2) * (tw + 2) + 15) / 16, ppw = (pieces + 7) / 8;
-    return ppw >= 1 && ppw <= 4;
+    return ppw >= 1 && ppw <= (BMt == 512 ? 6 : 4) && (BMt != 512 || pieces <= 42);
 }
 // Cin: BYTES per pixel (int8: channels; f16 pair operands: 4 x channels).  wide: images of 128 .. 1024 columns, cut into 64-column
 // blocks (no per-image row-add, no GroupNorm partials: the launcher checks)
@@ -2015,6 +2025,12 @@ static int conv3_tile(int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t N, b
     // 256-pixel tiles unless they do not even fill one round of the 256 CUs (the 8x8 level: 125 workgroups -> 250 half-size
     // ones, 88 -> 68 us; at 300 workgroups, the 16x16 level, both tile sizes take the same time)
     if (f128 && (!f256 || (B * H * W / 256) * ((N + bn - 1) / bn) <= small)) return 128;
+    // operand type 3 on the 128-column block: 512-pixel tiles (a wave owns 128 pixels x 64 columns: 12 fragment reads per 24 MFMAs,
+    // half the weight-slab traffic and barriers per MFMA) when they still give every CU several tiles
+    static const int64_t big = EDADM_TUNE_I("EDADM_CONV3_TILE512", 1);
+    if (wide && big && bn == 128 && f256 && H * W >= 512 && conv3_tile_fits(B, H, W, 512) &&
+        (B * H * W / 512) * ((N + bn - 1) / bn) >= 1024)
+        return 512;
     return f256 ? 256 : 0;
 }
 template <int DT>
@@ -2035,7 +2051,14 @@ static int launch_conv3_direct(const void* A, const void* Wdc, int64_t B, int64_
     hipLaunchKernelGGL((k_conv3_direct<DT, TN_, TM_>), dim3((unsigned)((N + 64 * TN_ - 1) / (64 * TN_)), (unsigned)(M / (128 * TM_))), dim3(512), 0, \
                        (hipStream_t)stream, (const uint8_t*)A, (const uint8_t*)Wdc, M, N, (int)B, (int)H, (int)W, (int)Cin, padval,    \
                        ups ? 1 : 0, scale, bias, rowadd, rows_per_batch, residual, ldr, out, ldo, gn_ws)
-    if (conv3_bn(N) == 192) {
+    if (tile == 512) {
+        if constexpr (DT == 3) {
+            if (rowadd || gn_ws) return EDADM_EINVAL;
+            CONV3_LAUNCH(2, 4);
+        } else {
+            return EDADM_EINVAL;
+        }
+    } else if (conv3_bn(N) == 192) {
         if (tile == 256) CONV3_LAUNCH(3, 2);
         else CONV3_LAUNCH(3, 1);
     } else {
