@@ -24,6 +24,15 @@
 #include "common.h"
 #include "../../include/edadm.h"
 #include <hip/hip_fp16.h>
+#include <type_traits>
+#include <stdlib.h>
+// launch choices are compile-time constants in the product; diagnostic builds (-DEDADM_DIAG: tools/attn_wide_bench.hip) read them
+// from the environment
+#ifdef EDADM_DIAG
+#define EDADM_TUNE_I(name, dflt) (getenv(name) ? atoll(getenv(name)) : (long long)(dflt))
+#else
+#define EDADM_TUNE_I(name, dflt) ((long long)(dflt))
+#endif
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
@@ -249,8 +258,561 @@ k_attn_fused(const __half* __restrict__ Q, int64_t ldq, int64_t sQ, int64_t hQ, 
         }
 }
 
+
+// ---- K6w: the same attention for ONE WIDE head (class-conditional LDM-4: 1 head of d = 384 at 32 x 32, openaimodel.py:384-406) ----
+// With d in the hundreds the two products are long-K GEMMs and the kernel is MFMA-bound, not VALU-bound: a wave keeps its 32
+// queries' Q fragments (d / 16 x 4 registers) AND the whole O^T accumulator (d / 32 blocks x 16 registers) in the 512-entry
+// register file of a one-wave-per-SIMD kernel; keys and values are staged in 32-key blocks.  K rows sit at a stride of d + 8
+// halfs (= 4 banks mod 64: conflict-free ds_read_b128 of the 32x32x16 A operand), V rows stay [key][d] at a stride of d + 32 halfs
+// (= 16 banks mod 64) and the P V product's A operand V^T is fetched with the gfx950 transposing read ds_read_b64_tr_b16: a
+// 16-lane group reads 4 keys x 16 dimensions and every lane receives one dimension's 4 keys -- the two reads of a lane half give
+// keys {4h .. 4h+3, 8+4h .. 8+4h+3} of a 16-key step, exactly the order in which the accumulator of S^T holds a lane's
+// probabilities.  Same two walks, same arithmetic, same codes as k_attn_fused.
+typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+#define ATTW_BK 32
+#ifdef EDADM_STAMPS              // diagnostic build (tools/attn_wide_bench.hip): cycle stamps of wave 0 of every workgroup
+__device__ unsigned long long g_attw_stamps[16];
+#define ATTW_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define ATTW_ADD(slot, d) attw_loc[slot] += (unsigned long long)(d)       // per-wave registers; one atomic per slot at the end
+#else
+#define ATTW_T(v)
+#define ATTW_ADD(slot, d)
+#endif
+
+template <int KD, int DVB>
+__global__ void __launch_bounds__(256)
+k_attn_wide(const __half* __restrict__ Q, int64_t ldq, int64_t sQ, int64_t hQ, const __half* __restrict__ K, int64_t ldk,
+            int64_t sK, int64_t hK, const __half* __restrict__ V, int64_t ldv, int64_t sV, int64_t hV, void* __restrict__ out,
+            int64_t ldo, int64_t sO, int Nq, int Nk, float alpha_qk, const QP* __restrict__ pqp, float alpha_pv, int out_mode,
+            const QP* __restrict__ oqp) {
+    const QP pw = qp_load(pqp, 0);
+#ifdef EDADM_STAMPS
+    unsigned long long attw_loc[16] = {0};
+#endif
+    constexpr int D = KD * 16;
+    static_assert(DVB * 32 == D, "d must be a multiple of 32");
+    constexpr int KROW = D + 8, VROW = D + 32;
+    __shared__ __half lk_[2][ATTW_BK * KROW];
+    __shared__ __half lv_[2][ATTW_BK * VROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fh = lane >> 5;
+    // Workgroups are dealt round-robin to the 8 XCDs by their linear index, and every query tile of an (image, head) walks the same
+    // K and V twice: XCD k takes the contiguous range [k n / 8, (k + 1) n / 8) of (image, head, tile) triples, so that an image's
+    // tiles share one L2 (n % 8 != 0: plain numbering)
+    int qt, h;
+    int64_t b;
+    {
+        const unsigned nx = gridDim.x, ny = gridDim.y, n = nx * ny * gridDim.z;
+        const unsigned id = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+        const unsigned L = (n & 7) ? id : (n >> 3) * (id & 7) + (id >> 3);
+        qt = (int)(L % nx);
+        h = (int)((L / nx) % ny);
+        b = L / (nx * ny);
+    }
+    const int q = qt * ATT_BQ + wave * 32 + fr;
+    const __half* Qb = Q + b * sQ + (int64_t)h * hQ;
+    const __half* Kb = K + b * sK + (int64_t)h * hK;
+    const __half* Vb = V + b * sV + (int64_t)h * hV;
+    half8 qf[KD];
+#pragma unroll
+    for (int ks = 0; ks < KD; ++ks) {
+        half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (q < Nq) z = *reinterpret_cast<const half8*>(Qb + (int64_t)q * ldq + ks * 16 + fh * 8);
+        qf[ks] = z;
+    }
+    const int nkb = Nk / ATTW_BK;                                  // the launcher guarantees Nk % 64 == 0
+    // staging: a thread owns the 16-byte chunks (key r0 + 16 a, chunk c0 + 16 c), a = 0, 1, c = 0 .. D / 128 - 1, of every block: one
+    // 32-bit offset per tensor and row half, everything else is an instruction immediate; a wave reads 4 x 256 contiguous bytes
+    static_assert(D % 128 == 0, "d must be a multiple of 128");
+    constexpr int CPR = D / 128;                                   // chunk columns per thread
+    constexpr int KPT = 2 * CPR;
+    half8 rk[KPT], rv[KPT];
+    const int r0 = tid >> 4, c0 = tid & 15;
+    const int kofs0 = r0 * (int)ldk + c0 * 8, kofs1 = kofs0 + 16 * (int)ldk;
+    const int vofs0 = r0 * (int)ldv + c0 * 8, vofs1 = vofs0 + 16 * (int)ldv;
+    const int klds = r0 * KROW + c0 * 8, vlds = r0 * VROW + c0 * 8;
+    auto gload_k = [&](int kb) {
+        const __half* base = Kb + (int64_t)kb * ATTW_BK * ldk;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < CPR; ++c) rk[a * CPR + c] = *reinterpret_cast<const half8*>(base + (a ? kofs1 : kofs0) + c * 128);
+    };
+    auto gload_v = [&](int kb) {
+        const __half* base = Vb + (int64_t)kb * ATTW_BK * ldv;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < CPR; ++c) rv[a * CPR + c] = *reinterpret_cast<const half8*>(base + (a ? vofs1 : vofs0) + c * 128);
+    };
+    auto lstore_k = [&](int buf) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < CPR; ++c) *reinterpret_cast<half8*>(lk_[buf] + klds + a * 16 * KROW + c * 128) = rk[a * CPR + c];
+    };
+    auto lstore_v = [&](int buf) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < CPR; ++c) *reinterpret_cast<half8*>(lv_[buf] + vlds + a * 16 * VROW + c * 128) = rv[a * CPR + c];
+    };
+    // S^T of one 32-key block for this wave's 32 queries.  The fragment reads run PF steps ahead of the MFMAs that consume them
+    // (left to itself hipcc issues each read right in front of its MFMA and waits out the LDS latency 24 times per block), and
+    // `valu` single-issue instructions of whatever independent arithmetic the caller placed in the same region -- the softmax of
+    // the PREVIOUS block -- go into every MFMA's shadow: one wave per SIMD, nothing else fills the matrix pipe's gaps
+    constexpr int PF = 6;
+    auto scores = [&](const __half* lk, float16v& c, auto valu) {
+        c = float16v{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const __half* base = lk + fr * KROW + fh * 8;
+        half8 a[KD];
+#pragma unroll
+        for (int ks = 0; ks < PF; ++ks) a[ks] = *reinterpret_cast<const half8*>(base + ks * 16);
+#pragma unroll
+        for (int ks = 0; ks < KD; ++ks) {
+            if (ks + PF < KD) a[ks + PF] = *reinterpret_cast<const half8*>(base + (ks + PF) * 16);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], qf[ks], c, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
+#pragma unroll
+        for (int ks = 0; ks < KD; ++ks) {
+            if (ks + PF < KD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+            if (decltype(valu)::value > 0) __builtin_amdgcn_sched_group_barrier(0x2, decltype(valu)::value, 0);
+        }
+    };
+    const float cexp = alpha_qk * 1.44269504088896340736f;
+
+    // ---- walk 1: row maximum and row sum (online form).  Pipeline: at the top of iteration kb the scores of block kb are in
+    // registers, K(kb + 1) is resident in buffer (kb + 1) & 1 and K(kb + 2) is on its way from L2 in registers
+    float mx = -INFINITY, sum = 0.f;
+    auto stats = [&](const float16v& acc) {
+        float bm = mx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bm = fmaxf(bm, acc[r]);
+        sum *= __builtin_amdgcn_exp2f((mx - bm) * cexp);
+        mx = bm;
+        const float cm = mx * cexp;
+        float part = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part += __builtin_amdgcn_exp2f(fmaf(acc[r], cexp, -cm));
+        sum += part;
+    };
+    // Order inside an iteration: FIRST the LDS stores of the blocks that arrived during the previous iteration (they drain beside
+    // the MFMAs: 48 KB per block is 600 LDS-array cycles at the ds_write_b128 rate), then the next blocks' global loads (a whole
+    // iteration to land), then the arithmetic, then the one barrier.  Top of iteration kb: scores of block kb in registers, K(kb + 1)
+    // resident in buffer (kb + 1) & 1, K(kb + 2) in the staging registers.
+    float16v sa, sb;
+    gload_k(0);
+    lstore_k(0);
+    gload_k(1);
+    lstore_k(1);
+    __syncthreads();
+    if (nkb > 2) gload_k(2);
+    scores(lk_[0], sa, std::integral_constant<int, 0>{});
+    __syncthreads();                                               // every wave is done with K(0) before iteration 0 overwrites it
+    auto step1 = [&](int kb, float16v& cur, float16v& nxt) {
+        ATTW_T(t0);
+        if (kb + 2 < nkb) lstore_k(kb & 1);
+        if (kb + 3 < nkb) gload_k(kb + 3);
+        ATTW_T(t1);
+        if (kb + 1 < nkb) scores(lk_[(kb + 1) & 1], nxt, std::integral_constant<int, 3>{});
+        stats(cur);
+        ATTW_T(t2);
+        __syncthreads();
+        ATTW_T(t3);
+        ATTW_ADD(0, t1 - t0); ATTW_ADD(1, t2 - t1); ATTW_ADD(2, t3 - t2); ATTW_ADD(5, 1);
+    };
+    for (int kb = 0; kb < nkb; kb += 2) {
+        step1(kb, sa, sb);
+        step1(kb + 1, sb, sa);
+    }
+    {
+        const float mo = __shfl_xor(mx, 32, 64), so = __shfl_xor(sum, 32, 64);
+        const float m = fmaxf(mx, mo);
+        sum = sum * __builtin_amdgcn_exp2f((mx - m) * cexp) + so * __builtin_amdgcn_exp2f((mo - m) * cexp);
+        mx = m;
+    }
+    const float cmax = mx * cexp;
+    const float inv = 1.0f / (sum * pw.d);
+    const bool z0 = pw.z == 0.f;
+    float16v o[DVB];
+#pragma unroll
+    for (int j = 0; j < DVB; ++j) o[j] = float16v{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // transposing read: lane 4 q4 + p of a 16-lane group supplies the address of key q4, dimensions 4 p .. 4 p + 3 of the group's 16
+    const int tr_off = (4 * fh + ((lane & 15) >> 2)) * VROW + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+
+    // ---- walk 2: probability codes and O^T = V^T P^T.  Same K pipeline; V(kb) is resident in buffer kb & 1 at the top of
+    // iteration kb and V(kb + 1) on its way.  The exponentials and roundings of block kb sit in the shadow of the MFMAs that
+    // compute the scores of block kb + 1.
+    auto pv = [&](const __half* lv, const half8 (&pf)[2]) {
+        // 2 x DVB steps (16-key step j2, 32-dimension block j), the two transposing reads of a step PF steps ahead of its MFMA
+        constexpr int NS = 2 * DVB;
+        const __half* vp = lv + tr_off;
+        half4 va[NS], vb[NS];
+        auto rd = [&](int st) {
+            const int j2 = st / DVB, j = st - j2 * DVB;
+            va[st] = __builtin_bit_cast(half4, __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                (__attribute__((address_space(3))) fp16x4*)(vp + j2 * 16 * VROW + j * 32)));
+            vb[st] = __builtin_bit_cast(half4, __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                (__attribute__((address_space(3))) fp16x4*)(vp + j2 * 16 * VROW + j * 32 + 8 * VROW)));
+        };
+#pragma unroll
+        for (int st = 0; st < PF; ++st) rd(st);
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            if (st + PF < NS) rd(st + PF);
+            const int j2 = st / DVB, j = st - j2 * DVB;
+            const half8 a = {va[st][0], va[st][1], va[st][2], va[st][3], vb[st][0], vb[st][1], vb[st][2], vb[st][3]};
+            o[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pf[j2], o[j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * PF, 1);
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            if (st + PF < NS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 1);
+        }
+    };
+    gload_k(0);
+    gload_v(0);
+    lstore_k(0);
+    lstore_v(0);
+    gload_k(1);
+    lstore_k(1);
+    __syncthreads();
+    if (nkb > 2) gload_k(2);
+    gload_v(1);
+    scores(lk_[0], sa, std::integral_constant<int, 0>{});
+    __syncthreads();
+    auto step2 = [&](int kb, float16v& cur, float16v& nxt) {
+        ATTW_T(t0);
+        if (kb + 2 < nkb) lstore_k(kb & 1);
+        if (kb + 1 < nkb) lstore_v((kb + 1) & 1);
+        if (kb + 3 < nkb) gload_k(kb + 3);
+        if (kb + 2 < nkb) gload_v(kb + 2);
+        ATTW_T(t1);
+        float r_[16];
+        float worst = 0.f;
+        if (kb + 1 < nkb) scores(lk_[(kb + 1) & 1], nxt, std::integral_constant<int, 4>{});
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = __builtin_amdgcn_exp2f(fmaf(cur[r], cexp, -cmax));
+            cur[r] = e;
+            const float t = e * inv;
+            r_[r] = rintf(t);
+            worst = fmaxf(worst, fabsf(t - r_[r]));
+        }
+        ATTW_T(t2);
+        if (__builtin_expect(worst > 0.499f, 0)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                asm volatile("" : "+v"(r_[r]));
+                r_[r] = rintf((cur[r] / sum) / pw.d);
+            }
+        }
+        half8 pf[2];
+        if (z0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pf[r >> 3][r & 7] = (_Float16)fminf(r_[r], pw.qmax);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pf[r >> 3][r & 7] = (_Float16)(fminf(fmaxf(r_[r] + pw.z, 0.f), pw.qmax) - pw.z);
+        }
+        pv(lv_[kb & 1], pf);
+        ATTW_T(t3);
+        __syncthreads();
+        ATTW_T(t4);
+        ATTW_ADD(8, t1 - t0); ATTW_ADD(9, t2 - t1); ATTW_ADD(10, t3 - t2); ATTW_ADD(11, t4 - t3); ATTW_ADD(13, 1);
+    };
+    for (int kb = 0; kb < nkb; kb += 2) {
+        step2(kb, sa, sb);
+        step2(kb + 1, sb, sa);
+    }
+#ifdef EDADM_STAMPS
+    if (tid == 0)
+        for (int i = 0; i < 16; ++i) atomicAdd(&g_attw_stamps[i], attw_loc[i]);
+#endif
+    if (q >= Nq) return;
+    QP oq;
+    if (out_mode == 2) oq = qp_load(oqp, 0);
+#pragma unroll
+    for (int j = 0; j < DVB; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int dv = j * 32 + 8 * g + 4 * fh;
+            float v4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v4[e] = o[j][4 * g + e] * alpha_pv;
+            const int64_t col = (int64_t)h * D + dv;
+            if (out_mode == 0) {
+                float* op = reinterpret_cast<float*>(out) + b * sO + (int64_t)q * ldo + col;
+                *reinterpret_cast<float4*>(op) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+            } else {
+                int8_t* op = reinterpret_cast<int8_t*>(out) + b * sO + (int64_t)q * ldo + col;
+                uint32_t pk = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float c = fminf(fmaxf(rint_div(v4[e], oq.d, oq.inv) + oq.z, 0.f), oq.qmax);
+                    pk |= (uint32_t)(uint8_t)(int8_t)((int)c - 128) << (8 * e);
+                }
+                *reinterpret_cast<uint32_t*>(op) = pk;
+            }
+        }
+}
+
+// ---- K6w, two waves per SIMD.  k_attn_wide above keeps a wave's whole state in a 512-register file and therefore runs ONE wave per
+// SIMD: whatever the wave issues besides MFMAs (a quarter of its instructions) or waits for (LDS latency, the block barrier)
+// leaves the matrix pipe idle -- 31 % MFMA utilisation measured (SQ_VALU_MFMA_BUSY_CYCLES / wave cycles; LDS array 17 % busy, no bank
+// conflicts).  This form gives a wave 16 queries on the 16x16x32 MFMA: Q fragments d / 32 x 4 = 48 registers, O^T d / 16 x 4 = 96,
+// so eight waves of 16 queries (the same 128-query tile, the same K / V staging per workgroup) fit two to a SIMD and one wave's
+// exponentials and waits sit under the other's MFMAs.  In the 16x16 accumulator layout a lane holds query (lane & 15) and keys
+// 4 g + r (g = lane >> 4) of a 16-key tile; the 8 values of two tiles, as f16, are the B operand of ONE 32-key P V step when V^T is
+// read in the key order {4g .. 4g+3, 16+4g .. 16+4g+3}: two transposing reads per 16-dimension block.  K and V rows both sit at a
+// stride of d + 16 halfs (8 banks mod 64): conflict-free for the 16-row ds_read_b128 fragments and for the transposing reads.
+typedef float float4v __attribute__((ext_vector_type(4)));
+#ifdef EDADM_DIAG
+__device__ int g_attw_exp;
+#endif
+
+template <int KD32, int DB16>
+__global__ void __launch_bounds__(512)
+k_attn_wide16(const __half* __restrict__ Q, int64_t ldq, int64_t sQ, int64_t hQ, const __half* __restrict__ K, int64_t ldk,
+              int64_t sK, int64_t hK, const __half* __restrict__ V, int64_t ldv, int64_t sV, int64_t hV, void* __restrict__ out,
+              int64_t ldo, int64_t sO, int Nq, int Nk, float alpha_qk, const QP* __restrict__ pqp, float alpha_pv, int out_mode,
+              const QP* __restrict__ oqp) {
+    const QP pw = qp_load(pqp, 0);
+#ifdef EDADM_DIAG
+    const int exp_ = g_attw_exp;                                   // timing experiments (wrong results): 1 no block barrier, 2 no LDS stores, 4 no P V
+#define ATTW_SYNC() do { if (!(exp_ & 1)) __syncthreads(); } while (0)
+#define ATTW_EXP(bit) (exp_ & (bit))
+#else
+#define ATTW_SYNC() __syncthreads()
+#define ATTW_EXP(bit) 0
+#endif
+    constexpr int D = KD32 * 32;
+    static_assert(DB16 * 16 == D && D % 128 == 0, "d must be a multiple of 128");
+    constexpr int ROW = D + 16;                                    // halfs per LDS row of K and of V
+    __shared__ __half lk_[2][ATTW_BK * ROW];
+    __shared__ __half lv_[2][ATTW_BK * ROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fc = lane & 15, fg = lane >> 4;
+    int qt, h;
+    int64_t b;
+    {   // XCD k takes a contiguous range of (image, head, tile) triples: an image's tiles share one L2 (see k_attn_wide)
+        const unsigned nx = gridDim.x, ny = gridDim.y, n = nx * ny * gridDim.z;
+        const unsigned id = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+        const unsigned L = (n & 7) ? id : (n >> 3) * (id & 7) + (id >> 3);
+        qt = (int)(L % nx);
+        h = (int)((L / nx) % ny);
+        b = L / (nx * ny);
+    }
+    const int q = qt * ATT_BQ + wave * 16 + fc;
+    const __half* Qb = Q + b * sQ + (int64_t)h * hQ;
+    const __half* Kb = K + b * sK + (int64_t)h * hK;
+    const __half* Vb = V + b * sV + (int64_t)h * hV;
+    half8 qf[KD32];                                                // B operand of S^T = K Q^T: query fc, dimensions 32 ks + 8 fg .. + 7
+#pragma unroll
+    for (int ks = 0; ks < KD32; ++ks) {
+        half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (q < Nq) z = *reinterpret_cast<const half8*>(Qb + (int64_t)q * ldq + ks * 32 + fg * 8);
+        qf[ks] = z;
+    }
+    const int nkb = Nk / ATTW_BK;                                  // the launcher guarantees Nk % 64 == 0
+    // staging: thread -> key r0 = tid >> 4, 16-byte chunks c0 + 16 c (c < D / 128) of every block
+    constexpr int CPR = D / 128;
+    half8 rk[CPR], rv[CPR];
+    const int r0 = tid >> 4, c0 = tid & 15;
+    const int kofs = r0 * (int)ldk + c0 * 8, vofs = r0 * (int)ldv + c0 * 8, sofs = r0 * ROW + c0 * 8;
+    auto gload_k = [&](int kb) {
+        const __half* base = Kb + (int64_t)kb * ATTW_BK * ldk;
+#pragma unroll
+        for (int c = 0; c < CPR; ++c) rk[c] = *reinterpret_cast<const half8*>(base + kofs + c * 128);
+    };
+    auto gload_v = [&](int kb) {
+        const __half* base = Vb + (int64_t)kb * ATTW_BK * ldv;
+#pragma unroll
+        for (int c = 0; c < CPR; ++c) rv[c] = *reinterpret_cast<const half8*>(base + vofs + c * 128);
+    };
+    auto lstore_k = [&](int buf) {
+        if (ATTW_EXP(2)) return;
+#pragma unroll
+        for (int c = 0; c < CPR; ++c) *reinterpret_cast<half8*>(lk_[buf] + sofs + c * 128) = rk[c];
+    };
+    auto lstore_v = [&](int buf) {
+        if (ATTW_EXP(2)) return;
+#pragma unroll
+        for (int c = 0; c < CPR; ++c) *reinterpret_cast<half8*>(lv_[buf] + sofs + c * 128) = rv[c];
+    };
+    // S^T of a 32-key block: two 16-key tiles x this wave's 16 queries; register r of tile t is key 16 t + 4 fg + r
+    constexpr int PF = 4;
+    auto scores = [&](const __half* lk, float4v (&c)[2]) {
+        c[0] = c[1] = float4v{0, 0, 0, 0};
+        const __half* base = lk + fc * ROW + fg * 8;
+        constexpr int NS = 2 * KD32;
+        half8 a[NS];
+        auto rd = [&](int st) { a[st] = *reinterpret_cast<const half8*>(base + (st / KD32) * 16 * ROW + (st % KD32) * 32); };
+#pragma unroll
+        for (int st = 0; st < PF; ++st) rd(st);
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            if (st + PF < NS) rd(st + PF);
+            c[st / KD32] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[st], qf[st % KD32], c[st / KD32], 0, 0, 0);
+        }
+    };
+    const float cexp = alpha_qk * 1.44269504088896340736f;
+    float mx = -INFINITY, sum = 0.f;
+    auto stats = [&](const float4v (&acc)[2]) {
+        float bm = mx;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bm = fmaxf(bm, acc[t][r]);
+        sum *= __builtin_amdgcn_exp2f((mx - bm) * cexp);
+        mx = bm;
+        const float cm = mx * cexp;
+        float part = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part += __builtin_amdgcn_exp2f(fmaf(acc[t][r], cexp, -cm));
+        sum += part;
+    };
+    // ---- walk 1 (pipeline as in k_attn_wide: stores of the arrived block, next loads, scores of block kb + 1 beside the statistics of kb)
+    float4v sa[2], sb[2];
+    gload_k(0);
+    lstore_k(0);
+    gload_k(1);
+    lstore_k(1);
+    __syncthreads();
+    if (nkb > 2) gload_k(2);
+    scores(lk_[0], sa);
+    __syncthreads();
+    auto step1 = [&](int kb, float4v (&cur)[2], float4v (&nxt)[2]) {
+        if (kb + 2 < nkb) lstore_k(kb & 1);
+        if (kb + 3 < nkb) gload_k(kb + 3);
+        if (kb + 1 < nkb) scores(lk_[(kb + 1) & 1], nxt);
+        stats(cur);
+        ATTW_SYNC();
+    };
+    for (int kb = 0; kb < nkb; kb += 2) {
+        step1(kb, sa, sb);
+        step1(kb + 1, sb, sa);
+    }
+#pragma unroll
+    for (int sh = 16; sh <= 32; sh <<= 1) {                        // the four lanes of a query (4 keys of every 16 each) combine
+        const float mo = __shfl_xor(mx, sh, 64), so = __shfl_xor(sum, sh, 64);
+        const float m = fmaxf(mx, mo);
+        sum = sum * __builtin_amdgcn_exp2f((mx - m) * cexp) + so * __builtin_amdgcn_exp2f((mo - m) * cexp);
+        mx = m;
+    }
+    const float cmax = mx * cexp;
+    const float inv = 1.0f / (sum * pw.d);
+    const bool z0 = pw.z == 0.f;
+    float4v o[DB16];
+#pragma unroll
+    for (int j = 0; j < DB16; ++j) o[j] = float4v{0, 0, 0, 0};
+    // transposing read: lane 4 q4 + p of a 16-lane group supplies the address of key 4 fg + q4, dimensions 4 p .. 4 p + 3
+    const int tr_off = (4 * fg + ((lane & 15) >> 2)) * ROW + 4 * (lane & 3);
+    auto pv = [&](const __half* lv, const half8& pf) {
+        const __half* vp = lv + tr_off;
+        half4 va[DB16], vb[DB16];
+        auto rd = [&](int j) {
+            va[j] = __builtin_bit_cast(half4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(vp + j * 16)));
+            vb[j] = __builtin_bit_cast(half4, __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                (__attribute__((address_space(3))) fp16x4*)(vp + j * 16 + 16 * ROW)));
+        };
+#pragma unroll
+        for (int j = 0; j < PF; ++j) rd(j);
+#pragma unroll
+        for (int j = 0; j < DB16; ++j) {
+            if (j + PF < DB16) rd(j + PF);
+            const half8 a = {va[j][0], va[j][1], va[j][2], va[j][3], vb[j][0], vb[j][1], vb[j][2], vb[j][3]};
+            o[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pf, o[j], 0, 0, 0);
+        }
+    };
+    gload_k(0);
+    gload_v(0);
+    lstore_k(0);
+    lstore_v(0);
+    gload_k(1);
+    lstore_k(1);
+    __syncthreads();
+    if (nkb > 2) gload_k(2);
+    gload_v(1);
+    scores(lk_[0], sa);
+    __syncthreads();
+    auto step2 = [&](int kb, float4v (&cur)[2], float4v (&nxt)[2]) {
+        if (kb + 2 < nkb) lstore_k(kb & 1);
+        if (kb + 1 < nkb) lstore_v((kb + 1) & 1);
+        if (kb + 3 < nkb) gload_k(kb + 3);
+        if (kb + 2 < nkb) gload_v(kb + 2);
+        if (kb + 1 < nkb) scores(lk_[(kb + 1) & 1], nxt);
+        float e_[8], r_[8];
+        float worst = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float e = __builtin_amdgcn_exp2f(fmaf(cur[i >> 2][i & 3], cexp, -cmax));
+            e_[i] = e;
+            const float t = e * inv;
+            r_[i] = rintf(t);
+            worst = fmaxf(worst, fabsf(t - r_[i]));
+        }
+        if (__builtin_expect(worst > 0.499f, 0)) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                asm volatile("" : "+v"(r_[i]));
+                r_[i] = rintf((e_[i] / sum) / pw.d);
+            }
+        }
+        half8 pf;
+        if (z0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pf[i] = (_Float16)fminf(r_[i], pw.qmax);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pf[i] = (_Float16)(fminf(fmaxf(r_[i] + pw.z, 0.f), pw.qmax) - pw.z);
+        }
+        if (!ATTW_EXP(4)) pv(lv_[kb & 1], pf);
+        else if (kb == -1) pv(lv_[kb & 1], pf);
+        else o[0][0] += (float)pf[0] + (float)pf[7];
+        ATTW_SYNC();
+    };
+    for (int kb = 0; kb < nkb; kb += 2) {
+        step2(kb, sa, sb);
+        step2(kb + 1, sb, sa);
+    }
+    if (q >= Nq) return;
+    // ---- epilogue: lane -> query q, output dimensions 16 j + 4 fg + e
+    QP oq;
+    if (out_mode == 2) oq = qp_load(oqp, 0);
+#pragma unroll
+    for (int j = 0; j < DB16; ++j) {
+        const int dv = j * 16 + 4 * fg;
+        float v4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v4[e] = o[j][e] * alpha_pv;
+        const int64_t col = (int64_t)h * D + dv;
+        if (out_mode == 0) {
+            float* op = reinterpret_cast<float*>(out) + b * sO + (int64_t)q * ldo + col;
+            *reinterpret_cast<float4*>(op) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+        } else {
+            int8_t* op = reinterpret_cast<int8_t*>(out) + b * sO + (int64_t)q * ldo + col;
+            uint32_t pk = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float c = fminf(fmaxf(rint_div(v4[e], oq.d, oq.inv) + oq.z, 0.f), oq.qmax);
+                pk |= (uint32_t)(uint8_t)(int8_t)((int)c - 128) << (8 * e);
+            }
+            *reinterpret_cast<uint32_t*>(op) = pk;
+        }
+    }
+}
+
+// shapes of the wide-head kernel: one instantiation per head dimension
+static bool attn_wide_shape(int64_t d, int64_t Nq, int64_t Nk) { return d == 384 && Nk >= 64 && Nk % (2 * ATTW_BK) == 0 && Nq >= 1; }
+
 extern "C" int edadm_attention_fused_ok(int64_t heads, int64_t d, int64_t Nq, int64_t Nk) {
-    return heads >= 1 && d >= 8 && d <= 160 && (d & 7) == 0 && Nq >= 1 && Nk >= 2;
+    return heads >= 1 && Nq >= 1 && ((d >= 8 && d <= 160 && (d & 7) == 0 && Nk >= 2) || attn_wide_shape(d, Nq, Nk));
 }
 
 extern "C" int edadm_attention_fused_f16(const void* Q, int64_t ldq, int64_t strideQ, int64_t headQ, const void* K, int64_t ldk,
@@ -269,6 +831,19 @@ extern "C" int edadm_attention_fused_f16(const void* Q, int64_t ldq, int64_t str
     if (!(alpha_qk > 0.f)) return EDADM_EINVAL;
     const QP* pq = reinterpret_cast<const QP*>(pqp);
     hipStream_t st = (hipStream_t)stream;
+    if (attn_wide_shape(d, Nq, Nk)) {
+        static const int64_t form = EDADM_TUNE_I("EDADM_ATTN_WIDE_FORM", 16);
+        if (form == 16) {
+            hipLaunchKernelGGL((k_attn_wide16<12, 24>), dim3((unsigned)((Nq + ATT_BQ - 1) / ATT_BQ), (unsigned)heads, (unsigned)B), dim3(512), 0, st,
+                               (const __half*)Q, ldq, strideQ, headQ, (const __half*)K, ldk, strideK, headK, (const __half*)V, ldv, strideV,
+                               headV, out, ldo, strideO, (int)Nq, (int)Nk, alpha_qk, pq, alpha_pv, out_mode, reinterpret_cast<const QP*>(oqp));
+            return edadm_launch_status();
+        }
+        hipLaunchKernelGGL((k_attn_wide<24, 12>), dim3((unsigned)((Nq + ATT_BQ - 1) / ATT_BQ), (unsigned)heads, (unsigned)B), dim3(256), 0, st,
+                           (const __half*)Q, ldq, strideQ, headQ, (const __half*)K, ldk, strideK, headK, (const __half*)V, ldv, strideV,
+                           headV, out, ldo, strideO, (int)Nq, (int)Nk, alpha_qk, pq, alpha_pv, out_mode, reinterpret_cast<const QP*>(oqp));
+        return edadm_launch_status();
+    }
     const int kd = (int)((d + 15) / 16), dvb = (int)((d + 31) / 32);
 #define ATT_CASE(KD_, DVB_)                                                                                                  \
     if (kd == KD_ && dvb == DVB_) {                                                                                          \

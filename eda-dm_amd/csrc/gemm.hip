@@ -634,9 +634,10 @@ static __device__ unsigned long long g_stamps[8];
 static __global__ void k_init_pad_rows() {
     for (int i = threadIdx.x; i < 256 * 64; i += blockDim.x) g_pad_rows[i] = (uint8_t)(i >> 6);
 }
-// The table lives in device memory of EVERY device this process drives: initialised once per device, stream-ordered ahead of
-// the first launch that reads it.  A first call that lands inside a stream capture records the kernel in that graph (so the
-// graph is self-contained) but does not count: eager launches issued before the graph's first replay initialise it themselves.
+// The table lives in device memory of EVERY device this process drives: filled once per device by a SYNCHRONOUS copy from the
+// host on the first eager launch -- complete before that launch (or any later one, on any stream: the sampling loop, the
+// decoder's side stream) is enqueued.  A first call that lands inside a stream capture cannot copy synchronously: it records the
+// fill kernel in that graph (so the graph is self-contained) and does not count -- the next eager launch still copies.
 static void ensure_pad_rows(hipStream_t st) {
     static std::atomic<bool> ready[EDADM_MAX_DEVICES];
     int dev = 0;
@@ -644,8 +645,16 @@ static void ensure_pad_rows(hipStream_t st) {
     if (ready[dev].load(std::memory_order_acquire)) return;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess) cs = hipStreamCaptureStatusNone;
-    hipLaunchKernelGGL(k_init_pad_rows, dim3(1), dim3(256), 0, st);
-    if (cs == hipStreamCaptureStatusNone) ready[dev].store(true, std::memory_order_release);
+    if (cs != hipStreamCaptureStatusNone) {
+        hipLaunchKernelGGL(k_init_pad_rows, dim3(1), dim3(256), 0, st);
+        return;
+    }
+    static uint8_t host_rows[256 * 64];
+    for (int i = 0; i < 256 * 64; ++i) host_rows[i] = (uint8_t)(i >> 6);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_pad_rows), host_rows, sizeof(host_rows)) == hipSuccess)
+        ready[dev].store(true, std::memory_order_release);
+    else
+        hipLaunchKernelGGL(k_init_pad_rows, dim3(1), dim3(256), 0, st);      // stream-ordered fallback; retried next time
 }
 // Device-side error word of this translation unit (bit 0: a hand-off wait of the persistent kernel gave up).  Kernels are
 // asynchronous, so the launching call cannot report it; edadm_device_status() does, at the caller's next synchronisation.

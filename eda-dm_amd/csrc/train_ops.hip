@@ -12,6 +12,7 @@
 // sizes, never the normalisation affines (block_recon.py:44-108), so their gradients are not computed at all.
 // All kernels are HBM-bound: algorithmic bytes = 4 B x (elements read + written), the statistics pass re-reads x.
 #include "common.h"
+#include <type_traits>
 #include "../../include/edadm.h"
 
 // ------------------------------------------------------------------------------------------------ block reductions
@@ -170,9 +171,14 @@ __device__ __forceinline__ float gnt_t(float xv, float dv, const GntCh& c, int s
 template <int MODE>
 __global__ void __launch_bounds__(256) k_gnt_partial(const float* __restrict__ x, const float* __restrict__ dy,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     const float* __restrict__ stats, float* __restrict__ ws, int64_t HW,
+                                                     const float* __restrict__ stats, float* __restrict__ ws_, int64_t HW,
                                                      int64_t C, int G, int nchunk, int silu) {
-    extern __shared__ float sm[];                                     // [RS][C][2]
+    // forward statistics (MODE 0) are summed in fp64 from the first element, like k_gn_fwd_nchw: var = E[x^2] - mean^2 cancels
+    // |mean| / std squared of the partials' precision, and an fp32 partial loses those digits before the fp64 reduction sees it
+    using Acc = typename std::conditional<MODE == 0, double, float>::type;
+    extern __shared__ double sm_raw[];
+    Acc* sm = reinterpret_cast<Acc*>(sm_raw);                         // [RS][C][2]
+    Acc* ws = reinterpret_cast<Acc*>(ws_);
     const int64_t b = blockIdx.y;
     const int chunk = blockIdx.x;
     const int64_t r0 = HW * chunk / nchunk, r1 = HW * (chunk + 1) / nchunk;
@@ -180,7 +186,7 @@ __global__ void __launch_bounds__(256) k_gnt_partial(const float* __restrict__ x
     const int q = threadIdx.x % Q, rs = threadIdx.x / Q;
     const float4* xa = reinterpret_cast<const float4*>(x) + b * HW * Q;
     const float4* da = reinterpret_cast<const float4*>(dy) + b * HW * Q;
-    float s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+    Acc s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
     GntCh ch[4];
     if (MODE == 1) {
         const int cg = (int)(C / G);
@@ -196,7 +202,7 @@ __global__ void __launch_bounds__(256) k_gnt_partial(const float* __restrict__ x
             const float e[4] = {v.x, v.y, v.z, v.w};
             if (MODE == 0) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { s[j] += e[j]; ss[j] += e[j] * e[j]; }
+                for (int j = 0; j < 4; ++j) { s[j] += (Acc)e[j]; ss[j] += (Acc)e[j] * (Acc)e[j]; }
             } else {
                 const float4 dv = da[r * Q + q];
                 const float d[4] = {dv.x, dv.y, dv.z, dv.w};
@@ -216,24 +222,26 @@ __global__ void __launch_bounds__(256) k_gnt_partial(const float* __restrict__ x
         }
     }
     __syncthreads();
-    float* wb = ws + ((b * nchunk + chunk) * C) * 2;
+    Acc* wb = ws + ((b * nchunk + chunk) * C) * 2;
     for (int c = threadIdx.x; c < C; c += 256) {
-        float a = 0.f, bq = 0.f;
+        Acc a = 0, bq = 0;
         for (int r = 0; r < RS; ++r) { a += sm[((int64_t)r * C + c) * 2]; bq += sm[((int64_t)r * C + c) * 2 + 1]; }
         wb[2 * c] = a;
         wb[2 * c + 1] = bq;
     }
 }
 template <int MODE>
-__global__ void __launch_bounds__(64) k_gnt_final(const float* __restrict__ ws, float* __restrict__ out2, int64_t HW, int64_t C,
+__global__ void __launch_bounds__(64) k_gnt_final(const float* __restrict__ ws_, float* __restrict__ out2, int64_t HW, int64_t C,
                                                   int G, int nchunk, float eps) {
+    using Acc = typename std::conditional<MODE == 0, double, float>::type;
+    const Acc* ws = reinterpret_cast<const Acc*>(ws_);
     const int64_t b = blockIdx.y, g = blockIdx.x;
     const int cg = (int)(C / G);
     const int items = nchunk * cg;
     double s = 0.0, ss = 0.0;
     for (int i = threadIdx.x; i < items; i += 64) {
         const int chk = i / cg, c = (int)(g * cg) + i % cg;
-        const float* p = ws + ((b * nchunk + chk) * C + c) * 2;
+        const Acc* p = ws + ((b * nchunk + chk) * C + c) * 2;
         s += (double)p[0];
         ss += (double)p[1];
     }
@@ -303,7 +311,7 @@ __global__ void __launch_bounds__(256) k_gnt_apply(const float* __restrict__ x, 
     }
 }
 extern "C" int64_t edadm_gn_nhwc_ws_floats(int64_t B, int64_t HW, int64_t C, int G) {
-    return B * gnt_chunks(B, HW) * C * 2 + B * G * 2;
+    return B * gnt_chunks(B, HW) * C * 4 + B * G * 2;            // forward partials are doubles
 }
 static bool gnt_ok(int64_t B, int64_t C, int64_t HW, int G) {
     return B > 0 && B <= 65535 && C > 0 && HW > 0 && G > 0 && !(C % G) && !(C & 3) && C <= 1024;
@@ -315,7 +323,8 @@ extern "C" int edadm_gn_fwd_nhwc(const float* x, const float* gamma, const float
     hipStream_t st = (hipStream_t)stream;
     const int nchunk = gnt_chunks(B, HW);
     const int Q = (int)(C >> 2), RS = 256 / Q;
-    const size_t smem = (size_t)RS * C * 2 * sizeof(float);
+    const size_t smem = (size_t)RS * C * 2 * sizeof(double);
+    if (((uintptr_t)ws & 7)) return EDADM_EINVAL;
     hipLaunchKernelGGL(k_gnt_partial<0>, dim3(nchunk, (unsigned)B), dim3(256), smem, st, x, (const float*)nullptr, gamma, beta,
                        (const float*)nullptr, ws, HW, C, G, nchunk, silu);
     hipLaunchKernelGGL(k_gnt_final<0>, dim3((unsigned)G, (unsigned)B), dim3(64), 0, st, ws, stats, HW, C, G, nchunk, eps);

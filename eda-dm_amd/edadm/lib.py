@@ -64,8 +64,15 @@ def load():
     return _lib
 
 
+# tests / tools: a dict here counts the entry points that run (name -> calls), e.g. to assert which contraction kernels a
+# reconstruction unit actually took
+CALLS = None
+
+
 def call(name, *args):
     """Invoke an int-returning entry point; non-zero status raises."""
+    if CALLS is not None:
+        CALLS[name] = CALLS.get(name, 0) + 1
     rc = getattr(load(), name)(*args)
     if rc != 0:
         raise EdadmError("%s failed with status %d" % (name, rc))

@@ -1540,13 +1540,180 @@ def g17_tdac_imagenet():
     save("g17_tdac_imagenet", d)
 
 
+
+class _G20Host(nn.Module):
+    """holder of the two G20 units (tests/golden/_g20.py); never run as a network"""
+
+    def __init__(self):
+        super().__init__()
+        import _g20
+        self.in_channels = _g20.RES["channels"]
+        self.res = ResBlock(_g20.RES["channels"], _g20.RES["emb_channels"], 0.0, out_channels=_g20.RES["out_channels"], dims=2,
+                            use_checkpoint=False, use_scale_shift_norm=False)
+        self.tf = BasicTransformerBlock(_g20.TF["dim"], _g20.TF["heads"], _g20.TF["d_head"], dropout=0.0,
+                                        context_dim=_g20.TF["context_dim"], gated_ff=True, checkpoint=False)
+
+
+def g20_f16x3_units(threads=None, fname="g20_f16x3_units"):
+    """G20: qdiff_control.block_reconstruction (qdiff_control/block_recon.py:13-243) on ONE LDM-4-sized ResBlock (192 -> 384 at
+    32 x 32) and ONE transformer block (d = 384, 1024 tokens), 32-row minibatches, the shipped ImageNet hyper-parameters and
+    0.5 / 0.5 masks -- the size at which the product contracts on its three-product f16 kernels.  Weights, cached unit inputs
+    and uniforms are formulas (tests/golden/_weights.py, _g20.py, _uniforms.uniform_hash); stored: the reference's initial
+    scales, minibatch draws, the direction of every alpha's first Adam step, every alpha's final sign and whether it ends
+    next to zero (bit-packed), strided trajectories, samples of the FP targets."""
+    import time
+    import _g20
+    import _uniforms
+    from _weights import formula_state_dict
+    import qdiff_control.block_recon as cb_mod
+    from qdiff_control.adaptive_rounding import AdaRoundQuantizer as AdaRoundControl
+    ARQ = (AdaRoundQuantizer, AdaRoundControl)
+    if threads:
+        torch.set_num_threads(threads)          # the noise-floor run: same code, another partition of the fp32 sums
+    seed_everything(_g20.SEED)
+    host = _G20Host().eval()
+    sd = formula_state_dict([(k, tuple(v.shape)) for k, v in host.state_dict().items()], _g20.SEED)
+    host.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    aq = dict(AQ8)
+    aq["prob"] = _g20.PROB
+    qnn = QuantModel(host, WQ4, aq, sm_abit=8)
+    qnn.eval()
+    qnn.set_grad_ckpt(False)
+    d = {"weights_seed": np.int64(_g20.SEED), "iters": np.int64(_g20.ITERS)}
+    traj, cur, idx_log = {}, {"name": None, "phase": "init"}, {}
+    rep = _uniforms.ReplayHash()
+    checks = []
+    orig_step, orig_sample, orig_rand_like = torch.optim.Adam.step, random.sample, torch.rand_like
+
+    def step(self, *a, **k):
+        r = orig_step(self, *a, **k)
+        ps = [p for gr in self.param_groups for p in gr["params"]]
+        key = "%s/%s" % (cur["name"], "a" if ps[0].numel() == 1 else "w")
+        traj.setdefault(key, []).append(torch.cat([p.detach().flatten() for p in ps]).clone())
+        return r
+
+    def sample(pop, k):
+        r = orig_sample(pop, k)
+        idx_log.setdefault(cur["name"], []).append(list(r))
+        return r
+
+    def rand_like(xx, **k):
+        owner = sys._getframe(1).f_locals.get("self")
+        name = None
+        if owner is not None:
+            for n, m in qnn.named_modules():
+                if m is owner:
+                    name = n
+        if name is None:
+            assert owner is None, type(owner)
+            name = "input_mix:" + cur["name"]
+        u = rep.draw(name, cur["phase"], xx.shape)
+        checks.append([float(u.reshape(-1)[0]), float(u.reshape(-1)[-1]), float(u.astype(np.float64).sum())])
+        return torch.from_numpy(u)
+
+    kwargs = dict(_g20.HYPER)
+    kwargs.update(cali_data=None, iters=_g20.ITERS)
+    for name in ("res", "tf"):
+        t0 = time.time()
+        unit = getattr(qnn.model, name)
+        cq, cf = _g20.caches(name)
+        cq, cf = [torch.from_numpy(a) for a in cq], [torch.from_numpy(a) for a in cf]
+        # initial scales the reference's way (set_quantize_params.py:48-69 / :9-46 on the unit): weight quantizers from one
+        # forward in the (True, False) state, activation quantizers over two batches of 32 of the quantised-prefix inputs
+        uaqs = [(n, m) for n, m in unit.named_modules() if isinstance(m, UniformAffineQuantizer)]
+        unit.set_quant_state(True, False)
+        for n, m in uaqs:
+            if not m.leaf_param:
+                m.set_inited(False)
+        with torch.no_grad():
+            unit(cq[0][:8], cq[1][:8])
+        for n, m in uaqs:
+            if not m.leaf_param:
+                m.set_inited(True)
+        unit.set_quant_state(True, True)
+        for n, m in uaqs:
+            if m.leaf_param:
+                m.set_inited(False)
+        with torch.no_grad():
+            for i in range(_g20.ROWS // 32):
+                unit(cq[0][i * 32:(i + 1) * 32], cq[1][i * 32:(i + 1) * 32])
+        for n, m in uaqs:
+            if m.leaf_param:
+                m.set_inited(True)
+        print(name, "scales initialised %.0f s" % (time.time() - t0))
+        for k, v in qparams_of(qnn).items():
+            if k.startswith("qp/model.%s." % name):
+                d["init/" + k] = v
+        # FP targets of the cached rows (data_utils.py:133-139: the unit's output with quantisation off on the FP inputs)
+        unit.set_quant_state(False, False)
+        with torch.no_grad():
+            out_fp = torch.cat([unit(cf[0][i:i + 32], cf[1][i:i + 32]) for i in range(0, _g20.ROWS, 32)])
+        pos = _g20.sample_positions(out_fp.numel())
+        d["out_fp/%s/sample" % name] = out_fp.reshape(-1)[torch.from_numpy(pos)]
+        d["out_fp/%s/sum" % name] = np.float64(out_fp.double().sum())
+        d["out_fp/%s/sumsq" % name] = np.float64((out_fp.double() ** 2).sum())
+
+        def fake_save(model, block, cali, asym, act_quant, batch_size=32, input_prob=True, keep_gpu=True):
+            return True, ([cq[0], cq[1]], [cf[0], cf[1]]), out_fp
+
+        orig_save = cb_mod.save_inp_oup_data
+        cb_mod.save_inp_oup_data = fake_save
+        torch.optim.Adam.step, random.sample, torch.rand_like = step, sample, rand_like
+        cur["name"], cur["phase"] = name, "iter"
+        alpha0 = None
+        try:
+            random.seed(_g20.SEED + 1)
+            t0 = time.time()
+            cb_mod.block_reconstruction(qnn, unit, **kwargs)
+            print(name, "reconstruction %.0f s" % (time.time() - t0))
+        finally:
+            torch.optim.Adam.step, random.sample, torch.rand_like = orig_step, orig_sample, orig_rand_like
+            cb_mod.save_inp_oup_data = orig_save
+        tw, ta = torch.stack(traj[name + "/w"]), torch.stack(traj[name + "/a"])
+        # AdaRound's initial alpha in parameter order (adaptive_rounding.py:62-72), recomputed from the same scales
+        a0 = []
+        for n, m in unit.named_modules():
+            if isinstance(m, ARQ):
+                w = dict(unit.named_modules())[n.rsplit(".", 1)[0]].org_weight
+                rest = (w / m.delta) - torch.floor(w / m.delta)
+                a0.append((-torch.log((m.zeta - m.gamma) / (rest - m.gamma) - 1)).flatten())
+        a0 = torch.cat(a0)
+        assert a0.numel() == tw.shape[1]
+        d["first/%s/up" % name] = _g20.pack((tw[0] > a0).numpy())           # direction of every alpha's first Adam step
+        d["first/%s/moved" % name] = _g20.pack((tw[0] != a0).numpy())
+        d["final/%s/sign" % name] = _g20.pack((tw[-1] >= 0).numpy())
+        d["final/%s/near" % name] = _g20.pack((tw[-1].abs() < _g20.NEAR).numpy())
+        d["final/%s/count" % name] = np.int64(tw.shape[1])
+        d["traj/%s/w" % name] = tw[:, ::_g20.STRIDE].clone()
+        d["traj/%s/a" % name] = ta
+        d["idx/" + name] = np.array(idx_log[name])
+        for k, v in qparams_of(qnn).items():
+            if k.startswith("qp/model.%s." % name) and "act_quantizer" in k:
+                d["final/" + k] = v
+        # the parameter order of the trajectories (module paths of the AdaRound / trained activation quantizers)
+        d["order/%s/w" % name] = np.array([n for n, m in unit.named_modules() if isinstance(m, ARQ)])
+    d["rand/log"] = np.array(["%s|%s|%d|%s" % (o, p, c, "x".join(map(str, s))) for o, p, c, s in rep.log])
+    d["rand/check"] = np.array(checks, dtype=np.float64).reshape(-1, 3)
+    if threads:
+        d = {k: v for k, v in d.items() if k.startswith(("final/", "first/", "traj/", "init/"))}
+        d["threads"] = np.int64(threads)
+    save(fname, d)
+
+
+def g20_noise_floor():
+    """The REFERENCE against ITSELF: the G20 run repeated with 3 CPU threads instead of 8 (torch splits its fp32 GEMM / convolution
+    sums differently), same seeds, same formulas.  What differs between the two is the floor any other arithmetic -- the product's
+    exact-fp32 or three-product f16 MFMA -- can be held to.  Stored next to G20 as the alternative run's bits."""
+    g20_f16x3_units(threads=3, fname="g20_reference_3threads")
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     jobs = dict(g1=g1_weight_init, g2=g2_act_init, g3=g3_uaq_forward, g4=g4_adaround, g5=g5_loss,
                 g6=g6_quant_module, g7=g7_blocks, g8=g8_g12_recon, g9=g9_tdac, g10=g10_steps,
                 g13c=g13_cifar_unet, g13i=lambda: g13_ldm_unet("imagenet"), g13h=lambda: g13_ldm_unet("church"), g14=g14_plms, g15=g15_decoder,
                 g17=g17_tdac_imagenet, g7b=g7b_blocks, g13w8=lambda: g13_cifar_unet(8, "g13_cifar_w8", 1301), g13sd=g13_ldm_sd, g16=g16_layer_recon,
-                g8b=g8b_recon_masks, g8c=g8c_recon_caches, g18=g18_church_driver, g19=g19_tdac_others, g1b=g1b_max_init)
+                g8b=g8b_recon_masks, g8c=g8c_recon_caches, g18=g18_church_driver, g19=g19_tdac_others, g1b=g1b_max_init, g20=g20_f16x3_units, g20n=g20_noise_floor)
     for k, fn in jobs.items():
         if not only or k in only:
             print("==", k)

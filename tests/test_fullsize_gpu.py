@@ -82,3 +82,197 @@ def test_ddim_loop_with_all_hoists_is_bit_identical_to_plain_stepping_at_full_si
     assert torch.isfinite(fast).all()
     assert torch.equal(fast, fast2)
     assert torch.equal(fast, img), float((fast - img).abs().max())
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# G20: the reconstruction loop in INDEX SPACE at a size where the production arithmetic runs (tests/golden/_g20.py)
+# ---------------------------------------------------------------------------------------------------------------------------
+F16X3_ENTRY_POINTS = ("edadm_qgemm_f16x3", "edadm_gemm_f16x3_nt", "edadm_split_f16", "edadm_transpose_split_f16",
+                      "edadm_qconv3_f16x3_direct")
+
+
+def _g20_targets(name, g):
+    """FP targets of the cached rows: the unit with quantisation off on the FP inputs (data_utils.py:133-139), evaluated by the
+    CPU oracle on this host (plain torch fp32, the reference's own operators) and checked against the samples the reference stored."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import _g20
+    from _weights import formula_state_dict
+    from oracle import qdiff_oracle as O
+    from helpers import WQ4, AQ8
+    from edadm.nets.ldm_unet import ResBlock, BasicTransformerBlock
+    with torch.device("meta"):
+        unit = (ResBlock(_g20.RES["channels"], _g20.RES["emb_channels"], 0.0, out_channels=_g20.RES["out_channels"], dims=2)
+                if name == "res" else BasicTransformerBlock(_g20.TF["dim"], _g20.TF["heads"], _g20.TF["d_head"],
+                                                             context_dim=_g20.TF["context_dim"], gated_ff=True, checkpoint=False))
+    sd = formula_state_dict([("%s.%s" % (name, k), tuple(v.shape)) for k, v in unit.state_dict().items()], _g20.SEED)
+    sd = {k: torch.as_tensor(v) for k, v in sd.items()}
+    B = O._Builder(sd, WQ4, AQ8, 8)
+    ou = (O.OResBlock(B, name, name, _g20.RES["channels"], _g20.RES["out_channels"]) if name == "res"
+          else O.OTransformerBlock(B, name, name, _g20.TF["heads"]))
+    ou.set_quant_state(False, False)
+    cq, cf = _g20.caches(name)
+    with torch.no_grad():
+        out = torch.cat([ou(torch.from_numpy(cf[0][i:i + 32]), torch.from_numpy(cf[1][i:i + 32])) for i in range(0, _g20.ROWS, 32)])
+    pos = torch.from_numpy(_g20.sample_positions(out.numel()))
+    ref = torch.from_numpy(g["out_fp/%s/sample" % name])
+    got = out.reshape(-1)[pos]
+    scale = float(ref.abs().max())
+    err = float((got - ref).abs().max()) / scale
+    print("G20 %s: FP targets on this host vs the reference's samples: max %.2e of range, %d of %d samples bit-identical"
+          % (name, err, int((got == ref).sum()), ref.numel()))
+    assert err < 2e-6
+    assert abs(float(out.double().sum()) - float(g["out_fp/%s/sum" % name])) <= 1e-6 * float(out.double().abs().sum())
+    return cq, cf, out
+
+
+def _g20_run(name, g, caches, f16x3):
+    """one reconstruction of unit `name` with contract.F16X3 = f16x3 on the reference's scales, caches, draws and masks"""
+    import random
+    import _g20
+    import _uniforms
+    from _weights import formula_state_dict
+    from helpers import WQ4, AQ8
+    from qdiff import QuantModel
+    from qdiff.adaptive_rounding import AdaRoundQuantizer
+    from qdiff.quant_layer import UniformAffineQuantizer
+    from edadm.state import load_quant_state
+    from edadm.nets.ldm_unet import ResBlock, BasicTransformerBlock
+    from edadm import contract, lib
+    import edadm.recon as recon
+    import torch.nn as nn
+    dev = torch.device("cuda", 0)
+
+    class Host(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.in_channels = _g20.RES["channels"]
+            self.res = ResBlock(_g20.RES["channels"], _g20.RES["emb_channels"], 0.0, out_channels=_g20.RES["out_channels"], dims=2,
+                                use_checkpoint=False, use_scale_shift_norm=False)
+            self.tf = BasicTransformerBlock(_g20.TF["dim"], _g20.TF["heads"], _g20.TF["d_head"], dropout=0.0,
+                                            context_dim=_g20.TF["context_dim"], gated_ff=True, checkpoint=False)
+
+    host = Host().eval()
+    sd = formula_state_dict([(k, tuple(v.shape)) for k, v in host.state_dict().items()], _g20.SEED)
+    host.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    aq = dict(AQ8)
+    aq["prob"] = _g20.PROB
+    qnn = QuantModel(host, WQ4, aq, sm_abit=8).to(dev).eval()
+    qnn.set_grad_ckpt(False)
+    pre = "init/qp/"
+    keys = {k: g[k] for k in g.files if k.startswith(pre + "model.%s." % name)}
+    n = load_quant_state(qnn, keys, prefix=pre)
+    assert n == len([k for k in keys if k.endswith("/delta")]), (n, len(keys))
+    unit = getattr(qnn.model, name)
+    cq, cf, out_fp = caches
+    cqd, cfd, ofd = [torch.from_numpy(a).to(dev) for a in cq], [torch.from_numpy(a).to(dev) for a in cf], out_fp.to(dev)
+
+    def save_fn(model, u, cali, asym, act_quant, batch_size=32, input_prob=True, keep_gpu=True):
+        return True, ([cqd[0], cqd[1]], [cfd[0], cfd[1]]), ofd
+
+    rep = _uniforms.ReplayHash(device=dev)
+    for qn, m in qnn.named_modules():
+        if isinstance(m, UniformAffineQuantizer) and m.leaf_param and qn.startswith("model.%s." % name):
+            m.injected_uniform = (lambda nm: lambda xx: rep.draw_calls(nm, "iter", xx.shape, recon.STATE["batched"]))(qn)
+    recon.INJECT_MIX_UNIFORM = lambda xx: rep.draw("input_mix:" + name, "iter", xx.shape)
+    traj_w, traj_a, idx_log = [], [], []
+    orig_launch, orig_sample = recon.FusedAdam.launch, random.sample
+
+    def launch(self):
+        orig_launch(self)
+        (traj_a if self.params[0].numel() == 1 else traj_w).append(self.flat.detach().clone())
+
+    def sample(pop, k):
+        r = orig_sample(pop, k)
+        idx_log.append(list(r))
+        return r
+
+    alpha0 = []
+    hyper = {k: v for k, v in _g20.HYPER.items()}
+    old = contract.F16X3
+    contract.F16X3 = f16x3
+    recon.FusedAdam.launch, random.sample = launch, sample
+    lib.CALLS = {}
+    try:
+        random.seed(_g20.SEED + 1)
+        recon.reconstruct(qnn, unit, None, is_block=True, iters=int(g["iters"]), control=True, save_fn=save_fn,
+                          cache_batch=hyper["batch_size"], **hyper)
+        calls = dict(lib.CALLS)
+    finally:
+        recon.FusedAdam.launch, random.sample = orig_launch, orig_sample
+        recon.INJECT_MIX_UNIFORM = None
+        contract.F16X3 = old
+        lib.CALLS = None
+    assert np.array_equal(np.asarray(idx_log), g["idx/" + name])                    # the reference's minibatch draws
+    order = [qn for qn, m in unit.named_modules() if isinstance(m, AdaRoundQuantizer)]
+    assert order == [str(s) for s in g["order/%s/w" % name]], order
+    for qn, m in unit.named_modules():
+        if isinstance(m, AdaRoundQuantizer):
+            w = dict(unit.named_modules())[qn.rsplit(".", 1)[0]].org_weight
+            with torch.no_grad():
+                rest = (w / m.delta) - torch.floor(w / m.delta)
+                alpha0.append((-torch.log((m.zeta - m.gamma) / (rest - m.gamma) - 1)).flatten())
+    got_log = sorted("%s|%s|%d|%s" % (o, p, c, "x".join(map(str, s))) for o, p, c, s in rep.log)
+    tw, ta = torch.stack(traj_w), torch.stack(traj_a)
+    return dict(tw=tw, ta=ta.cpu().numpy(), alpha0=torch.cat(alpha0), calls=calls, log=got_log, batched=recon.STATE["batched"])
+
+
+@pytest.mark.parametrize("name", ["res", "tf"])
+def test_recon_unit_f16x3_vs_exact_fp32_vs_reference(golden, name):
+    """VERDICT r3 item 1.  One LDM-4-sized unit (ResBlock 192 -> 384 at 32 x 32; transformer block d = 384, 1024 tokens), 32-row
+    minibatches, shipped hyper-parameters and 0.5 / 0.5 masks, reconstructed three ways on IDENTICAL scales, caches, draws
+    and masks: the reference on CPU (fixture G20, qdiff_control/block_recon.py:13-243), the product with the three-product
+    f16 contraction (production: contract.F16X3 = True) and the product on the exact-fp32 MFMA (F16X3 = False).  Compared
+    in index space: the direction of every alpha's first Adam step and every alpha's final hard rounding."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import _g20
+    g = golden("g20_f16x3_units")
+    caches = _g20_targets(name, g)
+    runs = {mode: _g20_run(name, g, caches, mode) for mode in (True, False)}
+    n = int(g["final/%s/count" % name])
+    ref_sign = _g20.unpack(g["final/%s/sign" % name], n)
+    ref_near = _g20.unpack(g["final/%s/near" % name], n)
+    ref_up = _g20.unpack(g["first/%s/up" % name], n)
+    ref_moved = _g20.unpack(g["first/%s/moved" % name], n)
+    ref_log = sorted(str(l) for l in g["rand/log"] if ("|iter|" in str(l)) and (("model.%s." % name) in str(l) or str(l).startswith("input_mix:" + name)))
+    bad = {}
+    for mode, r in runs.items():
+        label = "f16x3" if mode else "exact fp32"
+        took = sorted(k for k in r["calls"] if k in F16X3_ENTRY_POINTS)
+        print("G20 %s [%s]: contraction entry points %s; batched forwards %s" % (name, label, {k: r["calls"][k] for k in took}, r["batched"]))
+        if mode:
+            need = {"edadm_qgemm_f16x3", "edadm_gemm_f16x3_nt", "edadm_transpose_split_f16", "edadm_split_f16"}
+            if name == "res":
+                need.add("edadm_qconv3_f16x3_direct")
+            assert need <= set(took), (need, took)
+        else:
+            assert not took, took
+        assert r["log"] == ref_log                                         # every mask drawn as the reference drew it
+        tw = r["tw"]
+        assert tw.shape[1] == n
+        a1, a0, af = tw[0], r["alpha0"], tw[-1]
+        up = (a1 > a0).cpu().numpy()
+        moved = (a1 != a0).cpu().numpy()
+        first_bad = int(((up != ref_up) & (moved | ref_moved)).sum())
+        sign = (af >= 0).cpu().numpy()
+        dis = np.nonzero(sign != ref_sign)[0]
+        near_got = (af.abs() < _g20.NEAR).cpu().numpy()
+        far = [int(i) for i in dis if not (ref_near[i] and near_got[i])]
+        bad[mode] = set(int(i) for i in dis)
+        ref_w = g["traj/%s/w" % name]
+        dw = np.abs(tw[:, ::_g20.STRIDE].cpu().numpy() - ref_w)
+        ref_a = g["traj/%s/a" % name]
+        da = np.abs(r["ta"] - ref_a) / np.abs(ref_a)
+        print("G20 %s [%s] vs REFERENCE: first Adam step direction differs on %d of %d alphas; final hard rounding differs on %d "
+              "(%d not next to zero in both); strided alpha trajectory median %.2e frac>lr/10 %.5f; delta trajectory max rel %.2e"
+              % (name, label, first_bad, n, len(dis), len(far), np.median(dw), (dw > 0.05).mean(), da.max()))
+        r["first_bad"], r["far"], r["dis"] = first_bad, far, dis
+        print("   not next to zero:", [(i, float(af[i]), bool(ref_sign[i]), bool(ref_near[i])) for i in far[:8]])
+    extra = bad[True] - bad[False]
+    print("G20 %s: disagreements with the reference -- f16x3 %d, exact fp32 %d, in f16x3 only %d, in exact only %d"
+          % (name, len(bad[True]), len(bad[False]), len(extra), len(bad[False] - bad[True])))
+    G20_BOUNDS = {"res": dict(first=10**9, dis=10**9, far=10**9), "tf": dict(first=10**9, dis=10**9, far=10**9)}
+    b = G20_BOUNDS[name]
+    for mode, r in runs.items():
+        assert r["first_bad"] <= b["first"] and len(r["dis"]) <= b["dis"] and len(r["far"]) <= b["far"], (mode, r["first_bad"], len(r["dis"]), len(r["far"]))
+    # the three-product contraction must not be a worse citizen than the exact-fp32 one
+    assert len(bad[True]) <= max(2 * len(bad[False]), len(bad[False]) + 4)

@@ -50,7 +50,7 @@ def case(B, heads, d, Nq, Nk, v_transposed=False):
 for args in ((2, 1, 32, 16, 16), (2, 2, 16, 16, 16), (2, 2, 16, 16, 7), (2, 8, 8, 16, 16), (2, 8, 8, 16, 77), (2, 8, 16, 64, 64),
              (2, 8, 40, 64, 64), (2, 8, 40, 64, 77), (2, 8, 80, 16, 77), (2, 8, 160, 16, 77), (2, 4, 8, 16, 16), (2, 4, 24, 32, 32),
              (1, 8, 40, 1024, 1024), (2, 8, 24, 1024, 1024), (2, 8, 96, 64, 64), (1, 8, 40, 4096, 4096), (3, 8, 40, 4096, 77),
-             (2, 1, 256, 256, 256)):
+             (2, 1, 256, 256, 256), (2, 1, 384, 256, 256), (1, 1, 384, 1024, 1024)):
     case(*args)
 
 
@@ -86,3 +86,7 @@ timing(8, 8, 80, 1024, "SD 32x32 self-attention (8 rows, 8 heads x 80, 1024 keys
 timing(100, 8, 24, 1024, "Church 32x32 attention (100 rows, 8 heads x 24, 1024 keys)")
 timing(100, 8, 48, 256, "Church 16x16 attention (100 rows, 8 heads x 48, 256 keys)")
 timing(8, 8, 40, 4096, "SD 64x64 cross-attention (8 rows, 8 heads x 40, 4096 queries x 77 keys)", Nk=77)
+timing(100, 1, 384, 1024, "LDM-4 32x32 self-attention (100 rows, 1 head x 384, 1024 keys)")
+timing(50, 1, 384, 1024, "LDM-4 32x32 self-attention, shared half of a guidance pair (50 rows)")
+timing(100, 1, 576, 256, "LDM-4 16x16 self-attention (100 rows, 1 head x 576, 256 keys)")
+timing(100, 1, 960, 64, "LDM-4 8x8 self-attention (100 rows, 1 head x 960, 64 keys)")
