@@ -328,8 +328,9 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
         if TIMING is not None:
             torch.cuda.synchronize()
             _t_feat = time.time()
+        tr = getattr(model, "_fp_trace", None)               # the walk's HBM scale (qdiff.data_utils.hbm_scale), 1 without a trace
         feats = fp_features(unit, hooks, cached_inps, resblock, sz, batch_size,
-                            int(FP_FEAT_GB * (1 << 30)))
+                            int(FP_FEAT_GB * (tr.scale if tr is not None else 1.0) * (1 << 30)))
         unit.set_quant_state(True, act_quant)
         if TIMING is not None:
             torch.cuda.synchronize()

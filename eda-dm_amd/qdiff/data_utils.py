@@ -18,6 +18,8 @@ are kept first: most compute per cached byte).  The cached tensors are the value
 (same kernels, same inputs)."""
 import os
 
+import logging
+
 import torch
 
 from qdiff.quant_layer import QuantModule
@@ -87,6 +89,8 @@ class GetLayerInpOut:
             return resblock, input_store, self.data_saver.output_store.detach(), input_sym
         return resblock, input_store, self.data_saver.output_store.detach()
 
+logger = logging.getLogger(__name__)
+
 
 def recon_units(module, out=None):
     """The reconstruction units of a model: first QuantModule / BaseQuantBlock met on every path from the root (the
@@ -106,20 +110,43 @@ def recon_units(module, out=None):
 FP_TRACE_GB = 96.0          # look-ahead FP activations of pending units (4 FP prefix sweeps at the shipped size; 48: 9 sweeps, +7 s)
 Q_MEMO_GB = 64.0            # outputs of already reconstructed units under the quantised prefix
 STATS = {"fp_passes": 0, "fp_captures": 0, "units_served": 0, "memo_hits": 0}    # counters for bench.py / tests
+# what the walk keeps beside the three caches: the current unit's (inp_q, inp_fp, out_fp) slabs (<= 19 GB at the shipped size), the
+# model, the optimiser state and the iteration graph's working set
+HBM_RESERVE_GB = 40.0
+
+
+def hbm_scale(device, log=True):
+    """The constants above (and edadm.recon.FP_FEAT_GB) are UPPER bounds sized for a whole 288 GB MI355X.  On a shared GPU, a part
+    with less HBM or beside a larger resident model the walk degrades instead of running out of memory: every budget is scaled by
+    min(1, (free HBM - HBM_RESERVE_GB) / (sum of the three budgets)), free = what the driver reports + what torch's allocator holds
+    but does not use.  Evaluated once per walk (when the look-ahead trace is created); the walk then groups / memoises less and
+    runs more prefix passes -- same results (the caches only skip recomputation)."""
+    import edadm.recon as er
+    want = FP_TRACE_GB + Q_MEMO_GB + er.FP_FEAT_GB
+    if want <= 0 or not torch.cuda.is_available():
+        return 1.0
+    free, total = torch.cuda.mem_get_info(device)
+    free += torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+    scale = max(0.0, min(1.0, (free / 2 ** 30 - HBM_RESERVE_GB) / want))
+    if log and scale < 1.0:
+        logger.warning("calibration caches scaled to %.0f %% of their budgets: %.0f GB of HBM free (of %.0f), %.0f GB wanted + %.0f reserved"
+                       % (100 * scale, free / 2 ** 30, total / 2 ** 30, want, HBM_RESERVE_GB))
+    return scale
 
 
 class FPTrace:
     """FP (input, output) pairs of upcoming units, captured ahead of their turn."""
 
-    def __init__(self, key, budget_bytes):
+    def __init__(self, key, budget_bytes, scale=1.0):
         self.key, self.budget = key, budget_bytes
+        self.scale = scale           # of every cache budget of this walk (hbm_scale): edadm.recon reads it for the feature maps
         self.store = {}          # unit -> {batch index: (inputs tuple, output)}
         self.done = set()
         self.passes = 0          # FP prefix passes run (one per calibration batch per capture)
         self.memo = {}           # reconstructed unit -> {batch index: output under the quantised prefix}
         self.memo_admit = {}     # unit -> admitted (bytes reserved for all local batches) or refused
         self.memo_bytes = 0
-        self.memo_budget = int(Q_MEMO_GB * (1 << 30))
+        self.memo_budget = int(Q_MEMO_GB * scale * (1 << 30))
 
     @staticmethod
     def _density(unit, out):
@@ -226,7 +253,8 @@ def _trace_for(model, cali_data, batch_size, batch_transform):
     key = (tuple((c.data_ptr(), tuple(c.shape)) for c in cali_data), batch_size, batch_transform)
     tr = getattr(model, "_fp_trace", None)
     if tr is None or tr.key != key:
-        tr = FPTrace(key, int(gb * (1 << 30)))
+        scale = hbm_scale(cali_data[0].device) if cali_data[0].is_cuda else 1.0
+        tr = FPTrace(key, int(gb * scale * (1 << 30)), scale)
         model._fp_trace = tr
     return tr
 

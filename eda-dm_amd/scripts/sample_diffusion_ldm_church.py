@@ -23,6 +23,8 @@ if PKG not in sys.path:
 
 CHURCH = dict(image_size=32, in_channels=4, out_channels=4, model_channels=192, attention_resolutions=[1, 2, 4, 8], num_res_blocks=2,
               channel_mult=[1, 2, 2, 4, 4], num_heads=8, use_scale_shift_norm=True, resblock_updown=True)
+# what distinguishes the unconditional LDM tasks (scripts/sample_diffusion_ldm_bedroom.py reuses this module with its own table)
+TASK = dict(unet=CHURCH, linear_start=0.0015, linear_end=0.0155, tdac="TDAC_church_calib_data_generator")
 
 
 def parser():
@@ -60,10 +62,11 @@ def build(args, dev):
     from qdiff import QuantModel
     from qdiff.utils import seed_everything
     seed_everything(args.seed)
-    kw = args.unet or CHURCH
+    kw = args.unet or TASK["unet"]
     unet = UNetModel(**kw)
     H.reinit_zero_modules(unet, args.seed)
-    ld = LatentDiffusionLite(unet, timesteps=1000, linear_start=0.0015, linear_end=0.0155, conditioning_key=None).to(dev).eval()
+    ld = LatentDiffusionLite(unet, timesteps=1000, linear_start=TASK["linear_start"], linear_end=TASK["linear_end"],
+                             conditioning_key=None).to(dev).eval()
     wq = {'n_bits': args.weight_bit, 'symmetric': True, 'channel_wise': True, 'scale_method': 'mse'}
     aq = {'n_bits': args.act_bit, 'symmetric': True, 'channel_wise': False, 'scale_method': 'mse', 'leaf_param': True, 'prob': 0.5}
     qnn = QuantModel(model=ld.model.diffusion_model, weight_quant_params=wq, act_quant_params=aq, sm_abit=args.sm_abit).to(dev).eval()
@@ -76,12 +79,12 @@ def build(args, dev):
 
 def calibrate(args):
     from edadm import harness as H
-    from scripts.calibration import TDAC_church_calib_data_generator
+    from scripts import calibration as tdac_mod
     from qdiff import set_weight_quantize_params_LDM, set_act_quantize_params_LDM, Change_LDM_model_attnblock, recon_block_Qmodel
     world, rank, dev = H.init_dist()
     ld, qnn, kw, aq = build(args, dev)
     t0 = H.now()
-    cali = TDAC_church_calib_data_generator(ld, args, args.calib_num_samples, args.batch_samples, dev, args.custom_steps)
+    cali = getattr(tdac_mod, TASK["tdac"])(ld, args, args.calib_num_samples, args.batch_samples, dev, args.custom_steps)
     t1 = H.now()
     if args.split:
         qnn.model.split_shortcut = True
@@ -116,8 +119,8 @@ def sample(args):
             Change_LDM_model_attnblock(qnn, aq)                 # module paths of the saved state are those after the wrap
     eng = H.load_calibrated(qnn, args.state, lambda: qnn(torch.zeros(2, C, S, S, device=dev), torch.zeros(2, dtype=torch.long, device=dev)))
     B = args.batch_size
-    loop = DDIMLoop(eng, (C, S, S), B, steps=args.custom_steps, eta=args.eta, scale=1.0, linear_start=0.0015, linear_end=0.0155,
-                    context_shape=None, device=dev)
+    loop = DDIMLoop(eng, (C, S, S), B, steps=args.custom_steps, eta=args.eta, scale=1.0, linear_start=TASK["linear_start"],
+                    linear_end=TASK["linear_end"], context_shape=None, device=dev)
 
     def batch(i, gen):
         return loop.sample(torch.randn(B, C, S, S, generator=gen, device=dev))
@@ -125,8 +128,18 @@ def sample(args):
     H.run_sharded(batch, args.n_samples, B, args.seed, save=args.save, max_batches=args.max_batches, extra={"steps": args.custom_steps})
 
 
-def main(argv=None):
-    args = parser().parse_args(argv)
+def main(argv=None, task=None, make_parser=None):
+    global TASK
+    saved = TASK
+    if task is not None:
+        TASK = task
+    try:
+        _main((make_parser or parser)().parse_args(argv))
+    finally:
+        TASK = saved
+
+
+def _main(args):
     if args.job == "calibrate":
         calibrate(args)
         if int(os.environ.get("RANK", "0")) == 0:

@@ -1695,7 +1695,7 @@ def g20_f16x3_units(threads=None, fname="g20_f16x3_units"):
     d["rand/log"] = np.array(["%s|%s|%d|%s" % (o, p, c, "x".join(map(str, s))) for o, p, c, s in rep.log])
     d["rand/check"] = np.array(checks, dtype=np.float64).reshape(-1, 3)
     if threads:
-        d = {k: v for k, v in d.items() if k.startswith(("final/", "first/", "traj/", "init/"))}
+        d = {k: v for k, v in d.items() if k.startswith(("final/res/", "final/tf/", "first/")) or (k.startswith("traj/") and k.endswith("/a"))}
         d["threads"] = np.int64(threads)
     save(fname, d)
 

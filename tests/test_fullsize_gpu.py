@@ -262,17 +262,33 @@ def test_recon_unit_f16x3_vs_exact_fp32_vs_reference(golden, name):
         dw = np.abs(tw[:, ::_g20.STRIDE].cpu().numpy() - ref_w)
         ref_a = g["traj/%s/a" % name]
         da = np.abs(r["ta"] - ref_a) / np.abs(ref_a)
+        worst_q = int(np.argmax(da.max(0)))
         print("G20 %s [%s] vs REFERENCE: first Adam step direction differs on %d of %d alphas; final hard rounding differs on %d "
-              "(%d not next to zero in both); strided alpha trajectory median %.2e frac>lr/10 %.5f; delta trajectory max rel %.2e"
-              % (name, label, first_bad, n, len(dis), len(far), np.median(dw), (dw > 0.05).mean(), da.max()))
+              "(%d not next to zero in both); strided alpha trajectory median %.2e frac>lr/10 %.5f; delta trajectory max rel %.2e (step size #%d, %.4g)"
+              % (name, label, first_bad, n, len(dis), len(far), np.median(dw), (dw > 0.05).mean(), da.max(), worst_q, float(ref_a[0, worst_q])))
         r["first_bad"], r["far"], r["dis"] = first_bad, far, dis
         print("   not next to zero:", [(i, float(af[i]), bool(ref_sign[i]), bool(ref_near[i])) for i in far[:8]])
     extra = bad[True] - bad[False]
     print("G20 %s: disagreements with the reference -- f16x3 %d, exact fp32 %d, in f16x3 only %d, in exact only %d"
           % (name, len(bad[True]), len(bad[False]), len(extra), len(bad[False] - bad[True])))
-    G20_BOUNDS = {"res": dict(first=10**9, dis=10**9, far=10**9), "tf": dict(first=10**9, dis=10**9, far=10**9)}
+    # the floor: the reference against ITSELF with 3 CPU threads instead of 8 (g20_reference_3threads: another partition of torch's
+    # fp32 sums, nothing else changed)
+    alt = golden("g20_reference_3threads")
+    alt_sign, alt_near = _g20.unpack(alt["final/%s/sign" % name], n), _g20.unpack(alt["final/%s/near" % name], n)
+    alt_dis = alt_sign != ref_sign
+    alt_a = np.abs(alt["traj/%s/a" % name] - g["traj/%s/a" % name]) / np.abs(g["traj/%s/a" % name])
+    print("G20 %s: the reference with 3 threads vs the reference with 8: final hard rounding differs on %d (%d not next to zero in both); "
+          "delta trajectory max rel %.2e" % (name, int(alt_dis.sum()), int((alt_dis & ~(alt_near & ref_near)).sum()), alt_a.max()))
+    # Measured (round 4, MI355X): ResBlock 192 -> 384 at 32 x 32, 2 359 296 alphas -- first-step direction 2491 (f16x3) / 2497 (exact fp32),
+    # final rounding 71 / 65 (3 / 2 not next to zero), reference vs itself 2.  Transformer block d = 384 x 1024 tokens, 3 047 424
+    # alphas -- first step 6941 / 6704, final 8788 / 8660 (2110 / 2056 not next to zero), reference vs itself 534: its softmax
+    # step sizes (~0.004) move 2.5 % per Adam step at the shipped lr_a = 1e-4, and a noise-level gradient decides the direction.
+    # Gates at 2x the measurement.  The production arithmetic (three f16 products) and the exact-fp32 MFMA are equally far from
+    # the reference: what separates the GPU from the CPU is the order of its fp32 sums, not the operand expansion.
+    G20_BOUNDS = {"res": dict(first=5000, dis=142, far=6), "tf": dict(first=14000, dis=17600, far=4300)}
     b = G20_BOUNDS[name]
     for mode, r in runs.items():
         assert r["first_bad"] <= b["first"] and len(r["dis"]) <= b["dis"] and len(r["far"]) <= b["far"], (mode, r["first_bad"], len(r["dis"]), len(r["far"]))
     # the three-product contraction must not be a worse citizen than the exact-fp32 one
-    assert len(bad[True]) <= max(2 * len(bad[False]), len(bad[False]) + 4)
+    assert len(bad[True]) <= 1.25 * len(bad[False]) + 8, (len(bad[True]), len(bad[False]))
+    assert runs[True]["first_bad"] <= 1.25 * runs[False]["first_bad"] + 8

@@ -635,6 +635,21 @@ def test_task_harness_church_ldm(golden, tmp_path, capsys):
                  ["--n_samples", "8", "--batch_size", "4"], tmp_path, capsys, 2)
 
 
+def test_task_harness_bedroom_ldm(golden, tmp_path, capsys):
+    """scripts/sample_diffusion_ldm_bedroom.py (reference :257-316): the Church flow over TDAC_bedroom_calib_data_generator with the
+    bedroom task table (eta 1 DDIM: the stochastic update's noise comes from the per-batch generator, so two runs agree)."""
+    import json
+    from scripts import sample_diffusion_ldm_bedroom as H
+    from scripts import sample_diffusion_ldm_church as C
+    base = golden("g13_ldm_church")
+    kw = {k[4:]: (base[k].tolist() if base[k].ndim else base[k].item()) for k in base.files if k.startswith("cfg/")}
+    common = ["--unet", json.dumps(kw), "--custom_steps", "20"]
+    assert H.parser().parse_args(["calibrate"]).eta == 1.0 and H.parser().parse_args(["calibrate"]).custom_steps == 200
+    _run_harness(H, common, ["--calib_num_samples", "32", "--batch_samples", "8", "--iters", "2"],
+                 ["--n_samples", "8", "--batch_size", "4", "--eta", "0.0"], tmp_path, capsys, 2)
+    assert C.TASK["tdac"] == "TDAC_church_calib_data_generator"          # the task table is restored after the run
+
+
 def test_task_harness_txt2img_sd(golden, tmp_path, capsys):
     """scripts/sample_txt2img.py (reference :154-283; BASELINE config 5) on a Stable-Diffusion-shaped fixture UNet (8 heads, 77-token
     context): TDAC_coco through the PLMS sampler with guidance -> set_*_quantize_params_Stable -> conditional walk at batch 2 ->
