@@ -283,9 +283,10 @@ def time_h1_contraction(dev):
 
 
 def cpu_baseline(qnn, sd_cpu):
-    """The oracle (CPU restatement of the reference's PyTorch fake-quant path) on this box's host
-    cores: UNet forwards of one CFG-doubled image (2 rows, 1/20 of an image's work each), repeated until ~12 s of CPU
-    work have been timed (at most 4 forwards)."""
+    """The oracle (CPU restatement of the reference's PyTorch fake-quant path) on this box's host cores.  One image of the metric is
+    20 DDIM steps x one CFG-doubled UNet forward (2 rows) = 20 such forwards; timed here: as many of them as fit ~30 s of CPU work
+    (at least 2, at most 20 = one whole image), every one a full fake-quant forward at its own timestep of the 20-step schedule --
+    the per-forward cost does not depend on the step, so images/s = 1 / (20 x mean forward time); `extrapolation` states the factor."""
     from oracle import qdiff_oracle as O
     from edadm.state import quant_state_dict
     net = O.OUNet(sd_cpu, WQ, AQ, 8, **LDM4)
@@ -293,23 +294,25 @@ def cpu_baseline(qnn, sd_cpu):
     net.disable_network_output_quantization()
     net.split_shortcut = True
     g = torch.Generator().manual_seed(7)
-    x, t, c = torch.randn(2, 3, 64, 64, generator=g), torch.tensor([501, 501]), torch.randn(2, 1, 512, generator=g)
+    x, c = torch.randn(2, 3, 64, 64, generator=g), torch.randn(2, 1, 512, generator=g)
+    steps = list(np.arange(0, 1000, 50) + 1)[::-1]
     with torch.no_grad():
-        net(x, t, c)                                        # FP pass: creates split quantizers, warms up
+        net(x, torch.tensor([501, 501]), c)                  # FP pass: creates split quantizers, warms up
     st = {"qp/" + k: v for k, v in quant_state_dict(qnn).items()}
     net.load_qparams(st, prefix="qp/model.")
     net.set_quant_state(True, True)
     n, total = 0, 0.0
     with torch.no_grad():
-        while n < 4 and total < 12.0:
+        while n < 20 and (n < 2 or total < 30.0):
             t0 = time.time()
-            net(x, t, c)
+            net(x, torch.tensor([int(steps[n])] * 2), c)
             total += time.time() - t0
             n += 1
     dt = total / n
     return dict(value=1.0 / (20 * dt), unit="images/sec", cores=torch.get_num_threads(), kind="port",
-                sample="%d fake-quant UNet forwards of 1 CFG-doubled image (2 rows) = 1/20 of an image each; %.2f s in all"
-                       % (n, total))
+                sample="%d of the 20 fake-quant UNet forwards (CFG-doubled, 2 rows) of ONE image, %.1f s of CPU work" % (n, total),
+                extrapolation={"forwards_timed": n, "forwards_per_image": 20, "factor": 20.0 / n,
+                               "note": "a forward costs the same at every timestep: images/s = 1 / (20 x mean forward time)"})
 
 
 def main():
@@ -319,9 +322,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--calib", choices=["full", "bounded", "none"], default="full",
-                    help="N = 1 only.  full (default): the whole calibration job at the shipped size, measured (~9 min); bounded: a 256-sample "
-                         "x 40-iteration reconstruction walk extrapolated linearly (~1 min); none")
+    ap.add_argument("--calib", choices=["full", "bounded", "none"], default=None,
+                    help="full (default at N = 1): the whole calibration job at the shipped size, measured (~8 min); with N > 1 every rank runs "
+                         "it (TDAC and activation caching sharded) and the line carries the max-over-ranks wall-clock -- not the default there, "
+                         "the sampling throughput is; bounded (N = 1): a 256-sample x 40-iteration reconstruction walk extrapolated linearly "
+                         "(~1 min); none")
     ap.add_argument("--no-calib", action="store_true", help="= --calib none")
     ap.add_argument("--calib-ranks", action="store_true",
                     help="with --gpus N > 1: also time a bounded reconstruction walk with the activation caching sharded over the "
@@ -329,6 +334,8 @@ def main():
     args = ap.parse_args()
     if args.no_calib:
         args.calib = "none"
+    if args.calib is None:
+        args.calib = "full" if args.gpus <= 1 else "none"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` on its own: start N ranks (one process per GPU) through torch.distributed.run as a
@@ -420,18 +427,24 @@ def main():
     eng.ctx_r = eng.emb_r = None
     eng.cfg_pair = False
 
-    def kernel_ms(run, reps=5):
-        """average device time of one recorded GEMM launch: `reps` back-to-back launches between two HIP
-        events on the launch stream (a split layer is two launches and accumulates into its own output,
-        which does not change its timing)"""
+    # Each recorded launch is timed on its own between two HIP events (on the launch stream), `reps` times, and between two timed
+    # launches a 320 MB buffer is rewritten: the operands of the next launch are no longer in L2 (32 MB) or the Infinity Cache
+    # (256 MB) -- colder than in situ, where the producer has just written them.  (Round 3 replayed each launch 5x back to back:
+    # 15.57 ms for the group against 16.03 ms in the rocprof trace of the real call.)  `roofline` uses these cold numbers.
+    flush = torch.empty(80 * 1024 * 1024, dtype=torch.float32, device=dev)
+
+    def kernel_ms(run, reps=3):
         run()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
+        total = 0.0
+        for r in range(reps):
+            flush.fill_(float(r))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             run()
-        e1.record()
-        e1.synchronize()
-        return e0.elapsed_time(e1) / reps
+            e1.record()
+            e1.synchronize()
+            total += e0.elapsed_time(e1)
+        return total / reps
 
     i8 = [(f, kernel_ms(run), sum(v for k, v in by.items() if k != "kind")) for mode, _, _, _, _, f, run, by in prof if mode == "i8"]
     gemm_flop, gemm_ms = sum(r[0] for r in i8), sum(r[1] for r in i8)
@@ -444,11 +457,19 @@ def main():
     torch.cuda.synchronize()
     unet_ms = ev0.elapsed_time(ev1)
 
+    # HBM bytes per launch of the dominant kernel group from the committed rocprofv3 --pmc passes (tools/prof_round.sh step 2).  The
+    # file names the sources it was measured on (sha256 of csrc/gemm.hip); a file of another build is NOT used: traffic = null
     traffic, traffic_src = None, None
-    for name in ("r03z_gemm_traffic.json", "r02z_gemm_traffic.json"):
-        try:        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    import hashlib
+    with open(os.path.join(ROOT, "eda-dm_amd", "csrc", "gemm.hip"), "rb") as fh:
+        gemm_sha = hashlib.sha256(fh.read()).hexdigest()
+    for name in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_gemm_traffic.json")), reverse=True):
+        try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 tj = json.load(fh)
+            if tj.get("gemm_hip_sha256") != gemm_sha:
+                traffic_src = "stale: profiles/%s was measured on another csrc/gemm.hip" % name if traffic_src is None else traffic_src
+                continue
             # bytes of all int8 GEMM launches of one UNet call / the GEMM calls timed above (a split or tail-re-tiled
             # layer is two device launches of one call)
             traffic = tj["hbm_bytes_per_launch"] * tj["launches"] / tj.get("unet_calls", 4) / max(len(i8), 1)
@@ -523,33 +544,64 @@ def main():
         if decode is not None:
             line["first_stage_decode"] = decode
         if calib_mr is not None:
-            line["calibration"]["multi_rank"] = calib_mr
+            line["calibration"]["multi_rank_bounded_walk"] = calib_mr
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(qnn, sd_cpu)
             except Exception as e:      # the baseline is a report, never a reason to lose the bench line
                 line["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": torch.get_num_threads(),
                                         "kind": "port", "sample": "failed: %r" % (e,)}
-        if world == 1 and args.calib != "none":
-            try:
-                if args.calib == "bounded":
-                    line["calibration"]["reconstruction_bounded"] = time_calibration(qnn, dev)
-                else:
-                    # the sampling model, its engine, graphs and the decoder leave HBM first: the job needs ~175 GB
-                    del loop, eng, dec, prof, i8
-                    qnn.engine = None
-                    qnn = None
-                    import gc
-                    gc.collect()
-                    torch.cuda.empty_cache()
-                    full = full_calibration(dev)
-                    line["calibration"].update(full)
-                    line["calibration"]["metric"] = "full calibration+recon wall-clock, W4A8 LDM-4 ImageNet 256x256, 1 x MI355X"
-                    line["calibration"]["value_s"] = full["wall_s"]
-                line["calibration"]["h1_contraction"] = time_h1_contraction(dev)
-            except Exception as e:
-                import traceback
-                line["calibration"]["error"] = repr(e) + " | " + traceback.format_exc()[-600:]
+    # ---- the calibration job.  N = 1: bounded or full.  N > 1 with --calib full: EVERY rank runs the job -- TDAC trajectory batches and
+    # the activation caching are sharded (one all_gather_into_tensor per tensor / cached slab), scale initialisation and the
+    # reconstruction loops run replicated with rank 0's learned parameters broadcast after each unit -- and the wall-clock is the
+    # max over ranks between two barriers.
+    calib_out = {}
+    if args.calib != "none" and (world == 1 or args.calib == "full"):
+        try:
+            if args.calib == "bounded":
+                calib_out["reconstruction_bounded"] = time_calibration(qnn, dev)
+            else:
+                # the sampling model, its engine, graphs and the decoder leave HBM first: the job needs ~175 GB
+                loop = eng = dec = prof = i8 = None
+                qnn.engine = None
+                qnn = None
+                import gc
+                gc.collect()
+                torch.cuda.empty_cache()
+                if world > 1:
+                    dist.barrier()
+                full = full_calibration(dev)
+                if world > 1:
+                    dist.barrier()
+                    tt = torch.tensor([full["wall_s"]] + [full["stages"][k] for k in ("tdac_s", "scale_init_s", "caching_s", "loop_s")],
+                                      device=dev, dtype=torch.float64)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    full["wall_s"] = float(tt[0])
+                    full["stages_max_over_ranks"] = dict(zip(("tdac_s", "scale_init_s", "caching_s", "loop_s"), [float(v) for v in tt[1:]]))
+                calib_out.update(full)
+                calib_out["metric"] = "full calibration+recon wall-clock, W4A8 LDM-4 ImageNet 256x256, %d x MI355X" % world
+                calib_out["value_s"] = full["wall_s"]
+                st = full["stages"]
+                sharded = st["tdac_s"] + st["caching_s"]
+                rest = full["wall_s"] - sharded
+                calib_out["multi_rank"] = {
+                    "ranks": world,
+                    "sharded_stages": "TDAC trajectory batches (one gather of the calibration latents), activation caching of every unit "
+                                      "(one gather per cached slab)",
+                    "replicated_stages": "scale initialisation (the activation ranges are an EMA over the batch sequence), reconstruction "
+                                         "loops (rank 0's alphas / step sizes broadcast after each unit)",
+                    "sharded_s_this_run": sharded, "replicated_s_this_run": rest,
+                    # what N ranks can gain at best with this split: the stages of THIS run, sharded ones divided by N / this N
+                    "ceiling": {str(n): (rest + sharded * world) / (rest + sharded * world / n) for n in (1, 2, 4, 8)},
+                    "ceiling_note": "speed-up over one rank if the sharded stages scaled perfectly; the loops (three quarters of the job) "
+                                    "would need data parallelism over the 32-row minibatch (SURVEY 8e(2)): DESIGN.md section 7 prices it"}
+            if rank == 0:
+                calib_out["h1_contraction"] = time_h1_contraction(dev)
+        except Exception as e:
+            import traceback
+            calib_out["error"] = repr(e) + " | " + traceback.format_exc()[-600:]
+    if rank == 0:
+        line["calibration"].update(calib_out)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -39,8 +39,17 @@ def TDAC_cifar_calib_data_generator(model, config, lamda, calib_num_samples, num
 
 
 def TDAC_imagenet_calib_data_generator(model, args, calib_num_samples, num_samples, device, num_timesteps):
-    """-> (calib_x, t, index, cond, uncond) for class-conditional LDM with classifier-free guidance."""
+    """-> (calib_x, t, index, cond, uncond) for class-conditional LDM with classifier-free guidance (scripts/calibration.py:371-499).
+
+    With several ranks (edadm.dist.world) the trajectory batches -- independent DDIM runs, the whole cost of this stage -- are
+    sharded: rank r runs the contiguous block edadm.dist.shard_batches gives it, picks its rows of the calibration set locally and
+    ONE all_gather_into_tensor per returned tensor completes them everywhere ("TDAC trajectory generation shards by
+    sample").  The start noises are drawn up front by every rank in the reference's order (the sampler draws torch.randn per batch,
+    ddim.py:118; eta = 0 leaves no other draw in between), the step allocation and the permutation come from rank 0: the tuple is
+    bit-identical to the one-rank tuple.  eta > 0 keeps the replicated form (per-step noise interleaves with the start noises)."""
     from ldm.models.diffusion.ddim_control import DDIMSampler_control
+    from edadm import dist as edist
+    import torch.distributed as tdist
     uc = None
     if args.scale != 1.0:
         uc = model.get_learned_conditioning({model.cond_stage_key: torch.tensor(calib_num_samples * [1000]).to(model.device)})
@@ -49,30 +58,51 @@ def TDAC_imagenet_calib_data_generator(model, args, calib_num_samples, num_sampl
     sampler = DDIMSampler_control(model)
     unet = model.model.diffusion_model
     hook = AttentionMap(getattr(unet, "model", unet).middle_block[1])
-    samples, cond, uncond, feature_map, ts = [], [], [], None, None
+    nb = int(calib_num_samples / num_samples)
+    rank, world = edist.world()
+    sharded = world > 1 and float(args.ddim_eta) == 0.0 and nb >= world and (world - 1) * ((nb + world - 1) // world) < nb
+    mine = edist.shard_batches(nb) if sharded else list(range(nb))
+    x_T = [torch.randn([num_samples] + shape, device=device) for _ in range(nb)] if sharded else [None] * nb
+    samples, feature_map, ts = {}, None, None
     with torch.no_grad():
-        for i in range(int(calib_num_samples / num_samples)):
+        for i in mine:
             sl = slice(i * num_samples, (i + 1) * num_samples)
             out = sampler.sample(S=args.custom_steps, conditioning=c[sl], batch_size=num_samples, shape=shape,
                                  verbose=False, unconditional_guidance_scale=args.scale,
                                  unconditional_conditioning=None if uc is None else uc[sl], eta=args.ddim_eta,
-                                 hooks=[hook] if i == 0 else None)
+                                 x_T=x_T[i], hooks=[hook] if i == 0 else None)
             intermediates = out[1]
             if i == 0:
                 feature_map = out[2]
-            samples.append(intermediates['x_inter'][:-1])
+            samples[i] = intermediates['x_inter'][:-1]
             ts = intermediates['ts']
-            cond.append(intermediates['cond'][0])
-            if uc is not None:
-                uncond.append(intermediates['uncond'][0])
     hook.remove()
-    all_samples = [torch.cat([s[k] for s in samples]) for k in range(num_timesteps)]
-    _, _, _, t_num = tdac_allocate(feature_map, args.lamda, calib_num_samples, 3.0)
-    t = shuffled_step_list(t_num, device)
+    cond = c[:nb * num_samples]                       # intermediates['cond'][0] of batch i is c[sl] (ddim.py:151-154)
+    uncond = uc[:nb * num_samples] if uc is not None else None
+    if sharded:
+        # rank 0 owns trajectory batch 0, whose mid-block features score the steps: allocation + permutation travel from there
+        t = torch.empty(nb * num_samples, dtype=torch.long, device=device)
+        if rank == 0:
+            _, _, _, t_num = tdac_allocate(feature_map, args.lamda, calib_num_samples, 3.0)
+            t.copy_(shuffled_step_list(t_num, device))
+        else:
+            torch.randperm(nb * num_samples)          # the draw rank 0 makes in shuffled_step_list: the generators stay in step
+        if tdist.get_backend() == "gloo" and t.is_cuda:
+            h = t.cpu()
+            tdist.broadcast(h, src=0)
+            t.copy_(h)
+        else:
+            tdist.broadcast(t, src=0)
+        local = {i: pick_by_step(samples[i], t[i * num_samples:(i + 1) * num_samples]) for i in mine}
+        calib_data = edist.gather_rows(local, nb)
+    else:
+        all_samples = [torch.cat([samples[i][k] for i in range(nb)]) for k in range(num_timesteps)]
+        _, _, _, t_num = tdac_allocate(feature_map, args.lamda, calib_num_samples, 3.0)
+        t = shuffled_step_list(t_num, device)
+        calib_data = pick_by_step(all_samples, t)
     index = (num_timesteps - 1) - t
-    calib_data = pick_by_step(all_samples, t)
     calib_t = torch.stack([ts[int(s)][0] for s in t]).to(device)
-    return calib_data, calib_t, index, torch.cat(cond), (torch.cat(uncond) if uncond else None)
+    return calib_data, calib_t, index, cond, uncond
 
 
 def _tdac_unconditional_ldm(model, args, calib_num_samples, num_samples, device, num_timesteps, fixup_ge):

@@ -114,3 +114,84 @@ def test_gather_refuses_a_rank_without_batches_before_any_collective():
     assert ed.shard_batches(5, 0, 4) == [0, 1] and ed.shard_batches(5, 2, 4) == [4] and ed.shard_batches(5, 3, 4) == []
     assert ed.shard_batches(8, 3, 4) == [6, 7]
     assert ed.shard_round_robin(5, 1, 2) == [1, 3]
+
+
+# ---- TDAC trajectory sharding (scripts/calibration.py:371-499 -> eda-dm_amd/scripts/calibration.py) with a stand-in sampler ----
+class _FakeSampler:
+    """DDIMSampler_control's interface on plain torch: S deterministic steps from the start noise, hooked features for batch 0."""
+
+    def __init__(self, model):
+        self.model = model
+
+    def sample(self, S, conditioning, batch_size, shape, verbose, unconditional_guidance_scale, unconditional_conditioning, eta, x_T,
+               hooks):
+        x = torch.randn([batch_size] + list(shape)) if x_T is None else x_T
+        inter = {"x_inter": [x], "ts": [], "cond": [conditioning], "uncond": [unconditional_conditioning]}
+        feats = []
+        for k in range(S):
+            x = 0.9 * x + 0.01 * conditioning.reshape(batch_size, -1).mean(1).view(-1, 1, 1, 1) + 0.1 * torch.sin(x * (k + 1))
+            inter["x_inter"].append(x)
+            inter["ts"].append(torch.full((batch_size,), (S - 1 - k) * 50 + 1))
+            if hooks is not None:
+                feats.append(torch.cat([x[:, :, :2, :2] * (1.0 + k * k), 2.0 * k + torch.cos(x[:, :, :2, :2] * (k + 1))], 1))
+        return (x, inter, feats) if feats else (x, inter)
+
+
+class _FakeLD:
+    cond_stage_key = "class_label"
+    device = torch.device("cpu")
+
+    def __init__(self):
+        class _U(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.middle_block = torch.nn.ModuleList([torch.nn.Identity(), torch.nn.Identity()])
+        self.model = type("M", (), {})()
+        self.model.diffusion_model = _U()
+        g = torch.Generator().manual_seed(3)
+        self.table = torch.randn(1001, 1, 6, generator=g)
+
+    def get_learned_conditioning(self, d):
+        return self.table[d["class_label"].long().cpu()]
+
+
+def _tdac_tuple():
+    import sys
+    from types import SimpleNamespace
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "eda-dm_amd"))
+    import ldm.models.diffusion.ddim_control as dc
+    from scripts.calibration import TDAC_imagenet_calib_data_generator
+    dc.DDIMSampler_control = _FakeSampler
+    torch.manual_seed(77)
+    N, nb = 48, 8
+    args = SimpleNamespace(scale=3.0, data=torch.randint(0, 1000, (N,), generator=torch.Generator().manual_seed(5)), custom_steps=6,
+                           ddim_eta=0.0, lamda=1.2, latent_shape=[3, 4, 4])
+    out = TDAC_imagenet_calib_data_generator(_FakeLD(), args, N, nb, torch.device("cpu"), 6)
+    return [o.clone() for o in out], torch.rand(1)          # + the next CPU draw: the generators of all ranks stay in step
+
+
+def _tdac_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tup, nxt = _tdac_tuple()
+        ret[rank] = ([t.numpy() for t in tup], float(nxt))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tdac_trajectories_shard_by_sample_bit_identical_to_one_rank():
+    """VERDICT r3 item 5 / SURVEY 8e: with two ranks each runs half of the trajectory batches (6 batches of 8: ranks own [0, 1, 2] and
+    [3, 4, 5]), rank 0 allocates the steps and draws the permutation, one gather per tensor completes the calibration set:
+    (calib_x, t, index, cond, uncond) equals the one-rank tuple bit for bit on both ranks, and the ranks' generators end in step."""
+    alone, nxt = _tdac_tuple()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_tdac_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    for r in (0, 1):
+        got, n = ret[r]
+        assert len(got) == 5
+        for a, b in zip(got, alone):
+            assert a.shape == tuple(b.shape) and (a == b.numpy()).all()
+        assert n == float(nxt)

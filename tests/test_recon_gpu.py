@@ -128,6 +128,7 @@ def test_scale_init_cache_and_reconstruction(golden):
         if isinstance(m, AdaRoundQuantizer):
             ref = g["g8/final/alpha/" + name]
             agree = np.mean((m.alpha.detach().cpu().numpy() >= 0) == (ref >= 0))
+            print("G8 final hard rounding", name, "agree %.5f (%d of %d differ)" % (agree, int(round((1 - agree) * ref.size)), ref.size))
             assert agree > 0.995, (name, agree)
             assert m.soft_targets is False
     qnn.set_quant_state(True, True)

@@ -147,7 +147,8 @@ def test_recon_loop_index_space_reference_scales_caches_masks(golden, fixture):
     # Agreement except weights whose alpha ENDS within a fifth of one Adam step (lr_w = 5e-2) of zero in BOTH runs -- the
     # CPU oracle against the reference leaves 0 (masks) / 4 (prob 1) of these 26 816, the GPU 2 / 15 (measured, round 3): a
     # handful of alphas that twelve +-lr steps park next to the rounding boundary, decided by the last bits of a gradient
-    assert all(abs(r) < 1e-2 and abs(o) < 1e-2 for _, _, r, o in bad) and len(bad) <= 27, bad
+    # gate: 2x the measurement (round 4: 15 at prob 1, 2 with the shipped masks)
+    assert all(abs(r) < 1e-2 and abs(o) < 1e-2 for _, _, r, o in bad) and len(bad) <= (30 if fixture == "g8c_recon_caches" else 4), bad
 
 
 @pytest.mark.parametrize("fixture,unit", [("g8c_recon_caches", "rb"), ("g8c_recon_caches", "at"), ("g8b_recon_masks", "rb"),
@@ -352,8 +353,10 @@ def test_church_config3_unconditional_walk_with_shipped_masks(golden):
     print("final hard rounding: %d of %d agree (%.4f %%); on the reference's caches: %d disagreements %s" % (
         agree, total, 100.0 * agree / total, len(bad), bad[:8]))
     assert total == sum(g[k].size for k in g.files if k.startswith("final/alpha/"))
-    assert agree / total > 0.99
-    assert all(abs(r) < 1e-2 and abs(o) < 1e-2 for _, r, o in bad) and len(bad) <= 60, bad
+    # measured (round 4): 99.808 % over the whole walk (units after the first run on the product's OWN quantised prefix, which carries
+    # the near-zero alphas of the units before), 1 disagreement on the units fed the reference's caches; gates at 2x
+    assert agree / total > 0.996
+    assert all(abs(r) < 1e-2 and abs(o) < 1e-2 for _, r, o in bad) and len(bad) <= 2, bad
     assert qnn.block_count == int(g["block_count"])
     qnn.set_quant_state(True, True)
     with torch.no_grad():

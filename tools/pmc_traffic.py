@@ -35,5 +35,10 @@ out = {
     "per_kernel": {k: {"launches": v[0], "fetch_KB": v[1], "write_KB": write.get(k, [0, 0.0])[1]}
                    for k, v in sorted(fetch.items(), key=lambda kv: -kv[1][1])[:24]},
 }
+# the sources these bytes belong to: bench.py drops the file (roofline.traffic = null) when csrc/gemm.hip has changed since
+import hashlib
+_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+with open(os.path.join(_root, "eda-dm_amd", "csrc", "gemm.hip"), "rb") as _fh:
+    out["gemm_hip_sha256"] = hashlib.sha256(_fh.read()).hexdigest()
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps({k: out[k] for k in ("launches", "hbm_bytes_per_launch", "fetch_bytes_per_launch_corrected", "write_bytes_per_launch")}))
