@@ -328,6 +328,7 @@ def main():
                          "the sampling throughput is; bounded (N = 1): a 256-sample x 40-iteration reconstruction walk extrapolated linearly "
                          "(~1 min); none")
     ap.add_argument("--no-calib", action="store_true", help="= --calib none")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` key (one UNet call of configs 2, 3, 5 at full size, ~1 min)")
     ap.add_argument("--calib-ranks", action="store_true",
                     help="with --gpus N > 1: also time a bounded reconstruction walk with the activation caching sharded over the "
                          "ranks (all_gather_into_tensor of the cached slabs + broadcast of the learned parameters per unit)")
@@ -551,6 +552,32 @@ def main():
             except Exception as e:      # the baseline is a report, never a reason to lose the bench line
                 line["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": torch.get_num_threads(),
                                         "kind": "port", "sample": "failed: %r" % (e,)}
+    # ---- configs 2, 3, 5 at full size, timed by THIS run (tools/config_bench.py::quick_call_numbers): one UNet call each at the shipped
+    # rows per call on the frozen int8 executor
+    if rank == 0 and world == 1 and not args.no_configs:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        cfgs = {}
+        try:
+            import config_bench as cb
+            loop = eng = dec = prof = i8 = None                # the headline's engine, graphs and decoder leave HBM first
+            qnn.engine = None
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            for kind, label in (("cifar", "2: CIFAR-10 DDIM 32x32 W4A8, 500 rows per call"), ("church", "3: LSUN-Church LDM-8 256x256 W4A8, 100 rows per call"),
+                                ("sd", "5: Stable Diffusion v1-4 512x512 W4A8, 4 prompts x CFG = 8 rows per call")):
+                t0c = time.time()
+                try:
+                    r = cb.quick_call_numbers(kind, dev)
+                except Exception as e:
+                    r = {"error": repr(e)}
+                r["config"], r["wall_s"] = label, time.time() - t0c
+                cfgs[kind] = r
+                gc.collect()
+                torch.cuda.empty_cache()
+        except Exception as e:
+            cfgs["error"] = repr(e)
+        line["configs"] = cfgs
     # ---- the calibration job.  N = 1: bounded or full.  N > 1 with --calib full: EVERY rank runs the job -- TDAC trajectory batches and
     # the activation caching are sharded (one all_gather_into_tensor per tensor / cached slab), scale initialisation and the
     # reconstruction loops run replicated with rank 0's learned parameters broadcast after each unit -- and the wall-clock is the

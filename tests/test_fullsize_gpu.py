@@ -292,3 +292,41 @@ def test_recon_unit_f16x3_vs_exact_fp32_vs_reference(golden, name):
     # the three-product contraction must not be a worse citizen than the exact-fp32 one
     assert len(bad[True]) <= 1.25 * len(bad[False]) + 8, (len(bad[True]), len(bad[False]))
     assert runs[True]["first_bad"] <= 1.25 * runs[False]["first_bad"] + 8
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# configs 2, 3, 5 at full size: the three checks of the LDM-4 test above
+# ---------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind,rows", [("cifar", 64), ("church", 16), ("sd", 4)])
+def test_other_configs_engine_matches_fake_quant_graph_at_full_size(kind, rows):
+    """BASELINE configs 2 (CIFAR-10 DDPM UNet, configs/cifar10.yml:12-24: ch 128, mult 1-2-2-2, 35.7 M parameters), 3 (LSUN-Church
+    LDM-8, models/ldm/lsun_churches256/config.yaml:32-53: ch 192, mult 1-2-2-4-4, legacy 8-head attention at every level, 295 M) and 5
+    (Stable Diffusion v1-4, configs/stable-diffusion/v1-inference.yaml: ch 320, mult 1-2-4-4, 8 heads, 77 x 768 context, 860 M) at
+    FULL size, random-init weights, W4A8 scales from the build's own quick initialisation (tools/config_bench.py::build): the frozen
+    int8 engine against the fake-quant module graph (the calibration-time forward pinned to the reference on the fixture nets), replay
+    bit-identity, row independence."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import config_bench as cb
+    dev = torch.device("cuda", 0)
+    with torch.no_grad():
+        qnn, inputs, _, _ = cb.build(kind, dev)
+        x, t, c = inputs(rows)
+        qnn.set_quant_state(True, True)
+        fq = qnn(x, t, c).float()
+        eng = qnn.freeze()
+        out = qnn(x, t, c).float()
+        assert qnn.engine is not None
+        modes = cb._modes(eng)
+        rng = float(fq.abs().max())
+        err = (out - fq).abs()
+        print("full-size %s, %d rows: engine vs fake-quant graph max err %.3e of range, mean %.3e of range; layer modes %s"
+              % (kind, rows, float(err.max()) / rng, float(err.mean()) / rng, modes))
+        assert modes.get("i8", 0) >= 50
+        assert torch.isfinite(out).all()
+        # same bound as the headline network: an activation within ~1e-6 of a rounding boundary flips one code, and 100+ quantised
+        # layers deep the flips accumulate
+        assert float(err.max()) <= 0.10 * rng and float(err.mean()) <= 0.01 * rng
+        assert torch.equal(qnn(x, t, c).float(), out)                                   # replay: bit-identical
+        perm = torch.arange(rows - 1, -1, -1, device=dev)                               # row independence
+        out_p = qnn(x[perm], t[perm], None if c is None else c[perm]).float()
+        assert float((out_p[perm] - out).abs().max()) == 0.0

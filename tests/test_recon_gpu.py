@@ -129,7 +129,8 @@ def test_scale_init_cache_and_reconstruction(golden):
             ref = g["g8/final/alpha/" + name]
             agree = np.mean((m.alpha.detach().cpu().numpy() >= 0) == (ref >= 0))
             print("G8 final hard rounding", name, "agree %.5f (%d of %d differ)" % (agree, int(round((1 - agree) * ref.size)), ref.size))
-            assert agree > 0.995, (name, agree)
+            # measured (round 4): 10 of 9216 at worst (rb.conv1); gate at 2x
+            assert int(round((1 - agree) * ref.size)) <= max(2, int(0.0022 * ref.size)), (name, agree)
             assert m.soft_targets is False
     qnn.set_quant_state(True, True)
     with torch.no_grad():

@@ -100,6 +100,97 @@ def _modes(eng):
     return out
 
 
+def _ldm(kw, dev, seed):
+    from edadm.nets.ldm_unet import UNetModel
+    from qdiff.utils import seed_everything
+    seed_everything(seed)
+    m = UNetModel(**kw)
+    _reinit_zero(m, seed)
+    return m.to(dev).eval()
+
+
+def cifar_model(dev):
+    """configs/cifar10.yml:12-24 of the reference: DDPM UNet ch 128, mult 1-2-2-2, attention at 16 x 16"""
+    from edadm.nets.ddpm_unet import Model
+    from qdiff.utils import seed_everything
+    seed_everything(1234)
+    cfg = SimpleNamespace(model=SimpleNamespace(type="simple", in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 2, 2], num_res_blocks=2,
+                                                attn_resolutions=[16], dropout=0.1, resamp_with_conv=True),
+                          data=SimpleNamespace(image_size=32), diffusion=SimpleNamespace(num_diffusion_timesteps=1000))
+    return Model(cfg).to(dev).eval()
+
+
+CIFAR_SEQ = [int(s) for s in (np.linspace(0, np.sqrt(1000 * 0.8), 100) ** 2)]
+
+
+def build(kind, dev):
+    """(qnn with quick W4A8 scales, make_inputs(rows) -> (x, t, context or None), shipped rows per UNet call) for configs 2, 3, 5 at
+    full size: random-init weights of the reference's architecture, scales from the build's own initialisation on a few synthetic rows."""
+    if kind == "cifar":
+        model = cifar_model(dev)
+        g = torch.Generator().manual_seed(1)
+        rows = 32
+        cali = (torch.randn(rows, 3, 32, 32, generator=g).to(dev), torch.tensor(np.random.RandomState(0).choice(CIFAR_SEQ, rows)).float().to(dev))
+        qnn, t_init = _quantise(model, dev, cali, "cifar", rows)
+
+        def inputs(n, seed=5):
+            gg = torch.Generator().manual_seed(seed)
+            return (torch.randn(n, 3, 32, 32, generator=gg).to(dev),
+                    torch.tensor(np.random.RandomState(seed).choice(CIFAR_SEQ, n)).float().to(dev), None)
+        return qnn, inputs, 500, t_init
+    if kind == "church":
+        model = _ldm(CHURCH, dev, 1235)
+        g = torch.Generator().manual_seed(2)
+        rows = 16
+        ts = np.arange(0, 1000, 2) + 1
+        cali = (torch.randn(rows, 4, 32, 32, generator=g).to(dev),
+                torch.tensor(ts[np.random.RandomState(0).randint(0, 500, rows)], dtype=torch.long, device=dev))
+        qnn, t_init = _quantise(model, dev, cali, "church", rows)
+
+        def inputs(n, seed=5):
+            gg = torch.Generator().manual_seed(seed)
+            return (torch.randn(n, 4, 32, 32, generator=gg).to(dev),
+                    torch.tensor(ts[np.random.RandomState(seed).randint(0, 500, n)], dtype=torch.long, device=dev), None)
+        return qnn, inputs, 100, t_init
+    model = _ldm(SD, dev, 1236)
+    g = torch.Generator().manual_seed(3)
+    rows = 4
+    ts = np.arange(0, 1000, 20) + 1
+    cali = (torch.randn(rows, 4, 64, 64, generator=g).to(dev),
+            torch.tensor(ts[np.random.RandomState(0).randint(0, 50, rows)], dtype=torch.long, device=dev),
+            torch.randn(rows, 77, 768, generator=g).to(dev))
+    qnn, t_init = _quantise(model, dev, cali, "sd", rows)
+
+    def inputs(n, seed=5):
+        gg = torch.Generator().manual_seed(seed)
+        return (torch.randn(n, 4, 64, 64, generator=gg).to(dev),
+                torch.tensor(ts[np.random.RandomState(seed).randint(0, 50, n)], dtype=torch.long, device=dev),
+                torch.randn(n, 77, 768, generator=gg).to(dev))
+    return qnn, inputs, 8, t_init
+
+
+def quick_call_numbers(kind, dev):
+    """bench.py's `configs` key: one UNet call of config `kind` at its shipped rows per call on the frozen int8 executor -- the eager
+    call between HIP events (3 calls after a warm-up) and the int8 GEMM group's share of the dense int8 MFMA peak (cold-cache timing
+    as in bench.py is not repeated here: warm replay, 3x per launch)."""
+    with torch.no_grad():
+        qnn, inputs, rows, t_init = build(kind, dev)
+        eng = qnn.freeze()
+        x, t, c = inputs(rows)
+        eng(x, t, c)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            eng(x, t, c)
+        e1.record()
+        torch.cuda.synchronize()
+        grp = _gemm_group(eng, lambda: eng(x, t, c))
+    return {"rows_per_call": rows, "unet_call_ms_eager": e0.elapsed_time(e1) / 3, "scale_init_s": t_init, "layer_modes": _modes(eng),
+            "int8_gemm_ms": grp["int8_gemm_ms"], "int8_gemm_calls": grp["int8_gemm_calls"],
+            "frac_of_int8_mfma_peak": grp["frac_of_int8_mfma_peak"]}
+
+
 def run_cifar(dev, a):
     from edadm.nets.ddpm_unet import Model
     from edadm.sampling import GraphedUNet
@@ -147,15 +238,6 @@ def run_cifar(dev, a):
     return {"config": "2: CIFAR-10 DDIM 32x32 W4A8, batch %d x %d quad-skip steps" % (B, len(steps)), "images_per_sec": B / (per_step * 100),
             "unet_call_ms": 1e3 * per_step, "steps_run": len(steps), "batch": B, "scale_init_s": t_init, "layer_modes": _modes(eng),
             "gemm_group": grp, "algorithmic_tflops": B * 12.5e9 / per_step / 1e12}
-
-
-def _ldm(kw, dev, seed):
-    from edadm.nets.ldm_unet import UNetModel
-    from qdiff.utils import seed_everything
-    seed_everything(seed)
-    m = UNetModel(**kw)
-    _reinit_zero(m, seed)
-    return m.to(dev).eval()
 
 
 def run_church(dev, a):
