@@ -808,11 +808,184 @@ k_attn_wide16(const __half* __restrict__ Q, int64_t ldq, int64_t sQ, int64_t hQ,
     }
 }
 
+// ---- K6s: one wide head over FEW keys (LDM-4's 16 x 16 level: d = 576, 256 keys; 8 x 8: d = 960, 64 keys).  All scores of a
+// query fit a lane's registers (Nk / 4 values: a lane holds keys 4 g + r of every 16-key tile), so the keys are walked ONCE:
+// S tiles kept, row maximum / sum / probability codes in registers, then V walked once -- no recomputation, one launch instead of
+// three.  Same 16-query waves, operand layouts, staging and arithmetic as k_attn_wide16; four waves (64 queries) per workgroup so
+// that the small levels still give every CU work (400 workgroups at 16 x 16, 100 at 8 x 8).  When the O^T accumulator of the whole
+// head does not fit beside the codes (d = 960: 240 registers), the output dimensions are processed in DH passes over V.
+template <int KD32, int NT /* 16-key tiles */, int DH>
+__global__ void __launch_bounds__(256)
+k_attn_small(const __half* __restrict__ Q, int64_t ldq, int64_t sQ, int64_t hQ, const __half* __restrict__ K, int64_t ldk,
+             int64_t sK, int64_t hK, const __half* __restrict__ V, int64_t ldv, int64_t sV, int64_t hV, void* __restrict__ out,
+             int64_t ldo, int64_t sO, int Nq, int Nk, float alpha_qk, const QP* __restrict__ pqp, float alpha_pv, int out_mode,
+             const QP* __restrict__ oqp) {
+    const QP pw = qp_load(pqp, 0);
+    constexpr int D = KD32 * 32, ROW = D + 16;
+    constexpr int DB = D / 16 / DH;                                // 16-dimension blocks per pass
+    static_assert(D % 64 == 0 && (D / 16) % DH == 0 && NT % 2 == 0, "shape");
+    __shared__ __half lb_[2][ATTW_BK * ROW];                        // K blocks, then V blocks
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fc = lane & 15, fg = lane >> 4;
+    const int h = blockIdx.y;
+    const int64_t b = blockIdx.z;
+    const int q = blockIdx.x * 64 + wave * 16 + fc;
+    const __half* Qb = Q + b * sQ + (int64_t)h * hQ;
+    const __half* Kb = K + b * sK + (int64_t)h * hK;
+    const __half* Vb = V + b * sV + (int64_t)h * hV;
+    constexpr int NB = NT / 2;                                     // 32-key blocks (the launcher guarantees Nk == 16 NT)
+    constexpr int CPR = D / 64;                                    // staging: thread -> key r0 = tid / 8, 16-byte chunks c0 + 8 c of its row
+    const int r0 = tid >> 3, c0 = tid & 7;
+    // two staging register sets: blocks kb + 1 and kb + 2 are on their way from L2 while block kb computes (an iteration is a few
+    // hundred cycles of MFMA: with one block in flight every iteration waited out the whole load latency)
+    half8 rs[2][CPR];
+    auto gload = [&](const __half* base, int64_t ld, int kb) {
+        const __half* p = base + ((int64_t)kb * ATTW_BK + r0) * ld + c0 * 8;
+#pragma unroll
+        for (int c = 0; c < CPR; ++c) rs[kb & 1][c] = *reinterpret_cast<const half8*>(p + c * 64);
+    };
+    auto lstore = [&](int kb) {
+#pragma unroll
+        for (int c = 0; c < CPR; ++c) *reinterpret_cast<half8*>(lb_[kb & 1] + r0 * ROW + c0 * 8 + c * 64) = rs[kb & 1][c];
+    };
+    float4v s[NT];
+    {
+        half8 qf[KD32];
+#pragma unroll
+        for (int ks = 0; ks < KD32; ++ks) {
+            half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (q < Nq) z = *reinterpret_cast<const half8*>(Qb + (int64_t)q * ldq + ks * 32 + fg * 8);
+            qf[ks] = z;
+        }
+        gload(Kb, ldk, 0);
+        if (NB > 1) gload(Kb, ldk, 1);
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+            lstore(kb);
+            __syncthreads();
+            if (kb + 2 < NB) gload(Kb, ldk, kb + 2);
+            const __half* base = lb_[kb & 1] + fc * ROW + fg * 8;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float4v c = {0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < KD32; ++ks) {
+                    const half8 a = *reinterpret_cast<const half8*>(base + t * 16 * ROW + ks * 32);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[ks], c, 0, 0, 0);
+                }
+                s[2 * kb + t] = c;
+            }
+        }
+    }
+    // ---- softmax in registers: the four lanes of a query (4 keys of every 16 each) combine their maxima and sums
+    const float cexp = alpha_qk * 1.44269504088896340736f;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[t][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float cmax = mx * cexp;
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            s[t][r] = __builtin_amdgcn_exp2f(fmaf(s[t][r], cexp, -cmax));
+            sum += s[t][r];
+        }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / (sum * pw.d);
+    const bool z0 = pw.z == 0.f;
+    half8 pf[NB];                                                  // block kb: keys {4g .. 4g+3} of tile 2 kb, then of tile 2 kb + 1
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+        float r_[8];
+        float worst = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float t = s[2 * kb + (i >> 2)][i & 3] * inv;
+            r_[i] = rintf(t);
+            worst = fmaxf(worst, fabsf(t - r_[i]));
+        }
+        if (__builtin_expect(worst > 0.499f, 0)) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                asm volatile("" : "+v"(r_[i]));
+                r_[i] = rintf((s[2 * kb + (i >> 2)][i & 3] / sum) / pw.d);
+            }
+        }
+        if (z0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pf[kb][i] = (_Float16)fminf(r_[i], pw.qmax);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pf[kb][i] = (_Float16)(fminf(fmaxf(r_[i] + pw.z, 0.f), pw.qmax) - pw.z);
+        }
+    }
+    // ---- O^T = V^T P^T, DH passes over V of D / DH output dimensions each
+    const int tr_off = (4 * fg + ((lane & 15) >> 2)) * ROW + 4 * (lane & 3);
+    QP oq;
+    if (out_mode == 2) oq = qp_load(oqp, 0);
+#pragma unroll 1
+    for (int dh = 0; dh < DH; ++dh) {
+        float4v o[DB];
+#pragma unroll
+        for (int j = 0; j < DB; ++j) o[j] = float4v{0, 0, 0, 0};
+        __syncthreads();                                           // every wave is done with the buffers of the previous phase
+        gload(Vb, ldv, 0);
+        if (NB > 1) gload(Vb, ldv, 1);
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+            lstore(kb);
+            __syncthreads();
+            if (kb + 2 < NB) gload(Vb, ldv, kb + 2);
+            const __half* vp = lb_[kb & 1] + tr_off + dh * DB * 16;
+#pragma unroll
+            for (int j = 0; j < DB; ++j) {
+                const half4 va = __builtin_bit_cast(half4, __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                    (__attribute__((address_space(3))) fp16x4*)(vp + j * 16)));
+                const half4 vb = __builtin_bit_cast(half4, __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                    (__attribute__((address_space(3))) fp16x4*)(vp + j * 16 + 16 * ROW)));
+                const half8 a = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+                o[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pf[kb], o[j], 0, 0, 0);
+            }
+        }
+        if (q < Nq) {
+#pragma unroll
+            for (int j = 0; j < DB; ++j) {
+                const int dv = (dh * DB + j) * 16 + 4 * fg;
+                float v4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v4[e] = o[j][e] * alpha_pv;
+                const int64_t col = (int64_t)h * D + dv;
+                if (out_mode == 0) {
+                    float* op = reinterpret_cast<float*>(out) + b * sO + (int64_t)q * ldo + col;
+                    *reinterpret_cast<float4*>(op) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+                } else {
+                    int8_t* op = reinterpret_cast<int8_t*>(out) + b * sO + (int64_t)q * ldo + col;
+                    uint32_t pk = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float c = fminf(fmaxf(rint_div(v4[e], oq.d, oq.inv) + oq.z, 0.f), oq.qmax);
+                        pk |= (uint32_t)(uint8_t)(int8_t)((int)c - 128) << (8 * e);
+                    }
+                    *reinterpret_cast<uint32_t*>(op) = pk;
+                }
+            }
+        }
+    }
+}
+// shapes of the few-key kernel
+static bool attn_small_shape(int64_t d, int64_t Nq, int64_t Nk) { return (d == 576 && Nk == 256) || (d == 960 && Nk == 64); }
+
 // shapes of the wide-head kernel: one instantiation per head dimension
 static bool attn_wide_shape(int64_t d, int64_t Nq, int64_t Nk) { return d == 384 && Nk >= 64 && Nk % (2 * ATTW_BK) == 0 && Nq >= 1; }
 
 extern "C" int edadm_attention_fused_ok(int64_t heads, int64_t d, int64_t Nq, int64_t Nk) {
-    return heads >= 1 && Nq >= 1 && ((d >= 8 && d <= 160 && (d & 7) == 0 && Nk >= 2) || attn_wide_shape(d, Nq, Nk));
+    return heads >= 1 && Nq >= 1 && ((d >= 8 && d <= 160 && (d & 7) == 0 && Nk >= 2) || attn_wide_shape(d, Nq, Nk) || attn_small_shape(d, Nq, Nk));
 }
 
 extern "C" int edadm_attention_fused_f16(const void* Q, int64_t ldq, int64_t strideQ, int64_t headQ, const void* K, int64_t ldk,
@@ -831,6 +1004,17 @@ extern "C" int edadm_attention_fused_f16(const void* Q, int64_t ldq, int64_t str
     if (!(alpha_qk > 0.f)) return EDADM_EINVAL;
     const QP* pq = reinterpret_cast<const QP*>(pqp);
     hipStream_t st = (hipStream_t)stream;
+    if (attn_small_shape(d, Nq, Nk)) {
+        const dim3 grid((unsigned)((Nq + 63) / 64), (unsigned)heads, (unsigned)B);
+#define ATTS_LAUNCH(KD32_, NT_, DH_)                                                                                               \
+        hipLaunchKernelGGL((k_attn_small<KD32_, NT_, DH_>), grid, dim3(256), 0, st, (const __half*)Q, ldq, strideQ, headQ, (const __half*)K, \
+                           ldk, strideK, headK, (const __half*)V, ldv, strideV, headV, out, ldo, strideO, (int)Nq, (int)Nk, alpha_qk, pq,   \
+                           alpha_pv, out_mode, reinterpret_cast<const QP*>(oqp))
+        if (d == 576) ATTS_LAUNCH(18, 16, 1);
+        else ATTS_LAUNCH(30, 4, 2);
+#undef ATTS_LAUNCH
+        return edadm_launch_status();
+    }
     if (attn_wide_shape(d, Nq, Nk)) {
         static const int64_t form = EDADM_TUNE_I("EDADM_ATTN_WIDE_FORM", 16);
         if (form == 16) {

@@ -491,7 +491,8 @@ def test_deferred_device_status_and_rejected_misaligned_pair_output():
 
 @pytest.mark.parametrize("B,heads,d,Nq,Nk", [(2, 8, 8, 16, 16), (2, 8, 8, 16, 77), (2, 2, 16, 16, 7), (2, 8, 40, 200, 77), (2, 8, 24, 96, 96),
                                              (1, 8, 40, 1024, 1024), (2, 8, 80, 256, 256), (1, 4, 160, 64, 64), (2, 1, 32, 130, 130),
-                                             (1, 1, 384, 1024, 1024), (2, 1, 384, 256, 256), (3, 2, 384, 200, 64)])
+                                             (1, 1, 384, 1024, 1024), (2, 1, 384, 256, 256), (3, 2, 384, 200, 64),
+                                             (1, 1, 576, 256, 256), (3, 1, 576, 200, 256), (1, 1, 960, 64, 64), (2, 2, 960, 100, 64)])
 def test_fused_attention_against_torch_on_the_same_codes(B, heads, d, Nq, Nk):
     """K6f (csrc/attn.hip, edadm_attention_fused_f16): quantise -> Q K^T -> softmax -> 8-bit probability codes -> P V in one kernel,
     no score matrix in memory (quant_block.py:204-235 / :119-162 / :398-451), against torch on the same integer codes.  The
