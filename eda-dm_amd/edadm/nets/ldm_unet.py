@@ -107,12 +107,20 @@ def Normalize(in_channels):
     return _GroupNorm(num_groups=32, num_channels=in_channels, eps=1e-6, affine=True)
 
 
+_FREQS = {}
+
+
 def timestep_embedding(timesteps, dim, max_period=10000, repeat_only=False):
-    """cos | sin sinusoidal table (util.py:151-171)."""
+    """cos | sin sinusoidal table (util.py:151-171).  The frequency vector is evaluated on the host exactly as the reference does
+    (torch.exp on CPU, then moved) but ONCE per (dim, period, device): a host-to-device copy per forward is what kept the FP
+    forward out of a HIP graph (scripts/calibration.py: the TDAC trajectories replay one)."""
     if repeat_only:
         return timesteps[:, None].repeat(1, dim)
     half = dim // 2
-    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half).to(timesteps.device)
+    key = (half, max_period, str(timesteps.device))
+    if key not in _FREQS:
+        _FREQS[key] = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half).to(timesteps.device)
+    freqs = _FREQS[key]
     args = timesteps[:, None].float() * freqs[None]
     emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
     if dim % 2:
