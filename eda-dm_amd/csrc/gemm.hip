@@ -2140,6 +2140,132 @@ extern "C" int edadm_qconv3_f16x3_direct(const void* A, const void* Wdc, int64_t
 #endif
 
 #if EDADM_GEMM_DT == 0
+// ---- K4s: a dense layer with SPLIT quantisers (the 1x1 skip convolution of an up-path ResBlock over [h | skip],
+// quant_layer.py:415-427: two activation quantisers and two weight quantisers over the channel ranges, one convolution) in ONE
+// launch.  As two launches of the plain kernel the second accumulates through the residual port: the fp32 output is written,
+// read back and written again (3x its size of traffic; 409600 x 192 fp32 = 315 MB: 188 us per layer against a 75 us HBM roof).
+// Here a workgroup walks the K range of segment 1 into one set of accumulators and the K range of segment 2 into a second set
+// (the LDS-DMA ring runs on across the boundary) and the epilogue forms fl(fl(s2 acc2) + fl(s1 acc1 + bias)) -- exactly what the
+// two launches computed, bit for bit.  128 x 192 tile, 4 waves of 64 x 96, 192 accumulator registers: one workgroup per CU.
+template <int TN>
+__global__ void __launch_bounds__(256)
+k_gemm_split2(const uint8_t* __restrict__ A1, const uint8_t* __restrict__ A2, int64_t lda_b, const uint8_t* __restrict__ W1,
+              int64_t ldw1_b, int64_t K1b, const uint8_t* __restrict__ W2, int64_t ldw2_b, int64_t K2b, int64_t M, int64_t N,
+              const float* __restrict__ scale1, const float* __restrict__ scale2, const float* __restrict__ bias,
+              float* __restrict__ out, int64_t ldo) {
+    constexpr int TM = 2, BM = 128, BN = 64 * TN, NA = 2, NB = TN, LPT = NA + NB, STAGES = 3, TILE = (BM + BN) * 64;
+    __shared__ __attribute__((aligned(16))) uint8_t smem[STAGES * TILE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
+    const int wm = wave >> 1, wn = wave & 1;
+    unsigned bx_, by_;
+    xcd_tile(bx_, by_);
+    const int64_t m0 = (int64_t)by_ * BM, n0 = (int64_t)bx_ * BN;
+    const int sr = tid >> 2;
+    const int sc = (tid & 3) ^ ((tid >> 4) & 3);          // the XOR swizzle of k_gemm_nt, applied to the source chunk
+    const int64_t nk1 = K1b / 64, nk = nk1 + K2b / 64;
+    auto issue_tile = [&](int stage, int64_t kt) {
+        const bool second = kt >= nk1;
+        const int64_t off = (second ? kt - nk1 : kt) * 64 + sc * 16;
+        const uint8_t* a = second ? A2 : A1;
+        const uint8_t* w = second ? W2 : W1;
+        const int64_t ldw = second ? ldw2_b : ldw1_b;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) glds16(a + (m0 + sr + 64 * i) * lda_b + off, lds0 + (uint32_t)(stage * TILE + i * 4096 + wave * 1024));
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            glds16(w + (n0 + sr + 64 * i) * ldw + off, lds0 + (uint32_t)(stage * TILE + BM * 64 + i * 4096 + wave * 1024));
+    };
+    v16i acc1[TM][TN], acc2[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[i][j][r] = acc2[i][j][r] = 0;
+    const int fr = lane & 31, fh = lane >> 5;
+    // per-lane column constants (a lane owns one column per 32-wide block), requested ahead of the first tiles
+    float s1[TN], s2[TN], bb[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int64_t col = n0 + wn * (TN * 32) + j * 32 + fr;
+        s1[j] = scale1[col];
+        s2[j] = scale2[col];
+        bb[j] = bias ? bias[col] : 0.f;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int p = 0; p < STAGES - 1; ++p)
+        if (p < nk) issue_tile(p, p);
+    auto step = [&](int64_t kt, v16i (&acc)[TM][TN]) {
+        const int64_t ahead = nk - 1 - kt < STAGES - 2 ? nk - 1 - kt : STAGES - 2;
+        if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + STAGES - 1 < nk) issue_tile((int)((kt + STAGES - 1) % STAGES), kt + STAGES - 1);
+        const uint8_t* As = smem + (int)(kt % STAGES) * TILE;
+        const uint8_t* Bs = As + BM * 64;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int c = 2 * ks + fh;
+            uint4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int r = wm * (TM * 32) + i * 32 + fr;
+                fa[i] = *reinterpret_cast<const uint4*>(As + (r * 4 + (c ^ ((r >> 2) & 3))) * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int r = wn * (TN * 32) + j * 32 + fr;
+                fb[j] = *reinterpret_cast<const uint4*>(Bs + (r * 4 + (c ^ ((r >> 2) & 3))) * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) mma_step<0>(fa[i], fb[j], acc[i][j]);
+        }
+    };
+    for (int64_t kt = 0; kt < nk1; ++kt) step(kt, acc1);
+    for (int64_t kt = nk1; kt < nk; ++kt) step(kt, acc2);
+    // ---- epilogue: register r of block (i, j) is row 32 i + 8 (r / 4) + 4 fh + r % 4, column 32 j + fr: a store instruction writes two
+    // full 128-byte row segments
+    const int64_t row0 = m0 + wm * (TM * 32), col0 = n0 + wn * (TN * 32);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float* op = out + (row0 + i * 32 + 8 * g + e + 4 * fh) * ldo + col0 + fr;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float t1 = fmaf((float)acc1[i][j][4 * g + e], s1[j], bb[j]);       // launch 1 of the two-launch form
+                    float t2 = (float)acc2[i][j][4 * g + e] * s2[j];                         // launch 2 before its residual add
+                    asm volatile("" : "+v"(t2));                 // a rounded product, not an operand to contract into an FMA with t1
+                    EDADM_NT_STORE(t2 + t1, op + j * 32);
+                }
+            }
+}
+
+extern "C" int edadm_qgemm_i8_split2_ok(int64_t M, int64_t N, int64_t K1, int64_t K2) {
+    return M > 0 && M % 128 == 0 && N > 0 && N % 192 == 0 && K1 > 0 && K2 > 0 && K1 % 64 == 0 && K2 % 64 == 0;
+}
+extern "C" int edadm_qgemm_i8_split2(const int8_t* A, int64_t lda, int64_t split, const int8_t* W1, int64_t ldw1, const int8_t* W2,
+                                     int64_t ldw2, int64_t M, int64_t N, int64_t K1, int64_t K2, const float* scale1,
+                                     const float* scale2, const float* bias, float* out, int64_t ldo, void* stream) {
+    if (!A || !W1 || !W2 || !scale1 || !scale2 || !out || !edadm_qgemm_i8_split2_ok(M, N, K1, K2)) return EDADM_EINVAL;
+    if (split != K1 || (lda & 15) || (ldw1 & 15) || (ldw2 & 15) || lda < K1 + K2 || ldw1 < K1 || ldw2 < K2 || ldo < N) return EDADM_EINVAL;
+    if (((uintptr_t)A & 15) || ((uintptr_t)W1 & 15) || ((uintptr_t)W2 & 15) || ((uintptr_t)out & 3)) return EDADM_EINVAL;
+    const dim3 grid((unsigned)(N / 192), (unsigned)(M / 128), 1);
+    hipLaunchKernelGGL((k_gemm_split2<3>), grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t*)A, (const uint8_t*)A + split, lda,
+                       (const uint8_t*)W1, ldw1, K1, (const uint8_t*)W2, ldw2, K2, M, N, scale1, scale2, bias, out, ldo);
+    return edadm_launch_status();
+}
+#endif
+
+#if EDADM_GEMM_DT == 0
 extern "C" int edadm_device_status(int clear, void* stream) {
     unsigned int w = 0;
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return EDADM_EIO;

@@ -138,6 +138,7 @@ class Engine:
         self.fuse_rowadd_ln = True       # broadcast add + norm3 in one pass
         self.cfg_shared_prefix = True    # a guidance pair evaluates the context-independent prefix once
         self.w4_gemm_max_rows = 2048     # dense 4-bit layers at M <= this read their weights as packed nibbles (K4w); 0: never
+        self.fused_split = True          # split-quantiser skip convolutions as one launch (False: two, the second through the residual port)
         self.fused_attention = True      # K6f for heads of d <= 160 (False: the three-kernel path with the scores in memory;
                                          # the two differ only in the order of the fp32 row sum, i.e. in rare +-1 probability codes)
         # classifier-free guidance evaluates [x, x] with contexts [uncond, cond]: the two halves are identical until the first
@@ -334,6 +335,16 @@ class Engine:
             def run():
                 fn(a, s["w"], M, L.N, s["K"], s["scale"], L.bias, out, geom=geom, rowadd=rowadd, rows_per_batch=rpb,
                    residual=residual)
+        elif (self.fused_split and L.mode == "i8" and len(L.segs) == 2 and rowadd is None and residual is None and a.dim() == 2
+              and a.is_contiguous() and L.segs[0]["lo"] == 0 and L.segs[0]["hi"] == L.segs[1]["lo"] and L.segs[1]["hi"] == a.shape[-1]
+              and ops.qgemm_i8_split2_ok(M, L.N, L.segs[0]["K"], L.segs[1]["K"])
+              and L.segs[0]["K"] == L.segs[0]["hi"] and L.segs[1]["K"] == L.segs[1]["hi"] - L.segs[1]["lo"]):
+            # split quantisers over [h | skip] (quant_layer.py:415-427): both channel ranges in ONE launch, two accumulator sets --
+            # the bits of the two-launch form below without writing the fp32 output three times (K4s, csrc/gemm.hip)
+            s0, s1 = L.segs
+
+            def run():
+                ops.qgemm_i8_split2(a, s0["w"], s1["w"], M, L.N, s0["K"], s1["K"], s0["scale"], s1["scale"], L.bias, out)
         else:
             ctot = a.shape[-1]
 

@@ -492,6 +492,18 @@ def qgemm_i8(A, Wt, M, N, K, scale, bias, out, geom=None, lda=None, ldw=None, ro
     return out
 
 
+def qgemm_i8_split2_ok(M, N, K1, K2):
+    return bool(lib.load().edadm_qgemm_i8_split2_ok(int(M), int(N), int(K1), int(K2)))
+
+
+def qgemm_i8_split2(A, W1, W2, M, N, K1, K2, scale1, scale2, bias, out):
+    """edadm_qgemm_i8_split2: a dense layer with split quantisers in one launch; A [M][K1 + K2] int8 (the two ranges side by side)"""
+    lib.call("edadm_qgemm_i8_split2", ctypes.c_void_p(A.data_ptr()), int(A.stride(0)), int(K1), ctypes.c_void_p(W1.data_ptr()), int(K1),
+             ctypes.c_void_p(W2.data_ptr()), int(K2), int(M), int(N), int(K1), int(K2), _pf(scale1), _pf(scale2), _pf(bias), _pf(out), int(N),
+             _stream())
+    return out
+
+
 def qgemm_w4(A, W4, zp4, M, N, K, scale, bias, out, lda=None, rowadd=None, rows_per_batch=1, residual=None):
     """edadm_qgemm_w4: int8 activations x packed 4-bit weights (nibbles expanded in registers), fp32 out [M][N]"""
     lib.call("edadm_qgemm_w4", ctypes.c_void_p(A.data_ptr()), int(K if lda is None else lda), ctypes.c_void_p(W4.data_ptr()), _pf(zp4),

@@ -240,6 +240,18 @@ int edadm_qgemm_f16(const void* A, int64_t lda, const void* Wt, int64_t ldw, int
                     int64_t K, const int32_t* geom, const float* scale, const float* bias,
                     const float* rowadd, int64_t rows_per_batch, const float* residual, int64_t ldr,
                     float* out, int64_t ldo, void* stream);
+/* A dense layer with SPLIT quantisers in ONE launch -- the 1x1 skip convolution of an up-path ResBlock over the concatenation
+ * [h | skip] (quant_layer.py:415-427: act_quantizer / act_quantizer_0 and weight_quantizer / weight_quantizer_0 over the channel
+ * ranges [0, split) and [split, K1 + K2), one F.conv2d over the concatenated operands; split set by quant_block.py:86-116 /
+ * openaimodel.py:746-783).  A: int8 operand [M][lda], columns [0, K1) quantised by the first activation quantiser, [split = K1, K1 + K2)
+ * by the second; W1 [N][ldw1], W2 [N][ldw2]: integer weights of the two ranges; scale1 / scale2 [N] = delta_x * delta_w per range;
+ * bias [N] (zero-point corrections folded in) or NULL.  out fp32 [M][ldo] = fl(fl(scale2 acc2) + fl(scale1 acc1 + bias)): the bits
+ * of two edadm_qgemm_i8 launches with the second accumulating through the residual port, without writing the fp32 output
+ * three times.  Shapes: edadm_qgemm_i8_split2_ok (M % 128 == 0, N % 192 == 0, K1 % 64 == K2 % 64 == 0). */
+int edadm_qgemm_i8_split2_ok(int64_t M, int64_t N, int64_t K1, int64_t K2);
+int edadm_qgemm_i8_split2(const int8_t* A, int64_t lda, int64_t split, const int8_t* W1, int64_t ldw1, const int8_t* W2, int64_t ldw2,
+                          int64_t M, int64_t N, int64_t K1, int64_t K2, const float* scale1, const float* scale2, const float* bias,
+                          float* out, int64_t ldo, void* stream);
 /* Variants whose epilogue feeds the consuming activation quantizer directly (no fp32 round trip through
  * HBM): out_mode 1 -> f16 operand (code - zp) [M][N]; 2 -> int8 operand (code - 128) [M][N]; 3 (i8 only)
  * -> GEGLU a*gelu(gate) over INTERLEAVED (a_j, gate_j) output columns, then int8 operand [M][N/2]

@@ -242,3 +242,28 @@ def test_direct_conv3_partials_do_not_depend_on_the_tile(ops):
     n = small * H * H
     assert torch.equal(ob[:n], os_)
     assert torch.equal(wb[:n // 64], ws_)
+
+
+@pytest.mark.parametrize("M,N,K1,K2", [(1024, 192, 192, 192), (2048, 384, 576, 384), (640, 960, 960, 960), (4096, 192, 384, 192), (256, 576, 1152, 384)])
+def test_split_quantiser_layer_in_one_launch_bit_identical_to_two(M, N, K1, K2):
+    """K4s (csrc/gemm.hip, edadm_qgemm_i8_split2): the 1x1 skip convolution over [h | skip] with two activation / weight quantisers
+    (quant_layer.py:415-427) as ONE launch with two accumulator sets against the two-launch form whose second launch accumulates
+    through the residual port: the same fp32 bits, with and without a bias."""
+    from edadm import ops
+    g = torch.Generator().manual_seed(M + N + K1 + K2)
+    A = torch.randint(-128, 128, (M, K1 + K2), generator=g, dtype=torch.int8).cuda()
+    W1 = torch.randint(-8, 8, (N, K1), generator=g, dtype=torch.int8).cuda()
+    W2 = torch.randint(-8, 8, (N, K2), generator=g, dtype=torch.int8).cuda()
+    s1, s2 = (torch.rand(N, generator=g) * 1e-3 + 1e-4).cuda(), (torch.rand(N, generator=g) * 2e-3 + 1e-4).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    assert ops.qgemm_i8_split2_ok(M, N, K1, K2)
+    for b in (bias, None):
+        two = torch.empty(M, N, device="cuda")
+        ops.qgemm_i8(A[:, :K1], W1, M, N, K1, s1, b, two, lda=K1 + K2)
+        ops.qgemm_i8(A[:, K1:], W2, M, N, K2, s2, None, two, lda=K1 + K2, residual=two)
+        one = ops.qgemm_i8_split2(A, W1, W2, M, N, K1, K2, s1, s2, b, torch.empty(M, N, device="cuda"))
+        assert torch.equal(one, two), float((one - two).abs().max())
+    # exact integer reference of the first rows
+    ref = (A[:64, :K1].double() @ W1.double().t()) * s1.double() + bias.double() + (A[:64, K1:].double() @ W2.double().t()) * s2.double()
+    one = ops.qgemm_i8_split2(A, W1, W2, M, N, K1, K2, s1, s2, bias, torch.empty(M, N, device="cuda"))
+    assert float((one[:64].double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
