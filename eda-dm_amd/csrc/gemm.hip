@@ -2146,14 +2146,15 @@ extern "C" int edadm_qconv3_f16x3_direct(const void* A, const void* Wdc, int64_t
 // read back and written again (3x its size of traffic; 409600 x 192 fp32 = 315 MB: 188 us per layer against a 75 us HBM roof).
 // Here a workgroup walks the K range of segment 1 into one set of accumulators and the K range of segment 2 into a second set
 // (the LDS-DMA ring runs on across the boundary) and the epilogue forms fl(fl(s2 acc2) + fl(s1 acc1 + bias)) -- exactly what the
-// two launches computed, bit for bit.  128 x 192 tile, 4 waves of 64 x 96, 192 accumulator registers: one workgroup per CU.
-template <int TN>
-__global__ void __launch_bounds__(256)
+// two launches computed, bit for bit.  TM = 2: 128 x 192 tile, 4 waves of 64 x 96, 192 accumulator registers, one workgroup per CU;
+// TM = 1: 64 x 192 tile, waves of 32 x 96, 96 accumulator registers, two workgroups per CU (one's output burst beside the other's K loop).
+template <int TN, int TM>
+__global__ void __launch_bounds__(256, TM == 1 ? 2 : 1)
 k_gemm_split2(const uint8_t* __restrict__ A1, const uint8_t* __restrict__ A2, int64_t lda_b, const uint8_t* __restrict__ W1,
               int64_t ldw1_b, int64_t K1b, const uint8_t* __restrict__ W2, int64_t ldw2_b, int64_t K2b, int64_t M, int64_t N,
               const float* __restrict__ scale1, const float* __restrict__ scale2, const float* __restrict__ bias,
               float* __restrict__ out, int64_t ldo) {
-    constexpr int TM = 2, BM = 128, BN = 64 * TN, NA = 2, NB = TN, LPT = NA + NB, STAGES = 3, TILE = (BM + BN) * 64;
+    constexpr int BM = 64 * TM, BN = 64 * TN, NA = TM, NB = TN, LPT = NA + NB, STAGES = 3, TILE = (BM + BN) * 64;
     __shared__ __attribute__((aligned(16))) uint8_t smem[STAGES * TILE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2250,7 +2251,7 @@ k_gemm_split2(const uint8_t* __restrict__ A1, const uint8_t* __restrict__ A2, in
 }
 
 extern "C" int edadm_qgemm_i8_split2_ok(int64_t M, int64_t N, int64_t K1, int64_t K2) {
-    return M > 0 && M % 128 == 0 && N > 0 && N % 192 == 0 && K1 > 0 && K2 > 0 && K1 % 64 == 0 && K2 % 64 == 0;
+    return M > 0 && M % 64 == 0 && N > 0 && N % 192 == 0 && K1 > 0 && K2 > 0 && K1 % 64 == 0 && K2 % 64 == 0;
 }
 extern "C" int edadm_qgemm_i8_split2(const int8_t* A, int64_t lda, int64_t split, const int8_t* W1, int64_t ldw1, const int8_t* W2,
                                      int64_t ldw2, int64_t M, int64_t N, int64_t K1, int64_t K2, const float* scale1,
@@ -2258,9 +2259,16 @@ extern "C" int edadm_qgemm_i8_split2(const int8_t* A, int64_t lda, int64_t split
     if (!A || !W1 || !W2 || !scale1 || !scale2 || !out || !edadm_qgemm_i8_split2_ok(M, N, K1, K2)) return EDADM_EINVAL;
     if (split != K1 || (lda & 15) || (ldw1 & 15) || (ldw2 & 15) || lda < K1 + K2 || ldw1 < K1 || ldw2 < K2 || ldo < N) return EDADM_EINVAL;
     if (((uintptr_t)A & 15) || ((uintptr_t)W1 & 15) || ((uintptr_t)W2 & 15) || ((uintptr_t)out & 3)) return EDADM_EINVAL;
-    const dim3 grid((unsigned)(N / 192), (unsigned)(M / 128), 1);
-    hipLaunchKernelGGL((k_gemm_split2<3>), grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t*)A, (const uint8_t*)A + split, lda,
-                       (const uint8_t*)W1, ldw1, K1, (const uint8_t*)W2, ldw2, K2, M, N, scale1, scale2, bias, out, ldo);
+    static const int64_t tm_force = EDADM_TUNE_I("EDADM_SPLIT2_TM", 1);
+    if (tm_force == 2 && M % 128 == 0) {
+        const dim3 grid((unsigned)(N / 192), (unsigned)(M / 128), 1);
+        hipLaunchKernelGGL((k_gemm_split2<3, 2>), grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t*)A, (const uint8_t*)A + split, lda,
+                           (const uint8_t*)W1, ldw1, K1, (const uint8_t*)W2, ldw2, K2, M, N, scale1, scale2, bias, out, ldo);
+    } else {
+        const dim3 grid((unsigned)(N / 192), (unsigned)(M / 64), 1);
+        hipLaunchKernelGGL((k_gemm_split2<3, 1>), grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t*)A, (const uint8_t*)A + split, lda,
+                           (const uint8_t*)W1, ldw1, K1, (const uint8_t*)W2, ldw2, K2, M, N, scale1, scale2, bias, out, ldo);
+    }
     return edadm_launch_status();
 }
 #endif
