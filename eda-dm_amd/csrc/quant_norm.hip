@@ -217,11 +217,20 @@ __global__ void __launch_bounds__(256) k_gn_partial(const float* __restrict__ x,
         float s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
         if (rs < RS) {
             const bool first = q < Q1;
-            for (int64_t r = r0 + rs; r < r1; r += RS) {
-                const float4 v = first ? xa[r * Q1 + q] : xc[r * Q2 + (q - Q1)];
+            // four 16-byte loads in flight per lane (one at a time the pass waited out every load: 92 % of a wave's life parked,
+            // rocprofv3 --pmc SQ_WAIT_ANY); the sums still run over the rows in their order: the same bits
+            const float4* src = first ? xa + q : xc + (q - Q1);
+            const int64_t st = first ? Q1 : Q2;
+            auto acc = [&](const float4 v) {
                 s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
                 ss[0] += v.x * v.x; ss[1] += v.y * v.y; ss[2] += v.z * v.z; ss[3] += v.w * v.w;
+            };
+            int64_t r = r0 + rs;
+            for (; r + 3 * RS < r1; r += 4 * RS) {
+                const float4 v0 = src[r * st], v1 = src[(r + RS) * st], v2 = src[(r + 2 * RS) * st], v3 = src[(r + 3 * RS) * st];
+                acc(v0); acc(v1); acc(v2); acc(v3);
             }
+            for (; r < r1; r += RS) acc(src[r * st]);
             for (int j = 0; j < 4; ++j) {
                 sm[((int64_t)rs * C + q * 4 + j) * 2] = s[j];
                 sm[((int64_t)rs * C + q * 4 + j) * 2 + 1] = ss[j];
