@@ -981,6 +981,243 @@ k_attn_small(const __half* __restrict__ Q, int64_t ldq, int64_t sQ, int64_t hQ, 
 // shapes of the few-key kernel
 static bool attn_small_shape(int64_t d, int64_t Nq, int64_t Nk) { return (d == 576 && Nk == 256) || (d == 960 && Nk == 64); }
 
+// ---- K6w with the score product on the INT8 MFMA.  The two score walks of k_attn_wide16 are bound by LDS reads (a 16x16x32 f16 MFMA
+// consumes a 1 KB K fragment every 16 cycles: four SIMDs ask for the LDS array's whole 256 B / clk).  q and k are 8-bit codes: as
+// int8 operands (code - 128, the projection epilogues' out_mode 2) a 16x16x64 MFMA takes the same 1 KB fragment for TWICE the keys x
+// dimensions, the staged K block is half the bytes, and the sum is exact in int32 at any d.  With q8 = code_q - 128 = (code_q - z_q) -
+// c_q, c_q = 128 - z_q (likewise k):  (q8 + c_q) . (k8 + c_k) = q8 . k8 + c_q sum_d k8 + [c_k sum_d q8 + d c_q c_k]; the bracket does not
+// depend on the key and cancels in the softmax of a query, so the kernel adds c_q x ksum[key] only (ksum from the staging pass:
+// v_dot4 with ones, reduced over the 8 lanes of a row) and exponentiates (s - max) c, a difference of exact integers.  P V stays on
+// the f16 MFMA (probability codes 0 .. 255 do not fit int8; V through the transposing read as before).  64 keys per iteration.
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+
+template <int KD64, int DB16>
+__global__ void __launch_bounds__(512)
+k_attn_wide16_i8(const int8_t* __restrict__ Q, int64_t ldq, int64_t sQ, int64_t hQ, const int8_t* __restrict__ K, int64_t ldk,
+                 int64_t sK, int64_t hK, const __half* __restrict__ V, int64_t ldv, int64_t sV, int64_t hV, void* __restrict__ out,
+                 int64_t ldo, int64_t sO, int Nq, int Nk, float alpha_qk, float cq, const QP* __restrict__ pqp, float alpha_pv,
+                 int out_mode, const QP* __restrict__ oqp) {
+    const QP pw = qp_load(pqp, 0);
+    constexpr int D = KD64 * 64;
+    static_assert(DB16 * 16 == D && D % 128 == 0, "d must be a multiple of 128");
+    constexpr int KROWB = D + 32;                                  // bytes per LDS row of K (int8): 8 banks mod 64 beyond a multiple of 256
+    constexpr int VROW = D + 16;                                   // halfs per LDS row of V
+    constexpr int BK = 64;
+    __shared__ __attribute__((aligned(16))) int8_t lk_[2][BK * KROWB];
+    __shared__ __half lv_[2][2][32 * VROW];                         // [buffer][32-key half of the block]
+    __shared__ float ksum_[2][BK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fc = lane & 15, fg = lane >> 4;
+    int qt, h;
+    int64_t b;
+    {
+        const unsigned nx = gridDim.x, ny = gridDim.y, n = nx * ny * gridDim.z;
+        const unsigned id = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+        const unsigned L = (n & 7) ? id : (n >> 3) * (id & 7) + (id >> 3);
+        qt = (int)(L % nx);
+        h = (int)((L / nx) % ny);
+        b = L / (nx * ny);
+    }
+    const int q = qt * ATT_BQ + wave * 16 + fc;
+    const int8_t* Qb = Q + b * sQ + (int64_t)h * hQ;
+    const int8_t* Kb = K + b * sK + (int64_t)h * hK;
+    const __half* Vb = V + b * sV + (int64_t)h * hV;
+    v4i_t qf[KD64];                                                // B operand: query fc, dimensions 64 ks + 16 fg .. + 15
+#pragma unroll
+    for (int ks = 0; ks < KD64; ++ks) {
+        v4i_t z = {0, 0, 0, 0};
+        if (q < Nq) z = *reinterpret_cast<const v4i_t*>(Qb + (int64_t)q * ldq + ks * 64 + fg * 16);
+        qf[ks] = z;
+    }
+    const int nkb = Nk / BK;                                       // the launcher guarantees Nk % 64 == 0
+    // staging.  K: thread -> key tid / 8, 16-byte chunks (tid & 7) + 8 c of its 384-byte row.  V: thread -> key tid / 16 of each
+    // 32-key half, chunks (tid & 15) + 16 c
+    constexpr int KC = D / 128, VC = D / 128;
+    v4i_t rk[KC];
+    half8 rv[2][VC];
+    const int kr = tid >> 3, kc0 = tid & 7, vr = tid >> 4, vc0 = tid & 15;
+    auto gload_k = [&](int kb) {
+        const int8_t* p = Kb + ((int64_t)kb * BK + kr) * ldk + kc0 * 16;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) rk[c] = *reinterpret_cast<const v4i_t*>(p + c * 128);
+    };
+    auto gload_v = [&](int kb) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const __half* p = Vb + ((int64_t)kb * BK + hf * 32 + vr) * ldv + vc0 * 8;
+#pragma unroll
+            for (int c = 0; c < VC; ++c) rv[hf][c] = *reinterpret_cast<const half8*>(p + c * 128);
+        }
+    };
+    auto lstore_k = [&](int buf) {
+        int part = 0;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            *reinterpret_cast<v4i_t*>(lk_[buf] + kr * KROWB + kc0 * 16 + c * 128) = rk[c];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) part = __builtin_amdgcn_sdot4(rk[c][e], 0x01010101, part, false);
+        }
+        part += __shfl_xor(part, 1, 64);
+        part += __shfl_xor(part, 2, 64);
+        part += __shfl_xor(part, 4, 64);
+        if (kc0 == 0) ksum_[buf][kr] = (float)part;
+    };
+    auto lstore_v = [&](int buf) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int c = 0; c < VC; ++c) *reinterpret_cast<half8*>(lv_[buf][hf] + vr * VROW + vc0 * 8 + c * 128) = rv[hf][c];
+    };
+    // S^T of a 64-key block: four 16-key tiles x this wave's 16 queries; register r of tile t is key 16 t + 4 fg + r
+    auto scores = [&](int buf, float (&s)[16]) {
+        const int8_t* base = lk_[buf] + fc * KROWB + fg * 16;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            v4i_t c = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < KD64; ++ks) {
+                const v4i_t a = *reinterpret_cast<const v4i_t*>(base + t * 16 * KROWB + ks * 64);
+                c = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, qf[ks], c, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[4 * t + r] = fmaf(cq, ksum_[buf][16 * t + 4 * fg + r], (float)c[r]);
+        }
+    };
+    const float cexp = alpha_qk * 1.44269504088896340736f;
+    // ---- walk 1: row maximum and sum (online form)
+    float mx = -INFINITY, sum = 0.f;
+    gload_k(0);
+    for (int kb = 0; kb < nkb; ++kb) {
+        lstore_k(kb & 1);
+        __syncthreads();
+        if (kb + 1 < nkb) gload_k(kb + 1);
+        float s[16];
+        scores(kb & 1, s);
+        float bm = mx;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bm = fmaxf(bm, s[i]);
+        sum *= __builtin_amdgcn_exp2f((mx - bm) * cexp);
+        mx = bm;
+        float part = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) part += __builtin_amdgcn_exp2f((s[i] - mx) * cexp);
+        sum += part;
+    }
+#pragma unroll
+    for (int sh = 16; sh <= 32; sh <<= 1) {
+        const float mo = __shfl_xor(mx, sh, 64), so = __shfl_xor(sum, sh, 64);
+        const float m = fmaxf(mx, mo);
+        sum = sum * __builtin_amdgcn_exp2f((mx - m) * cexp) + so * __builtin_amdgcn_exp2f((mo - m) * cexp);
+        mx = m;
+    }
+    const float inv = 1.0f / (sum * pw.d);
+    const bool z0 = pw.z == 0.f;
+    float4v o[DB16];
+#pragma unroll
+    for (int j = 0; j < DB16; ++j) o[j] = float4v{0, 0, 0, 0};
+    const int tr_off = (4 * fg + ((lane & 15) >> 2)) * VROW + 4 * (lane & 3);
+    // ---- walk 2: codes and O^T = V^T P^T
+    __syncthreads();                                               // every wave is done with the last K block of walk 1
+    gload_k(0);
+    gload_v(0);
+    for (int kb = 0; kb < nkb; ++kb) {
+        lstore_k(kb & 1);
+        lstore_v(kb & 1);
+        __syncthreads();
+        if (kb + 1 < nkb) {
+            gload_k(kb + 1);
+            gload_v(kb + 1);
+        }
+        float s[16];
+        scores(kb & 1, s);
+        float r_[16];
+        float worst = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            s[i] = __builtin_amdgcn_exp2f((s[i] - mx) * cexp);
+            const float t = s[i] * inv;
+            r_[i] = rintf(t);
+            worst = fmaxf(worst, fabsf(t - r_[i]));
+        }
+        if (__builtin_expect(worst > 0.499f, 0)) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                asm volatile("" : "+v"(r_[i]));
+                r_[i] = rintf((s[i] / sum) / pw.d);
+            }
+        }
+        half8 pf[2];                                               // half hf: tiles 2 hf, 2 hf + 1 = keys {4g .. 4g+3, 16+4g .. 16+4g+3} of its 32
+        if (z0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) pf[i >> 3][i & 7] = (_Float16)fminf(r_[i], pw.qmax);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) pf[i >> 3][i & 7] = (_Float16)(fminf(fmaxf(r_[i] + pw.z, 0.f), pw.qmax) - pw.z);
+        }
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const __half* vp = lv_[kb & 1][hf] + tr_off;
+#pragma unroll
+            for (int j = 0; j < DB16; ++j) {
+                const half4 va = __builtin_bit_cast(half4, __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                    (__attribute__((address_space(3))) fp16x4*)(vp + j * 16)));
+                const half4 vb = __builtin_bit_cast(half4, __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                    (__attribute__((address_space(3))) fp16x4*)(vp + j * 16 + 16 * VROW)));
+                const half8 a = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+                o[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pf[hf], o[j], 0, 0, 0);
+            }
+        }
+    }
+    if (q >= Nq) return;
+    QP oq;
+    if (out_mode == 2) oq = qp_load(oqp, 0);
+#pragma unroll
+    for (int j = 0; j < DB16; ++j) {
+        const int dv = j * 16 + 4 * fg;
+        float v4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v4[e] = o[j][e] * alpha_pv;
+        const int64_t col = (int64_t)h * D + dv;
+        if (out_mode == 0) {
+            float* op = reinterpret_cast<float*>(out) + b * sO + (int64_t)q * ldo + col;
+            *reinterpret_cast<float4*>(op) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+        } else {
+            int8_t* op = reinterpret_cast<int8_t*>(out) + b * sO + (int64_t)q * ldo + col;
+            uint32_t pk = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float c = fminf(fmaxf(rint_div(v4[e], oq.d, oq.inv) + oq.z, 0.f), oq.qmax);
+                pk |= (uint32_t)(uint8_t)(int8_t)((int)c - 128) << (8 * e);
+            }
+            *reinterpret_cast<uint32_t*>(op) = pk;
+        }
+    }
+}
+
+extern "C" int edadm_attention_fused_i8qk_ok(int64_t heads, int64_t d, int64_t Nq, int64_t Nk) {
+    return heads >= 1 && d == 384 && Nq >= 1 && Nk >= 64 && Nk % 64 == 0;
+}
+extern "C" int edadm_attention_fused_i8qk(const int8_t* Q, int64_t ldq, int64_t strideQ, int64_t headQ, const int8_t* K, int64_t ldk,
+                                          int64_t strideK, int64_t headK, const void* V, int64_t ldv, int64_t strideV, int64_t headV,
+                                          void* out, int64_t ldo, int64_t strideO, int64_t B, int64_t heads, int64_t Nq, int64_t Nk,
+                                          int64_t d, float alpha_qk, float zq, const float* pqp, float alpha_pv, int out_mode,
+                                          const float* oqp, void* stream) {
+    if (!Q || !K || !V || !out || !pqp || B <= 0 || !edadm_attention_fused_i8qk_ok(heads, d, Nq, Nk)) return EDADM_EINVAL;
+    if ((out_mode != 0 && out_mode != 2) || (out_mode == 2 && !oqp)) return EDADM_EINVAL;
+    if ((ldq & 15) || (ldk & 15) || (ldv & 7) || (strideQ & 15) || (strideK & 15) || (strideV & 7) || (headQ & 15) || (headK & 15) ||
+        (headV & 7) || headQ < d || headK < d || headV < d)
+        return EDADM_EINVAL;
+    if (((uintptr_t)Q & 15) || ((uintptr_t)K & 15) || ((uintptr_t)V & 15)) return EDADM_EINVAL;
+    if (out_mode == 0 && (((uintptr_t)out & 15) || (ldo & 3) || (strideO & 3))) return EDADM_EINVAL;
+    if (out_mode == 2 && (((uintptr_t)out & 3) || (ldo & 3) || (strideO & 3))) return EDADM_EINVAL;
+    if (!(alpha_qk > 0.f)) return EDADM_EINVAL;
+    hipLaunchKernelGGL((k_attn_wide16_i8<6, 24>), dim3((unsigned)((Nq + ATT_BQ - 1) / ATT_BQ), (unsigned)heads, (unsigned)B), dim3(512), 0,
+                       (hipStream_t)stream, Q, ldq, strideQ, headQ, K, ldk, strideK, headK, (const __half*)V, ldv, strideV, headV, out, ldo,
+                       strideO, (int)Nq, (int)Nk, alpha_qk, 128.0f - zq, reinterpret_cast<const QP*>(pqp), alpha_pv, out_mode,
+                       reinterpret_cast<const QP*>(oqp));
+    return edadm_launch_status();
+}
+
 // shapes of the wide-head kernel: one instantiation per head dimension
 static bool attn_wide_shape(int64_t d, int64_t Nq, int64_t Nk) { return d == 384 && Nk >= 64 && Nk % (2 * ATTW_BK) == 0 && Nq >= 1; }
 

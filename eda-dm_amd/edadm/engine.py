@@ -138,6 +138,7 @@ class Engine:
         self.fuse_rowadd_ln = True       # broadcast add + norm3 in one pass
         self.cfg_shared_prefix = True    # a guidance pair evaluates the context-independent prefix once
         self.w4_gemm_max_rows = 2048     # dense 4-bit layers at M <= this read their weights as packed nibbles (K4w); 0: never
+        self.attention_i8_scores = True  # one wide head (d = 384): Q K^T on the int8 MFMA (False: the f16 form of K6w; same codes up to boundary cases)
         self.fused_split = True          # split-quantiser skip convolutions as one launch (False: two, the second through the residual port)
         self.fused_attention = True      # K6f for heads of d <= 160 (False: the three-kernel path with the scores in memory;
                                          # the two differ only in the order of the fp32 row sum, i.e. in rare +-1 probability codes)
@@ -584,6 +585,13 @@ class Engine:
             self._attn_cache[key] = (ops.qp_tensor([(d, z, qmax)], self.dev), _f(d))
         return self._attn_cache[key]
 
+    def _zp(self, q):
+        """zero point of a quantiser as a host float (read once per quantiser: a device-to-host copy)"""
+        key = ("zp", id(q))
+        if key not in self._attn_cache:
+            self._attn_cache[key] = float(q.zero_point.detach().reshape(-1)[0].item())
+        return self._attn_cache[key]
+
     def attention(self, q2d, k2d, v2d, B, Nq, Nk, heads, d, aq_q, aq_k, aq_v, aq_w, scale, premul=1.0,
                   qcols=None, kcols=None, vcols=None, coded=False, out_qp=None, v_transposed=False):
         """q2d [B*Nq][*], k2d/v2d [B*Nk][*]: fp32 (quantised here) or, with coded=True, the f16 operands
@@ -789,10 +797,27 @@ class Engine:
 
     def ldm_cross_attn(self, attn, x2d_q, ctx_ops, B, Nq, Nk, residual):
         """x2d_q: int8 operand for to_q; ctx_ops: (operand for to_k, operand for to_v)."""
-        q = self._gemm(self.L(attn.to_q), x2d_q, B * Nq, out_mode=1, oqp=self._aq(attn.act_quantizer_q)[0])
-        k = self._gemm(self.L(attn.to_k), ctx_ops[0], B * Nk, out_mode=1, oqp=self._aq(attn.act_quantizer_k)[0])
         Lv = self.L(attn.to_v)
         heads_ = attn.heads
+        d_ = self.L(attn.to_q).N // heads_
+        # one wide head over many keys: scores on the int8 MFMA (K6w, csrc/attn.hip k_attn_wide16_i8) -- q and k leave their
+        # projections as int8 operands (code - 128), v as f16 codes
+        if (self.fused_attention and self.attention_i8_scores and ops.attention_i8qk_ok(heads_, d_, Nq, Nk)
+                and all(self.L(m).mode == "i8" and len(self.L(m).segs) == 1 for m in (attn.to_q, attn.to_k)) and Lv.mode == "i8"
+                and len(Lv.segs) == 1):
+            q8 = self._gemm(self.L(attn.to_q), x2d_q, B * Nq, out_mode=2, oqp=self._aq(attn.act_quantizer_q)[0])
+            k8 = self._gemm(self.L(attn.to_k), ctx_ops[0], B * Nk, out_mode=2, oqp=self._aq(attn.act_quantizer_k)[0])
+            v = self._gemm(Lv, ctx_ops[1], B * Nk, out_mode=1, oqp=self._aq(attn.act_quantizer_v)[0], rpb=Nk)
+            Lo = self.L(attn.to_out[0])
+            fuse = Lo.mode == "i8" and not Lo.split
+            (_, dq), (_, dk), (_, dv), (qpw, dw) = (self._aq(a) for a in (attn.act_quantizer_q, attn.act_quantizer_k, attn.act_quantizer_v,
+                                                                          attn.act_quantizer_w))
+            zq = self._zp(attn.act_quantizer_q)
+            o = ops.attention_fused_i8qk(q8, k8, v, B, heads_, Nq, Nk, d_, dq * dk * attn.scale, zq, qpw, dw * dv,
+                                         out_qp=Lo.qp if (fuse and (heads_ * d_) % 4 == 0) else None)
+            return self.lin(attn.to_out[0], None if fuse else o, residual=residual, pre=o if fuse else None)
+        q = self._gemm(self.L(attn.to_q), x2d_q, B * Nq, out_mode=1, oqp=self._aq(attn.act_quantizer_q)[0])
+        k = self._gemm(self.L(attn.to_k), ctx_ops[0], B * Nk, out_mode=1, oqp=self._aq(attn.act_quantizer_k)[0])
         fused = self.fused_attention and ops.attention_fused_ok(heads_, self.L(attn.to_q).N // heads_, Nq, Nk)
         vt_ok = (not fused) and Lv.mode == "i8" and len(Lv.segs) == 1 and ops.vt_mode_ok(B * Nk, Lv.N, Nk)
         # the v projection writes the P.V product's B operand directly: f16 codes, transposed per image

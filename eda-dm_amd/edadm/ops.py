@@ -308,6 +308,22 @@ def attention_fused(q, k, v, B, heads, Nq, Nk, d, alpha_qk, pqp, alpha_pv, q_off
     return out
 
 
+def attention_i8qk_ok(heads, d, Nq, Nk):
+    return bool(lib.load().edadm_attention_fused_i8qk_ok(int(heads), int(d), int(Nq), int(Nk)))
+
+
+def attention_fused_i8qk(q8, k8, v, B, heads, Nq, Nk, d, alpha_qk, zq, pqp, alpha_pv, out_qp=None):
+    """K6w on the int8 MFMA for the scores: q8 / k8 int8 operands (code - 128) [B*N][heads*d], v f16 codes; zq: zero point of the q
+    quantiser.  -> [B*Nq][heads*d] fp32, or the consumer's int8 operand with out_qp."""
+    hd = heads * d
+    out = torch.empty(B * Nq, hd, dtype=torch.int8 if out_qp is not None else torch.float32, device=v.device)
+    lib.call("edadm_attention_fused_i8qk", ctypes.c_void_p(q8.data_ptr()), q8.stride(0), Nq * q8.stride(0), d,
+             ctypes.c_void_p(k8.data_ptr()), k8.stride(0), Nk * k8.stride(0), d, ctypes.c_void_p(v.data_ptr()), v.stride(0),
+             Nk * v.stride(0), d, ctypes.c_void_p(out.data_ptr()), hd, Nq * hd, int(B), int(heads), int(Nq), int(Nk), int(d), float(alpha_qk),
+             float(zq), _pf(pqp), float(alpha_pv), 2 if out_qp is not None else 0, _pf(out_qp), _stream())
+    return out
+
+
 def nchw_to_nhwc(x):
     B, C = x.shape[0], x.shape[1]
     HW = x.numel() // (B * C)

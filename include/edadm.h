@@ -264,6 +264,16 @@ int edadm_qgemm_i8_q(const int8_t* A, int64_t lda, const int8_t* Wt, int64_t ldw
                      int64_t K, const int32_t* geom, const float* scale, const float* bias,
                      const float* rowadd, int64_t rows_per_batch, const float* residual, int64_t ldr,
                      void* out, int64_t ldo, int out_mode, const float* oqp, void* stream);
+/* The same attention (quant_block.py:204-235; openaimodel.py:384-406) for ONE WIDE head with q and k as INT8 operands (code - 128:
+ * edadm_qgemm_i8_q out_mode 2) and v as the f16 operand (out_mode 1): the score product runs on the int8 MFMA, exact in int32;
+ * zq = zero point of the q quantiser (the (128 - zq) sum_d k8 term is added per key; the key-independent terms cancel in the softmax).
+ * Strides in ELEMENTS of each tensor's own type.  Shapes: edadm_attention_fused_i8qk_ok (d == 384, Nk % 64 == 0).  Output as
+ * edadm_attention_fused_f16 (out_mode 0: fp32, 2: the consumer's int8 operand). */
+int edadm_attention_fused_i8qk_ok(int64_t heads, int64_t d, int64_t Nq, int64_t Nk);
+int edadm_attention_fused_i8qk(const int8_t* Q, int64_t ldq, int64_t strideQ, int64_t headQ, const int8_t* K, int64_t ldk, int64_t strideK,
+                               int64_t headK, const void* V, int64_t ldv, int64_t strideV, int64_t headV, void* out, int64_t ldo,
+                               int64_t strideO, int64_t B, int64_t heads, int64_t Nq, int64_t Nk, int64_t d, float alpha_qk, float zq,
+                               const float* pqp, float alpha_pv, int out_mode, const float* oqp, void* stream);
 /* K6f: the whole quantised attention core in one kernel -- S = alpha_qk Qc Kc^T, P = softmax(S), Pc = quantise(P; pqp), O = alpha_pv
  * Pc Vc -- for heads of 8 <= d <= 160 (d % 8 == 0) and any number of queries / keys >= 2: the heads x Nq x Nk score matrix is
  * never written (quant_block.py:204-235, :119-162, :398-451; openaimodel.py:384-406).  Q [B][Nq][..], K / V [B][Nk][..]: f16 integer

@@ -665,3 +665,46 @@ def test_task_harness_txt2img_sd(golden, tmp_path, capsys):
     common = ["--unet", json.dumps(kw), "--custom_steps", "30", "--H", "64", "--W", "64"]
     _run_harness(H, common, ["--calib_num_samples", "8", "--batch_samples", "2", "--iters", "2"],
                  ["--n_samples", "4", "--n_batch", "2"], tmp_path, capsys, 2)
+
+
+@pytest.mark.parametrize("B,heads,Nq,Nk,zq,zk", [(1, 1, 1024, 1024, 128, 128), (2, 1, 256, 256, 127, 128), (2, 2, 200, 128, 125, 131), (1, 1, 64, 64, 128, 127)])
+def test_wide_head_attention_with_int8_scores_against_torch_on_the_same_codes(B, heads, Nq, Nk, zq, zk):
+    """K6w, int8 score form (csrc/attn.hip k_attn_wide16_i8, edadm_attention_fused_i8qk): q and k as int8 operands (code - 128), the
+    (128 - z_q) sum_d k8 correction per key, key-independent terms dropped (they cancel in the softmax), v as f16 codes -- against
+    torch on the same integer codes (quant_block.py:204-235) and against the f16 form of the same kernel family; any zero points."""
+    from edadm import ops
+    dev = torch.device("cuda")
+    d = 384
+    g = torch.Generator().manual_seed(B * 1000 + Nq + Nk + zq)
+    hd = heads * d
+    cq = torch.randint(0, 256, (B * Nq, hd), generator=g).to(dev)
+    ck = torch.randint(0, 256, (B * Nk, hd), generator=g).to(dev)
+    cv = torch.randint(0, 256, (B * Nk, hd), generator=g).to(dev)
+    zv, dq_, dk_, dv_, dw_ = 128, 0.03, 0.031, 0.029, 1.0 / 255.0
+    scale = d ** -0.5
+    q8, k8 = (cq - 128).to(torch.int8), (ck - 128).to(torch.int8)
+    vh = (cv - zv).to(torch.float16)
+    pqp = ops.qp_tensor([(torch.tensor(dw_), torch.tensor(0.0), 255)], dev)
+    alpha = dq_ * dk_ * scale * 0.4                       # random codes: logits of a few units -- several keys per query keep a non-zero code
+    out = ops.attention_fused_i8qk(q8, k8, vh, B, heads, Nq, Nk, d, alpha, float(zq), pqp, dw_ * dv_)
+    sp = lambda t, n: t.reshape(B, n, heads, d).permute(0, 2, 1, 3).double()
+    s = torch.einsum("bhid,bhjd->bhij", sp(cq - zq, Nq), sp(ck - zk, Nk)) * alpha
+    p = torch.softmax(s.float(), -1)
+    cp = torch.clamp(torch.round(p / dw_), 0, 255)
+    ref = (torch.einsum("bhij,bhjd->bhid", cp.double(), sp(cv - zv, Nk)) * (dw_ * dv_)).permute(0, 2, 1, 3).reshape(B * Nq, hd).float()
+    one_code = 128.0 * dw_ * dv_
+    diff = (out - ref).abs()
+    frac = float((diff > 1e-6).float().mean())
+    print("int8 scores B=%d heads=%d Nq=%d Nk=%d zq=%d zk=%d vs torch on the codes: %.4f %% of outputs differ, max %.2f codes; mean |out| %.3f"
+          % (B, heads, Nq, Nk, zq, zk, 100 * frac, float(diff.max()) / one_code, float(ref.abs().mean())))
+    assert float(ref.abs().max()) > 10 * one_code                     # the probabilities are not all rounded away
+    assert frac < 5e-3 and float(diff.max()) <= 2.0 * one_code + 1e-6
+    # the f16 form of the kernel on the same codes (both operands minus their own zero points)
+    qh, kh = (cq - zq).to(torch.float16), (ck - zk).to(torch.float16)
+    f16 = ops.attention_fused(qh, kh, vh, B, heads, Nq, Nk, d, alpha, pqp, dw_ * dv_)
+    d2 = (out - f16).abs()
+    assert float((d2 > 1e-6).float().mean()) < 5e-3 and float(d2.max()) <= 2.0 * one_code + 1e-6
+    oqp = ops.qp_tensor([(torch.tensor(0.037), torch.tensor(131.0), 255)], dev)
+    got = ops.attention_fused_i8qk(q8, k8, vh, B, heads, Nq, Nk, d, alpha, float(zq), pqp, dw_ * dv_, out_qp=oqp)
+    want = ops.quant_i8(out, oqp)
+    assert got.dtype == torch.int8 and float((got != want).float().mean()) < 1e-3

@@ -90,3 +90,33 @@ timing(100, 1, 384, 1024, "LDM-4 32x32 self-attention (100 rows, 1 head x 384, 1
 timing(50, 1, 384, 1024, "LDM-4 32x32 self-attention, shared half of a guidance pair (50 rows)")
 timing(100, 1, 576, 256, "LDM-4 16x16 self-attention (100 rows, 1 head x 576, 256 keys)")
 timing(100, 1, 960, 64, "LDM-4 8x8 self-attention (100 rows, 1 head x 960, 64 keys)")
+
+
+def timing_i8(B, N, label):
+    """K6w with int8 scores (edadm_attention_fused_i8qk) against its f16 form on the same codes"""
+    import time
+    g = torch.Generator().manual_seed(2)
+    d = 384
+    c = lambda n: torch.randint(0, 256, (B * n, d), generator=g).to(dev)
+    cq, ck, cv = c(N), c(N), c(N)
+    q8, k8 = (cq - 128).to(torch.int8), (ck - 128).to(torch.int8)
+    qh, kh, vh = (cq - 128).half(), (ck - 128).half(), (cv - 128).half()
+    pqp = ops.qp_tensor([(torch.tensor(1 / 255.0), torch.tensor(0.0), 255)], dev)
+    alpha = 0.03 * 0.031 * d ** -0.5 * 0.4
+    res = {}
+    for name, f in (("int8 scores", lambda: ops.attention_fused_i8qk(q8, k8, vh, B, 1, N, N, d, alpha, 128.0, pqp, 0.029 / 255)),
+                    ("f16", lambda: ops.attention_fused(qh, kh, vh, B, 1, N, N, d, alpha, pqp, 0.029 / 255))):
+        out = f()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(10):
+            f()
+        torch.cuda.synchronize()
+        res[name] = ((time.time() - t0) / 10 * 1e3, out)
+    diff = (res["int8 scores"][1] - res["f16"][1]).abs()
+    print("%s: int8 scores %.3f ms, f16 %.3f ms (%.2fx); outputs differ in %.5f %% of elements" % (
+        label, res["int8 scores"][0], res["f16"][0], res["f16"][0] / res["int8 scores"][0], 100.0 * (diff > 0).float().mean().item()))
+
+
+timing_i8(100, 1024, "LDM-4 32x32 self-attention (100 rows, 1 head x 384, 1024 keys)")
+timing_i8(50, 1024, "LDM-4 32x32 self-attention (50 rows)")

@@ -19,12 +19,12 @@ def load(d, counter):
 
 
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
-is_i8 = lambda k: ("k_gemm_nt8<0" in k) or ("k_gemm_nt<0" in k) or ("k_gemm_p<0" in k) or ("k_conv3_direct<0" in k)
+is_i8 = lambda k: ("k_gemm_nt8<0" in k) or ("k_gemm_nt<0" in k) or ("k_gemm_p<0" in k) or ("k_conv3_direct<0" in k) or ("k_gemm_split2" in k)
 nl = sum(v[0] for k, v in fetch.items() if is_i8(k))
 fkb = sum(v[1] for k, v in fetch.items() if is_i8(k))
 wkb = sum(v[1] for k, v in write.items() if is_i8(k))
 out = {
-    "kernel": "int8 GEMM launches of edadm_qgemm_i8 / _q / edadm_qconv3_i8_direct (k_gemm_nt8<0,*>, k_gemm_p<0,*>, k_gemm_nt<0,*>, k_conv3_direct<0,3,2> / <0,3,1>)",
+    "kernel": "int8 GEMM launches of edadm_qgemm_i8 / _q / edadm_qconv3_i8_direct (k_gemm_nt8<0,*>, k_gemm_p<0,*>, k_gemm_nt<0,*>, k_conv3_direct<0,3,2> / <0,3,1>, k_gemm_split2<3,1>)",
     "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, in a separate pass, --pmc WRITE_SIZE) --output-format csv -- python "
                "tools/unet_prof.py  [N_CALLS=2: 4 eager UNet calls of the frozen LDM-4 engine as a DDIM step issues them, 100 rows]",
     "launches": nl, "unet_calls": int(sys.argv[4]) if len(sys.argv) > 4 else 4, "FETCH_SIZE_sum_KB": fkb, "WRITE_SIZE_sum_KB": wkb,
