@@ -958,6 +958,16 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
     if (direct) {
         EpiRegs<TN> er;
         load_epi_regs<TN, BN>(er, ec, lane, m0, m0 + wm * (TM * 32), wn * (TN * 32), rows_per_batch);
+        if constexpr (DT == 0 && TM == 2) {
+            // the next GroupNorm's partial sums from the epilogue's registers (a wave owns a whole 64-row slab: the direct
+            // convolution's order of sums, no LDS): launches with gn_ws are full tiles only (launch_gemm)
+            if (gn_ws) {
+                gemm_epilogue_direct_gnreg<DT, TM, TN>(acc, er, lane, m0 + wm * (TM * 32), n0 + wn * (TN * 32), rowadd != nullptr,
+                                                       residual, ldr, out, ldo, gn_ws, N);
+                stamp_out();
+                return;
+            }
+        }
         gemm_epilogue_direct<DT, TM, TN>(acc, er, lane, m0 + wm * (TM * 32), n0 + wn * (TN * 32), rowadd != nullptr, residual,
                                          ldr, out, ldo, gacc_all + (wm * BN + wn * (TN * 32)) * 2, gn_ws, N);
         stamp_out();
@@ -1647,7 +1657,7 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
     // the 8-wave tile's smaller operand traffic per flop (tools/gemm_table.py, EDADM_GEMM_FORCE=2 vs 3)
     static const int64_t nt8_min_kb = EDADM_TUNE_I("EDADM_NT8_MIN_KB", 2049);
     if (force != 2 && EDADM_USE_NT8 && (force == 3 || (tiles8 >= 224 && (Kb >= nt8_min_kb || tn == 4))) && nt8_gather_ok &&
-        !(out_mode == 4 && M % 256)) {
+        !(out_mode == 4 && M % 256) && !gn_ws) {               // GroupNorm partials: the 4-wave kernel's epilogue
         // Tail re-tiling: one workgroup per CU means the launch runs in rounds of #CU tiles, and a last round that is
         // mostly empty costs a full round (300 tiles on 256 CUs: 2 rounds for 1.17 rounds of work).  The m-tiles that
         // fill whole rounds go to this kernel; the remaining rows go to the 128-row, two-per-CU kernel in a second
@@ -2284,10 +2294,10 @@ extern "C" int edadm_device_status(int clear, void* stream) {
     }
     return w ? EDADM_EIO : 0;
 }
-extern "C" int edadm_qgemm_i8(const int8_t* A, int64_t lda, const int8_t* Wt, int64_t ldw, int64_t M, int64_t N,
-                              int64_t K, const int32_t* geom, const float* scale, const float* bias,
-                              const float* rowadd, int64_t rows_per_batch, const float* residual, int64_t ldr,
-                              float* out, int64_t ldo, void* stream) {
+static int qgemm_i8_impl(const int8_t* A, int64_t lda, const int8_t* Wt, int64_t ldw, int64_t M, int64_t N,
+                         int64_t K, const int32_t* geom, const float* scale, const float* bias,
+                         const float* rowadd, int64_t rows_per_batch, const float* residual, int64_t ldr,
+                         float* out, int64_t ldo, float* gn_ws, int64_t gn_hw, void* stream) {
     if (!A || !Wt || !out || !scale || M <= 0 || N <= 0 || K <= 0 || (K & 15) || (ldw & 15)) return EDADM_EINVAL;
     if (((uintptr_t)A & 15) || ((uintptr_t)Wt & 15)) return EDADM_EINVAL;
     ConvGeom g;
@@ -2306,7 +2316,28 @@ extern "C" int edadm_qgemm_i8(const int8_t* A, int64_t lda, const int8_t* Wt, in
     }
     if (rowadd && rows_per_batch < 16) return EDADM_EINVAL;   // the epilogue stages <= BM/16+1 row-add rows in LDS
     return launch_gemm<0>(A, lda, 0, Wt, ldw, 0, M, N, K, g, scale, bias, rowadd, rows_per_batch, residual, ldr,
-                             out, ldo, 0, 1, 1.0f, (hipStream_t)stream, 1, 0, 0, 0, 0, nullptr, nullptr, 0);
+                             out, ldo, 0, 1, 1.0f, (hipStream_t)stream, 1, 0, 0, 0, 0, nullptr, gn_ws, gn_hw);
+}
+
+extern "C" int edadm_qgemm_i8(const int8_t* A, int64_t lda, const int8_t* Wt, int64_t ldw, int64_t M, int64_t N,
+                              int64_t K, const int32_t* geom, const float* scale, const float* bias,
+                              const float* rowadd, int64_t rows_per_batch, const float* residual, int64_t ldr,
+                              float* out, int64_t ldo, void* stream) {
+    return qgemm_i8_impl(A, lda, Wt, ldw, M, N, K, geom, scale, bias, rowadd, rows_per_batch, residual, ldr, out, ldo, nullptr, 0,
+                         stream);
+}
+
+extern "C" int edadm_qgemm_i8_gn_ok(int64_t M, int64_t N, int64_t hw) {
+    return M > 0 && M % 256 == 0 && (N % 192 == 0 || N % 128 == 0) && hw > 0 && hw % 64 == 0 && M % hw == 0;
+}
+
+extern "C" int edadm_qgemm_i8_gn(const int8_t* A, int64_t lda, const int8_t* Wt, int64_t ldw, int64_t M, int64_t N,
+                                 int64_t K, const int32_t* geom, const float* scale, const float* bias,
+                                 const float* rowadd, int64_t rows_per_batch, const float* residual, int64_t ldr,
+                                 float* out, int64_t ldo, float* gn_ws, int64_t hw, void* stream) {
+    if (!gn_ws || !edadm_qgemm_i8_gn_ok(M, N, hw)) return EDADM_EINVAL;
+    return qgemm_i8_impl(A, lda, Wt, ldw, M, N, K, geom, scale, bias, rowadd, rows_per_batch, residual, ldr, out, ldo, gn_ws, hw,
+                         stream);
 }
 #endif
 

@@ -153,6 +153,7 @@ class Engine:
         self.direct_conv = True          # LDS-resident-patch 3x3 convolution (False: every convolution as an implicit GEMM)
         self.direct_conv_min_k = 1152    # ... from this K on
         self.gn_partials = True          # ... which also writes the next GroupNorm's partial sums
+        self.gn_partials_gemm = True     # ... and so do the implicit-GEMM layers in front of a GroupNorm (proj_out, Downsample)
         self.graph = None
         self.prof = None
         self.tap = None              # {layer name: [operands]}: diagnostics (per-layer code census), off on the hot path
@@ -330,12 +331,23 @@ class Engine:
                                       self._alg_bytes(L, a, M, 4.0 * M * L.N, residual, "dense")))
                 run()
                 return out
+        # GroupNorm partials of this output from the epilogue's registers when the next layer normalises it (proj_out of a
+        # transformer block, a Downsample convolution): its statistics pass then only reduces them (_gn_stats)
+        ws = None
+        if (gn_hw and self.gn_partials and self.gn_partials_gemm and L.mode == "i8" and len(L.segs) == 1 and (rowadd is None or rpb >= 64)
+                and ops.qgemm_i8_gn_ok(M, L.N, gn_hw)):
+            ws = torch.empty(M // 64, L.N, 2, dtype=torch.float32, device=self.dev)
+            out._gn = (ws, gn_hw, 64)
         if geom is not None:
             s = L.segs[0]
 
             def run():
-                fn(a, s["w"], M, L.N, s["K"], s["scale"], L.bias, out, geom=geom, rowadd=rowadd, rows_per_batch=rpb,
-                   residual=residual)
+                if ws is not None:
+                    fn(a, s["w"], M, L.N, s["K"], s["scale"], L.bias, out, geom=geom, rowadd=rowadd, rows_per_batch=rpb,
+                       residual=residual, gn_ws=ws, gn_hw=gn_hw)
+                else:
+                    fn(a, s["w"], M, L.N, s["K"], s["scale"], L.bias, out, geom=geom, rowadd=rowadd, rows_per_batch=rpb,
+                       residual=residual)
         elif (self.fused_split and L.mode == "i8" and len(L.segs) == 2 and rowadd is None and residual is None and a.dim() == 2
               and a.is_contiguous() and L.segs[0]["lo"] == 0 and L.segs[0]["hi"] == L.segs[1]["lo"] and L.segs[1]["hi"] == a.shape[-1]
               and ops.qgemm_i8_split2_ok(M, L.N, L.segs[0]["K"], L.segs[1]["K"])
@@ -350,6 +362,11 @@ class Engine:
             ctot = a.shape[-1]
 
             def run():
+                if ws is not None:
+                    s = L.segs[0]
+                    fn(a, s["w"], M, L.N, s["K"], s["scale"], L.bias, out, lda=ctot, rowadd=rowadd, rows_per_batch=rpb,
+                       residual=residual, gn_ws=ws, gn_hw=gn_hw)
+                    return
                 for i, s in enumerate(L.segs):
                     av = a if len(L.segs) == 1 else a[:, s["lo"]:s["hi"]]
                     fn(av, s["w"], M, L.N, s["K"], s["scale"], L.bias if i == 0 else None, out, lda=ctot,
@@ -370,11 +387,11 @@ class Engine:
         return {"kind": kind, "a": float(a.numel() * a.element_size()), "w": float(wb), "out": float(out_bytes),
                 "res": 4.0 * M * L.N if residual is not None else 0.0}
 
-    def lin(self, qm, x2d, rowadd=None, rpb=1, residual=None, pre=None):
-        """x2d fp32 [M][C] (or a ready operand via `pre`) -> fp32 [M][N]."""
+    def lin(self, qm, x2d, rowadd=None, rpb=1, residual=None, pre=None, gn_hw=0):
+        """x2d fp32 [M][C] (or a ready operand via `pre`) -> fp32 [M][N]; gn_hw = rows per image when a GroupNorm reads the output next."""
         L = self.L(qm)
         a = pre if pre is not None else self._quant(L, x2d)
-        return self._gemm(L, a, a.shape[0], rowadd=rowadd, rpb=rpb, residual=residual)
+        return self._gemm(L, a, a.shape[0], rowadd=rowadd, rpb=rpb, residual=residual, gn_hw=gn_hw)
 
     def conv(self, qm, a, B, H, W, ups=False, rowadd=None, residual=None):
         """a: int8 NHWC operand [B,H,W,Cin] -> fp32 [B,Ho,Wo,N]."""
@@ -734,9 +751,16 @@ class Engine:
             wp[:, :9 * C] = L.segs[0]["w"]
             L.w_pad = wp
         col = ops.im2col_quant_i8(xh, kpad, L.qp)
-        out = torch.empty(B * H * W, L.N, dtype=torch.float32, device=self.dev)
-        ops.qgemm_i8(col, L.w_pad, B * H * W, L.N, kpad, L.segs[0]["scale"], L.bias, out)
-        return out.reshape(B, H, W, L.N)
+        M = B * H * W
+        out = torch.empty(M, L.N, dtype=torch.float32, device=self.dev)
+        ws = None
+        if self.gn_partials and self.gn_partials_gemm and ops.qgemm_i8_gn_ok(M, L.N, H * W):
+            ws = torch.empty(M // 64, L.N, 2, dtype=torch.float32, device=self.dev)     # the first ResBlock's (and the last skip's) GroupNorm
+        ops.qgemm_i8(col, L.w_pad, M, L.N, kpad, L.segs[0]["scale"], L.bias, out, gn_ws=ws, gn_hw=H * W)
+        o4 = out.reshape(B, H, W, L.N)
+        if ws is not None:
+            o4._gn = (ws, H * W, 64)
+        return o4
 
     def last_conv(self, norm, qm, h):
         L = self.L(qm)
@@ -941,8 +965,10 @@ class Engine:
                 x = torch.cat([x, x])
                 B *= 2
         if emitted:
-            return self.lin(st.proj_out, None, residual=x.reshape(B * N, C), pre=t).reshape(B, H, W, C)
-        return self.lin(st.proj_out, t, residual=x.reshape(B * N, C)).reshape(B, H, W, C)
+            o = self.lin(st.proj_out, None, residual=x.reshape(B * N, C), pre=t, gn_hw=N)
+            return self._keep_gn(o, o.reshape(B, H, W, C))
+        o = self.lin(st.proj_out, t, residual=x.reshape(B * N, C), gn_hw=N)
+        return self._keep_gn(o, o.reshape(B, H, W, C))
 
     def ldm_legacy_attn(self, ab, x):
         """AttentionBlock + QKVAttentionLegacy with Quant{QK,SMV}MatMul (openaimodel.py:281-406)."""
@@ -959,7 +985,8 @@ class Engine:
                            smv.act_quantizer_v, smv.act_quantizer_w, 1.0, premul=sc,
                            qcols=[h * 3 * ch for h in range(heads)], kcols=[h * 3 * ch + ch for h in range(heads)],
                            vcols=[h * 3 * ch + 2 * ch for h in range(heads)])
-        return self.lin(ab.proj_out, o, residual=x.reshape(B * N, C)).reshape(B, H, W, C)
+        o = self.lin(ab.proj_out, o, residual=x.reshape(B * N, C), gn_hw=N)
+        return self._keep_gn(o, o.reshape(B, H, W, C))
 
     def ldm_seq(self, mods, h, emb, context, split=0):
         for m in mods:

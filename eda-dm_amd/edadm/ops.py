@@ -496,12 +496,22 @@ def device_status(clear=True):
                            "are invalid)" % rc)
 
 
+def qgemm_i8_gn_ok(M, N, hw):
+    return bool(lib.load().edadm_qgemm_i8_gn_ok(int(M), int(N), int(hw)))
+
+
 def qgemm_i8(A, Wt, M, N, K, scale, bias, out, geom=None, lda=None, ldw=None, rowadd=None, rows_per_batch=1,
-             residual=None):
-    """out[M][N] (fp32, contiguous rows of length N) = scale[n] * (A . Wt^T) + bias[n] [+rowadd] [+residual]."""
+             residual=None, gn_ws=None, gn_hw=0):
+    """out[M][N] (fp32, contiguous rows of length N) = scale[n] * (A . Wt^T) + bias[n] [+rowadd] [+residual]; gn_ws [M / 64][N][2]:
+    the per-channel (sum, sum of squares) of every 64-row slab of out, from the epilogue's registers (edadm_qgemm_i8_gn)."""
     lda = K if lda is None else lda
     ldw = K if ldw is None else ldw
     gptr = ctypes.cast(geom, ctypes.c_void_p) if geom is not None else None
+    if gn_ws is not None:
+        lib.call("edadm_qgemm_i8_gn", ctypes.c_void_p(A.data_ptr()), int(lda), ctypes.c_void_p(Wt.data_ptr()), int(ldw),
+                 int(M), int(N), int(K), gptr, _pf(scale), _pf(bias), _pf(rowadd), int(rows_per_batch), _pf(residual),
+                 int(N), _pf(out), int(N), _pf(gn_ws), int(gn_hw), _stream())
+        return out
     lib.call("edadm_qgemm_i8", ctypes.c_void_p(A.data_ptr()), int(lda), ctypes.c_void_p(Wt.data_ptr()), int(ldw),
              int(M), int(N), int(K), gptr, _pf(scale), _pf(bias), _pf(rowadd), int(rows_per_batch), _pf(residual),
              int(N), _pf(out), int(N), _stream())

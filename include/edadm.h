@@ -220,6 +220,17 @@ int edadm_qgemm_i8(const int8_t* A, int64_t lda, const int8_t* Wt, int64_t ldw, 
                    int64_t K, const int32_t* geom, const float* scale, const float* bias,
                    const float* rowadd, int64_t rows_per_batch, const float* residual, int64_t ldr,
                    float* out, int64_t ldo, void* stream);
+/* edadm_qgemm_i8 that also writes the NEXT GroupNorm's partial sums (ldm/modules/diffusionmodules/util.py GroupNorm32 over the
+ * tensor this layer produces: openaimodel.py:217-263 ResBlock.in_layers[0] after a SpatialTransformer's proj_out
+ * (attention.py:247-275) or a Downsample convolution (openaimodel.py:143-170)): gn_ws [M / 64][N][2] = per-channel (sum, sum of
+ * squares) of every 64-row slab of out (fp32 of the stored values, one fixed order of sums -- the direct convolution's, so
+ * edadm_groupnorm_final_cat* reduces both alike); hw = rows per image.  Full tiles only: edadm_qgemm_i8_gn_ok (M % 256 == 0,
+ * N % 192 == 0 or N % 128 == 0, hw % 64 == 0, M % hw == 0). */
+int edadm_qgemm_i8_gn_ok(int64_t M, int64_t N, int64_t hw);
+int edadm_qgemm_i8_gn(const int8_t* A, int64_t lda, const int8_t* Wt, int64_t ldw, int64_t M, int64_t N,
+                      int64_t K, const int32_t* geom, const float* scale, const float* bias,
+                      const float* rowadd, int64_t rows_per_batch, const float* residual, int64_t ldr,
+                      float* out, int64_t ldo, float* gn_ws, int64_t hw, void* stream);
 /* Deferred device-side errors.  Every entry point returns as soon as its kernels are enqueued, so a failure INSIDE a kernel
  * (today: a hand-off wait of the persistent GEMM that gave up after 4 M polls instead of hanging the GPU -- its outputs are
  * then wrong) cannot come back from the launching call: it sets a device error word.  This call synchronises `stream`, reads

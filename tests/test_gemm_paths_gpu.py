@@ -244,6 +244,66 @@ def test_direct_conv3_partials_do_not_depend_on_the_tile(ops):
     assert torch.equal(wb[:n // 64], ws_)
 
 
+@pytest.mark.parametrize("B,H,K,N,res", [(4, 32, 384, 384, True), (8, 16, 576, 576, True), (16, 8, 960, 960, True), (2, 64, 192, 192, False)])
+def test_dense_layer_groupnorm_partials_from_the_epilogue(ops, B, H, K, N, res):
+    """edadm_qgemm_i8_gn on a dense layer (a transformer's proj_out with its residual, attention.py:247-275): the output of the plain
+    launch bit for bit, and per-channel partials of every 64-row slab that reduce to the two-pass statistics of that output (2e-5:
+    fp32 sums in another order, combined in fp64) -- alone and as one half of a skip concatenation."""
+    g = torch.Generator().manual_seed(B + H + N)
+    HW = H * H
+    M = B * HW
+    a = torch.randint(-128, 128, (M, K), generator=g, dtype=torch.int8).cuda()
+    w = torch.randint(-8, 9, (N, K), generator=g, dtype=torch.int8).cuda()
+    scale, bias = (torch.rand(N, generator=g) * 1e-2 + 1e-3).cuda(), torch.randn(N, generator=g).cuda()
+    r = torch.randn(M, N, generator=g).cuda() if res else None
+    assert ops.qgemm_i8_gn_ok(M, N, HW)
+    out0 = ops.qgemm_i8(a, w, M, N, K, scale, bias, torch.empty(M, N, device="cuda"), residual=r)
+    ws = torch.full((M // 64, N, 2), float("nan"), device="cuda")
+    out = ops.qgemm_i8(a, w, M, N, K, scale, bias, torch.empty(M, N, device="cuda"), residual=r, gn_ws=ws, gn_hw=HW)
+    assert torch.equal(out, out0) and torch.isfinite(ws).all()
+    o3 = out.reshape(M // 64, 64, N).double()
+    assert ((ws[..., 0].double() - o3.sum(1)).abs() <= 1e-5 * o3.abs().sum(1).clamp_min(1.0)).all()
+    assert ((ws[..., 1].double() - (o3 * o3).sum(1)).abs() <= 1e-5 * (o3 * o3).sum(1).clamp_min(1.0)).all()
+    G = 32
+    xo = out.reshape(B, HW, N)
+    tol = lambda got, want: ((got - want).abs() <= 2e-5 * want.abs().clamp_min(1.0)).all()
+    assert tol(ops.groupnorm_final(ws, N, None, 0, B, HW, G, 1e-5, rows1=64), ops.groupnorm_stats(xo, G, 1e-5))
+    other = torch.randn(B, HW, 64, generator=g).cuda() * 3
+    ws_o = torch.empty(M // 64, 64, 2, device="cuda")
+    o64 = other.reshape(M // 64, 64, 64)
+    ws_o[..., 0], ws_o[..., 1] = o64.sum(1), (o64 * o64).sum(1)
+    assert tol(ops.groupnorm_final(ws, N, ws_o, 64, B, HW, G, 1e-5, rows1=64), ops.groupnorm_stats(ops.Cat(xo, other), G, 1e-5))
+
+
+@pytest.mark.parametrize("B,H,Cin,N,stride", [(4, 64, 192, 192, 2), (8, 32, 384, 384, 2), (16, 16, 576, 576, 2), (3, 32, 192, 384, 1)])
+def test_implicit_gemm_groupnorm_partials_equal_the_direct_convolutions(ops, B, H, Cin, N, stride):
+    """The implicit-GEMM kernel's partials (a Downsample convolution, openaimodel.py:143-170) -- and, for a stride-1 3x3 layer both
+    kernels can take, THE SAME BITS as edadm_qconv3_i8_direct's: one order of sums per 64-row slab whichever kernel produced the
+    tensor (a layer may change kernels with the batch size; the sampling loop's half-batch prefix must not change statistics)."""
+    g = torch.Generator().manual_seed(B + H + N + stride)
+    x = torch.randint(-128, 128, (B, H, H, Cin), generator=g, dtype=torch.int8).cuda()
+    w = torch.randint(-8, 9, (N, 9 * Cin), generator=g, dtype=torch.int8).cuda()
+    scale, bias = (torch.rand(N, generator=g) * 1e-2 + 1e-3).cuda(), torch.randn(N, generator=g).cuda()
+    Ho = H // stride
+    M, HW, K = B * Ho * Ho, Ho * Ho, 9 * Cin
+    if not ops.qgemm_i8_gn_ok(M, N, HW):
+        pytest.skip("shape outside edadm_qgemm_i8_gn_ok")
+    geom = ops.make_geom(B, H, H, Cin, Ho, Ho, 3, 3, stride, 1, False, 5)
+    rowadd = torch.randn(B, N, generator=g).cuda()
+    out0 = ops.qgemm_i8(x, w, M, N, K, scale, bias, torch.empty(M, N, device="cuda"), geom=geom, rowadd=rowadd, rows_per_batch=HW)
+    ws = torch.full((M // 64, N, 2), float("nan"), device="cuda")
+    out = ops.qgemm_i8(x, w, M, N, K, scale, bias, torch.empty(M, N, device="cuda"), geom=geom, rowadd=rowadd, rows_per_batch=HW,
+                       gn_ws=ws, gn_hw=HW)
+    assert torch.equal(out, out0) and torch.isfinite(ws).all()
+    tol = lambda got, want: ((got - want).abs() <= 2e-5 * want.abs().clamp_min(1.0)).all()
+    assert tol(ops.groupnorm_final(ws, N, None, 0, B, HW, 32, 1e-5, rows1=64), ops.groupnorm_stats(out.reshape(B, HW, N), 32, 1e-5))
+    if stride == 1 and ops.conv3_direct_ok(B, H, H, Cin, N):
+        ws_d = torch.full((M // 64, N, 2), float("nan"), device="cuda")
+        out_d = ops.qconv3_i8_direct(x, ops.conv3_pack_w(w, N, Cin), B, H, H, Cin, N, 5, scale, bias, torch.empty(M, N, device="cuda"),
+                                     rowadd=rowadd, rows_per_batch=HW, gn_ws=ws_d)
+        assert torch.equal(out_d, out) and torch.equal(ws_d, ws)
+
+
 @pytest.mark.parametrize("M,N,K1,K2", [(1024, 192, 192, 192), (2048, 384, 576, 384), (640, 960, 960, 960), (4096, 192, 384, 192), (256, 576, 1152, 384)])
 def test_split_quantiser_layer_in_one_launch_bit_identical_to_two(M, N, K1, K2):
     """K4s (csrc/gemm.hip, edadm_qgemm_i8_split2): the 1x1 skip convolution over [h | skip] with two activation / weight quantisers
