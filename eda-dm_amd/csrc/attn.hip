@@ -22,6 +22,11 @@
 // for two 16-key K-steps if the keys of a K-step are taken in the order the accumulator rows have (lane half h holds keys
 // {4h .. 4h+3, 8+4h .. 8+4h+3} of each 16): V^T is fetched from LDS in that order, P never moves between registers.
 #include "common.h"
+// Softmax codes rint((e / sum) / delta) through ONE reciprocal: t = fl(e * fl(1 / fl(sum * delta))) is within 3 x 2^-24 |t| of the quotient,
+// the reference's fl(fl(e / sum) / delta) within 2 x 2^-24: the rounded integers can differ only inside the band |t - rint(t)| +
+// 3.6e-7 t > 0.5 - 4e-5, whose lanes redo both divisions (relative: tight for 8-bit codes, sufficient for 16-bit ones; common.h)
+#define EDADM_SM_BAND_REL 3.6e-7f
+#define EDADM_SM_NEAR (0.5f - 4e-5f)
 #include "../../include/edadm.h"
 #include <hip/hip_fp16.h>
 #include <type_traits>
@@ -197,9 +202,9 @@ k_attn_fused(const __half* __restrict__ Q, int64_t ldq, int64_t sQ, int64_t hQ, 
                 acc[sb][r] = e;
                 const float t = e * inv;
                 r_[r] = rintf(t);
-                worst = fmaxf(worst, fabsf(t - r_[r]));
+                worst = fmaxf(worst, fmaf(t, EDADM_SM_BAND_REL, fabsf(t - r_[r])));
             }
-            if (__builtin_expect(worst > 0.499f, 0)) {
+            if (__builtin_expect(worst > EDADM_SM_NEAR, 0)) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     asm volatile("" : "+v"(r_[r]));
@@ -500,10 +505,10 @@ k_attn_wide(const __half* __restrict__ Q, int64_t ldq, int64_t sQ, int64_t hQ, c
             cur[r] = e;
             const float t = e * inv;
             r_[r] = rintf(t);
-            worst = fmaxf(worst, fabsf(t - r_[r]));
+            worst = fmaxf(worst, fmaf(t, EDADM_SM_BAND_REL, fabsf(t - r_[r])));
         }
         ATTW_T(t2);
-        if (__builtin_expect(worst > 0.499f, 0)) {
+        if (__builtin_expect(worst > EDADM_SM_NEAR, 0)) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 asm volatile("" : "+v"(r_[r]));
@@ -755,9 +760,9 @@ k_attn_wide16(const __half* __restrict__ Q, int64_t ldq, int64_t sQ, int64_t hQ,
             e_[i] = e;
             const float t = e * inv;
             r_[i] = rintf(t);
-            worst = fmaxf(worst, fabsf(t - r_[i]));
+            worst = fmaxf(worst, fmaf(t, EDADM_SM_BAND_REL, fabsf(t - r_[i])));
         }
-        if (__builtin_expect(worst > 0.499f, 0)) {
+        if (__builtin_expect(worst > EDADM_SM_NEAR, 0)) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 asm volatile("" : "+v"(r_[i]));
@@ -908,9 +913,9 @@ k_attn_small(const __half* __restrict__ Q, int64_t ldq, int64_t sQ, int64_t hQ, 
         for (int i = 0; i < 8; ++i) {
             const float t = s[2 * kb + (i >> 2)][i & 3] * inv;
             r_[i] = rintf(t);
-            worst = fmaxf(worst, fabsf(t - r_[i]));
+            worst = fmaxf(worst, fmaf(t, EDADM_SM_BAND_REL, fabsf(t - r_[i])));
         }
-        if (__builtin_expect(worst > 0.499f, 0)) {
+        if (__builtin_expect(worst > EDADM_SM_NEAR, 0)) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 asm volatile("" : "+v"(r_[i]));
@@ -1137,9 +1142,9 @@ k_attn_wide16_i8(const int8_t* __restrict__ Q, int64_t ldq, int64_t sQ, int64_t 
             s[i] = __builtin_amdgcn_exp2f((s[i] - mx) * cexp);
             const float t = s[i] * inv;
             r_[i] = rintf(t);
-            worst = fmaxf(worst, fabsf(t - r_[i]));
+            worst = fmaxf(worst, fmaf(t, EDADM_SM_BAND_REL, fabsf(t - r_[i])));
         }
-        if (__builtin_expect(worst > 0.499f, 0)) {
+        if (__builtin_expect(worst > EDADM_SM_NEAR, 0)) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 asm volatile("" : "+v"(r_[i]));

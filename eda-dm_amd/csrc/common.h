@@ -98,15 +98,23 @@ __device__ __forceinline__ float erf_fast(float a) {
     return t > 0.927734375f ? big : small;
 }
 
-// round(v / d) with the reference's true-division result at the cost of a multiply: t = v * (1/d) differs from
-// v / d by a couple of ulp, which can only change the rounded integer when t sits within 1e-3 of a .5
-// boundary (|t| < 1024; larger magnitudes saturate in the clamp that follows).  Those rare lanes redo the IEEE
-// division behind a REAL branch: the empty asm keeps the compiler from if-converting it into an unconditional
-// 10-instruction division per element.
+// round(v / d) with the reference's true-division result at the cost of a multiply.  t = fl(v * fl(1 / d)) and the reference's
+// fl(v / d) are both within 2^-24 |q| (x2 for t: the reciprocal's rounding and the product's) of q = v / d, so the two rounded
+// integers can differ only when t lies within 1.8e-7 |t| of a .5 boundary; with the zero point riding in the FMA the sum is
+// rounded once more (half an ulp of t) and the reciprocal's error also scales |z|.  Lanes inside the band
+//     |t - rint(t)| + 2.4e-7 |t|  >  0.5 - (4e-5 + 1.2e-7 |z|)
+// redo the IEEE division behind a REAL branch (the empty asm keeps the compiler from if-converting it into an unconditional
+// 10-instruction division per element).  The band is relative: the fixed 1e-3 of rounds 1-3 was 20x wider than needed for 8-bit
+// codes -- a wave executes the exact path when ANY of its 64 x NV elements is inside, i.e. 40 % of the 4-element groups instead
+// of 3 %, and the quantising GEMM epilogues are bound by exactly this arithmetic -- and too narrow for 16-bit codes above ~5000
+// (softmax with sm_abit = 16).  Exact ties are inside the band, so the half-to-even decision is always the reference's.
+#define EDADM_BAND_REL 2.4e-7f
+__device__ __forceinline__ float near_limit(float z = 0.f) { return 0.5f - fmaf(fabsf(z), 1.2e-7f, 4e-5f); }
+
 __device__ __forceinline__ float rint_div(float v, float d, float inv_d) {
     const float t = v * inv_d;
     float r = rintf(t);
-    if (__builtin_expect(fabsf(t - r) > 0.499f, 0)) {
+    if (__builtin_expect(fmaf(fabsf(t), EDADM_BAND_REL, fabsf(t - r)) > near_limit(), 0)) {
         asm volatile("" : "+v"(r));
         r = rintf(v / d);
     }
@@ -115,14 +123,14 @@ __device__ __forceinline__ float rint_div(float v, float d, float inv_d) {
 
 template <int NV>
 __device__ __forceinline__ void rint_div_n(const float (&v)[NV], float d, float inv_d, float (&r)[NV]) {
-    float worst = 0.f;                                     // max |t - rint(t)| of the group: one compare, one branch
+    float worst = 0.f;                                     // max band distance of the group: one compare, one branch
 #pragma unroll
     for (int e = 0; e < NV; ++e) {
         const float t = v[e] * inv_d;
         r[e] = rintf(t);
-        worst = fmaxf(worst, fabsf(t - r[e]));
+        worst = fmaxf(worst, fmaf(fabsf(t), EDADM_BAND_REL, fabsf(t - r[e])));
     }
-    if (__builtin_expect(worst > 0.499f, 0)) {
+    if (__builtin_expect(worst > near_limit(), 0)) {
 #pragma unroll
         for (int e = 0; e < NV; ++e) {
             asm volatile("" : "+v"(r[e]));
@@ -131,8 +139,7 @@ __device__ __forceinline__ void rint_div_n(const float (&v)[NV], float d, float 
     }
 }
 
-// rint(v / d) + z (z an integer-valued zero point): the addition rides in the multiply (one FMA), exact ties are
-// inside the 0.499 band and take the exact path, so the half-to-even decision is the reference's
+// rint(v / d) + z (z an integer-valued zero point): the addition rides in the multiply (one FMA)
 template <int NV>
 __device__ __forceinline__ void rint_div_zp_n(const float (&v)[NV], float d, float inv_d, float z, float (&r)[NV]) {
     float worst = 0.f;
@@ -140,9 +147,9 @@ __device__ __forceinline__ void rint_div_zp_n(const float (&v)[NV], float d, flo
     for (int e = 0; e < NV; ++e) {
         const float t = fmaf(v[e], inv_d, z);
         r[e] = rintf(t);
-        worst = fmaxf(worst, fabsf(t - r[e]));
+        worst = fmaxf(worst, fmaf(fabsf(t), EDADM_BAND_REL, fabsf(t - r[e])));
     }
-    if (__builtin_expect(worst > 0.499f, 0)) {
+    if (__builtin_expect(worst > near_limit(z), 0)) {
 #pragma unroll
         for (int e = 0; e < NV; ++e) {
             asm volatile("" : "+v"(r[e]));

@@ -9,7 +9,7 @@
 
 // (delta, zero point, qmax) as the host passes them; `inv` (the 4th float, unused by the host) is filled with
 // 1/delta when a kernel loads the entry: codes are rint(x * inv) with the exact division kept for the rare values
-// within 1e-3 of a rounding boundary (rint_div, common.h) -- the IEEE division costs ~12 instructions per element
+// inside the rounding-boundary band (rint_div, common.h) -- the IEEE division costs ~12 instructions per element
 // and made these producers ALU-bound instead of HBM-bound.
 struct QP { float d, z, qmax, inv; };
 __device__ __forceinline__ QP qp_load(const QP* p, int i) {
@@ -866,7 +866,7 @@ __global__ void __launch_bounds__(256) k_softmax_q_v4(const float* __restrict__ 
             for (int k = 0; k < 4; ++k) {
                 const float t = e[k] * inv;
                 r[k] = rintf(t);
-                near |= fabsf(t - r[k]) > 0.499f;
+                near |= fmaf(t, 3.6e-7f, fabsf(t - r[k])) > 0.5f - 4e-5f;      // relative band (attn.hip, common.h)
             }
             if (__builtin_expect(near, 0)) {
 #pragma unroll
