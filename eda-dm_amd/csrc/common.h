@@ -159,34 +159,38 @@ __device__ __forceinline__ void rint_div_zp_n(const float (&v)[NV], float d, flo
 }
 
 // GEGLU + quantise for the GEMM epilogue: codes r[e] = rint((val * gelu(gate)) / d) + z for NV (value, gate) pairs, equal
-// BIT FOR BIT to the exact form (erf_fast to < 1 ulp, IEEE division) at about half its instruction count.
-// Fast pass: 1 + erf(g / sqrt 2) by Abramowitz-Stegun 7.1.26 (one rcp, one exp2, five FMAs; |error| <= 1.5e-7 + fp32
-// evaluation, 5e-7 in all), reciprocal multiply for the division.  The rounded code can differ from the exact form's only
-// if t = y / d + z lies closer to a .5 boundary than the fast pass's error in t: |val gate| / d * 6e-7 (erf error and
-// product roundings, both proportional to |val gate|) + 2e-4 (roundings of t itself, |t| < 512; beyond that the clamp
-// saturates).  Groups with such an element redo all NV the exact way behind a real branch (a few % of the calls).
+// BIT FOR BIT to the exact form (erf_fast to < 1 ulp, IEEE division) at a third of its instruction count -- this epilogue is bound
+// by the vector ALU (tools/stamps.py: 12 k cycles per 256 x 192 tile against 3.7 k of MFMA), so the fast pass is written for
+// instruction count: 17 per pair.
+// Fast pass: with pe = poly(u) u exp(-g^2 / 2), u = 1 / (1 + p |g| / sqrt 2) (Abramowitz-Stegun 7.1.26: erf(|g| / sqrt 2) = 1 - pe,
+// |error| <= 1.5e-7), gate * (1 + erf(gate / sqrt 2)) = g + |g| (1 - pe) for either sign of g -- no select, no separate 2 - pe -- so
+//     t = val * (g + |g| (1 - pe)) * (0.5 / d) + z.
+// The absolute error of g + |g| (1 - pe) is |g| x (1.5e-7 + the roundings of pe, of 1 - pe and of the sum: 5e-7 in all), that of the
+// exact form's y a few 2^-24 |y|: the rounded code can differ from the exact form's only if t lies closer to a .5 boundary than
+// |val gate| / d * 1.2e-6 + 6e-5 (roundings of t itself and of the exact form's quotient, |t| < 512; beyond that the clamp
+// saturates).  Groups with such an element redo all NV the exact way behind a real branch (a few % of the wave groups).
 template <int NV>
 __device__ __forceinline__ void geglu_codes_n(const float (&val)[NV], const float (&gate)[NV], float d, float inv_d, float z,
                                               float (&r)[NV]) {
     float worst = 0.f;
+    const float hd = 0.5f * inv_d, kb = inv_d * 1.2e-6f;     // exact scaling / bound coefficient: uniform, hoisted
 #pragma unroll
     for (int e = 0; e < NV; ++e) {
         const float g = gate[e];
-        // x = |g| / sqrt 2 never materialises: 1 + p x = fma(|g|, p / sqrt 2, 1), and exp(-x^2) = exp2(-(|g| sqrt(log2(e) / 2))^2)
+        // x = |g| / sqrt 2 never materialises: 1 + p x = fma(|g|, p / sqrt 2, 1), and exp(-x^2) = exp2(-(g sqrt(log2(e) / 2))^2)
         const float u = __builtin_amdgcn_rcpf(fmaf(fabsf(g), 0.3275911f * 0.70710678118654752440f, 1.0f));
-        const float xe = fabsf(g) * 0.84932180028801904272f;
+        const float xe = g * 0.84932180028801904272f;
         float pl = fmaf(1.061405429f, u, -1.453152027f);
         pl = fmaf(pl, u, 1.421413741f);
         pl = fmaf(pl, u, -0.284496736f);
         pl = fmaf(pl, u, 0.254829592f);
-        const float pe = pl * u * __builtin_amdgcn_exp2f(-(xe * xe));
-        const float E = g >= 0.f ? 2.0f - pe : pe;          // 1 + erf(g / sqrt 2)
-        const float vg = val[e] * g;
-        const float t = fmaf(vg * E, 0.5f * inv_d, z);      // 0.5 inv_d: exact scaling, hoisted out of the loop by the compiler
+        const float om = fmaf(-__builtin_amdgcn_exp2f(-(xe * xe)), pl * u, 1.0f);      // erf(|g| / sqrt 2)
+        const float h = fmaf(fabsf(g), om, g);                                          // g (1 + erf(g / sqrt 2))
+        const float t = fmaf(val[e] * h, hd, z);
         r[e] = rintf(t);
-        worst = fmaxf(worst, fabsf(t - r[e]) + fmaf(fabsf(vg) * inv_d, 6e-7f, 2e-4f));
+        worst = fmaxf(worst, fmaf(fabsf(val[e]) * fabsf(g), kb, fabsf(t - r[e])));
     }
-    if (__builtin_expect(worst > 0.5f, 0)) {
+    if (__builtin_expect(worst > 0.5f - 6e-5f, 0)) {
 #pragma unroll
         for (int e = 0; e < NV; ++e) {
             asm volatile("" : "+v"(r[e]));

@@ -526,8 +526,14 @@ __device__ __forceinline__ void gemm_epilogue_qdirect(typename Acc<DT>::type (&a
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        asm volatile("" : "+v"(acc[i][j][4 * g + e]));     // read here (in place: no copy), not hoisted
-                        v[e] = (float)acc[i][j][4 * g + e];
+                        if constexpr (DT == 0) {
+                            // converted here, straight from the accumulator register (a volatile asm is not hoisted above the
+                            // dispatch; the "+v" form made the compiler copy each accumulator first: 4 of ~50 instructions per group)
+                            asm volatile("v_cvt_f32_i32 %0, %1" : "=v"(v[e]) : "v"(acc[i][j][4 * g + e]));
+                        } else {
+                            asm volatile("" : "+v"(acc[i][j][4 * g + e]));     // read here (in place: no copy), not hoisted
+                            v[e] = (float)acc[i][j][4 * g + e];
+                        }
                     }
                     v[0] = fmaf(v[0], s4.x, b4.x); v[1] = fmaf(v[1], s4.y, b4.y); v[2] = fmaf(v[2], s4.z, b4.z); v[3] = fmaf(v[3], s4.w, b4.w);
                     if (residual) {                        // the lane's four columns are one 16-byte piece of its row
