@@ -685,6 +685,9 @@ __device__ __forceinline__ void xcd_tile(unsigned& bx, unsigned& by) {
     bx = t - by * nx;
 }
 
+#ifndef EDADM_NT_PIPELINED
+#define EDADM_NT_PIPELINED 1
+#endif
 template <int DT, int TM, int TN>
 __global__ void __launch_bounds__(256, 2)      // two workgroups per CU: at most 256 registers (VGPR + AGPR) per lane
 k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const uint8_t* __restrict__ Bm,
@@ -848,6 +851,74 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
         if (p < nk) issue_tile(p, (int64_t)p * 64);
     STAMP(t_issued);
     STAMP(t_setup);
+    // K-step hand-off: tile t has landed once at most the `ahead` newer tiles' LPT loads each are still in flight; the barrier
+    // makes every wave's pieces visible and frees the slot of tile t - 1 for tile t + STAGES - 1
+    auto land = [&](int64_t t) {
+        const int64_t ahead = nk - 1 - t < STAGES - 2 ? nk - 1 - t : STAGES - 2;
+        if (ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPT) : "memory");
+        else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + STAGES - 1 < nk) issue_tile((int)((t + STAGES - 1) % STAGES), (t + STAGES - 1) * 64);
+    };
+    // DT != 3: the two 32-byte halves of a K-step live in two fragment sets; the reads of one set are in flight while the MFMAs of
+    // the other issue, ACROSS the hand-off of the next tile -- the wait, the barrier and the next tile's DMA issue sit between
+    // the MFMAs of half 0 and the reads of the next tile's half 0, with six MFMAs in the matrix pipe (tools/gemm_stamps.py: the
+    // plain order -- barrier, reads, MFMAs, reads, MFMAs -- spent twice the MFMAs' own time per K-step, waits excluded)
+    auto main_loop_pipelined = [&](auto swp) {
+        uint4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+        auto rd = [&](const uint8_t* As, const uint8_t* Bs, int ks, uint4 (&fa)[TM], uint4 (&fb)[TN]) {
+            const int c = 2 * ks + fh;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int r = wm * (TM * 32) + i * 32 + fr;
+                fa[i] = *reinterpret_cast<const uint4*>(As + (r * 4 + (c ^ ((r >> 2) & 3))) * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int r = wn * (TN * 32) + j * 32 + fr;
+                fb[j] = *reinterpret_cast<const uint4*>(Bs + (r * 4 + (c ^ ((r >> 2) & 3))) * 16);
+            }
+        };
+        auto mm = [&](uint4 (&fa)[TM], uint4 (&fb)[TN]) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (decltype(swp)::value) mma_step<DT>(fb[j], fa[i], acc[i][j]);
+                    else mma_step<DT>(fa[i], fb[j], acc[i][j]);
+                }
+        };
+        {
+            STAMP(ts0);
+            land(0);
+#ifdef EDADM_STAMPS
+            { STAMP(ts1); d_wait += ts1 - ts0; }
+#endif
+        }
+        rd(smem, smem + BM * 64, 0, fa0, fb0);
+        // the last K-step is peeled: inside the loop nothing about the reads is conditional, so the wait in front of the second
+        // MFMA group leaves the five reads of the next tile in flight (lgkmcnt counts in order)
+        for (int64_t kt = 0; kt + 1 < nk; ++kt) {
+            const uint8_t* As = smem + (int)(kt % STAGES) * TILE;
+            rd(As, As + BM * 64, 1, fa1, fb1);
+            mm(fa0, fb0);
+            STAMP(ts0);
+            land(kt + 1);
+#ifdef EDADM_STAMPS
+            { STAMP(ts1); d_wait += ts1 - ts0; }
+#endif
+            const uint8_t* An = smem + (int)((kt + 1) % STAGES) * TILE;
+            rd(An, An + BM * 64, 0, fa0, fb0);
+            mm(fa1, fb1);
+        }
+        const uint8_t* Al = smem + (int)((nk - 1) % STAGES) * TILE;
+        rd(Al, Al + BM * 64, 1, fa1, fb1);
+        mm(fa0, fb0);
+        mm(fa1, fb1);
+    };
     auto main_loop = [&](auto swp) {
     for (int64_t kt = 0; kt < nk; ++kt) {
         STAMP(ts0);
@@ -932,8 +1003,13 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
         }
     }
     };
-    if (qdirect) main_loop(std::true_type{});
-    else main_loop(std::false_type{});
+    if constexpr (DT != 3 && EDADM_NT_PIPELINED) {
+        if (qdirect) main_loop_pipelined(std::true_type{});
+        else main_loop_pipelined(std::false_type{});
+    } else {
+        if (qdirect) main_loop(std::true_type{});
+        else main_loop(std::false_type{});
+    }
     store_epilogue_consts<BN, RA>(ec, ek, tid);
     __syncthreads();
     STAMP(t_main);
@@ -1629,14 +1705,15 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
     if constexpr (DT == 0) {
         // persistent wave-specialised kernel: full 256-row tiles of the short-K, wide-N layers (the GEGLU projections:
         // many N tiles re-use each A block from L2), where a per-tile launch spends most of its life in prologue latency
-        // and epilogue.  Measured on the LDM-4 layer mix (tools/gemm_table.py, EDADM_GEMM_FORCE=2/3/5): narrow short-K
+        // and epilogue (K <= 512: since the 4-wave kernel prefetches its fragments across the K-step hand-off, round 4, it takes
+        // the 576- and 960-deep GEGLU projections 6 % faster than this one).  Measured on the LDM-4 layer mix (tools/gemm_table.py, EDADM_GEMM_FORCE=2/3/5): narrow short-K
         // layers are as fast or faster on the 4-wave kernel since the register-direct epilogues, long-K convolutions
         // on k_gemm_nt8.
         const int kstep = force == 6 ? 128 : 64;
         const int64_t ptiles = (M / 256) * (N / (64 * tn));
         if (force != 2 && force != 3 && !gn_ws && batch == 1 && inner == 1 && tn >= 2 && M % 256 == 0 && N % (64 * tn) == 0 &&
             (Kb + kstep - 1) / kstep >= 3 && (!rowadd || rpb >= 64) && (out_mode == 0 || (!rowadd && (!residual || !(ldr & 3)))) &&
-            (force >= 5 || (ptiles >= 224 && Kb <= 1024 && N >= 1024)) && (g.mode == 0 || (int64_t)g.B * g.H * g.W * g.Cin < (1ll << 31))) {
+            (force >= 5 || (ptiles >= 224 && Kb <= 512 && N >= 1024)) && (g.mode == 0 || (int64_t)g.B * g.H * g.W * g.Cin < (1ll << 31))) {
             static int ncu = 0;
             if (!ncu) {
                 int dev = 0;
