@@ -512,6 +512,14 @@ __device__ __forceinline__ void gemm_epilogue_qdirect(typename Acc<DT>::type (&a
     const bool hi = fh4 != 0;
     auto body = [&](auto mode_tag) {
         constexpr int MODE = decltype(mode_tag)::value;
+        // residual: the 16-byte piece of group q + 1 is requested before group q is processed (one piece in flight: loaded where
+        // it was used, every group waited out a memory round trip -- +33 us on the 102400 x 384 x 1536 ff.net.2 layer)
+        auto res_piece = [&](int q) {
+            const int j = q / (TM * 4), i = (q / 4) % TM, g = q & 3;
+            return *reinterpret_cast<const float4*>(residual + (row0 + i * 32 + fr) * ldr + col0 + j * 32 + 8 * g + fh4);
+        };
+        float4 rnext = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (residual) rnext = res_piece(0);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
 #pragma unroll
@@ -537,8 +545,10 @@ __device__ __forceinline__ void gemm_epilogue_qdirect(typename Acc<DT>::type (&a
                     }
                     v[0] = fmaf(v[0], s4.x, b4.x); v[1] = fmaf(v[1], s4.y, b4.y); v[2] = fmaf(v[2], s4.z, b4.z); v[3] = fmaf(v[3], s4.w, b4.w);
                     if (residual) {                        // the lane's four columns are one 16-byte piece of its row
-                        const int64_t col = col0 + j * 32 + 8 * g + fh4;
-                        const float4 r4 = *reinterpret_cast<const float4*>(residual + (row0 + i * 32 + fr) * ldr + col);
+                        const float4 r4 = rnext;
+                        constexpr int QN = TN * TM * 4;
+                        const int q = (j * TM + i) * 4 + g;
+                        if (q + 1 < QN) rnext = res_piece(q + 1);
                         v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
                     }
                     if constexpr (MODE == 3) {             // GEGLU on interleaved (a, gate) columns -> two int8 codes
@@ -1058,6 +1068,151 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
     gemm_epilogue<DT, TM, TN, BN, RA, (TN % 2 == 0 || TN == 3) ? 4 : 2>(acc, smem, ec, wave, lane, m0, m0 + wm * (TM * 32), n0 + wn * (TN * 32),
                                       wn * (TN * 32), M, N, rows_per_batch, rowadd != nullptr, residual, ldr, out, ldo, out_mode);
     stamp_out();
+}
+
+// ---- persistent form of the 4-wave kernel for the QUANTISED-output dense layers (q / k / v projections, ff.net.2, the deeper GEGLU
+// projections: int8, full 128 x (64 TN) tiles, out_mode 1..4, no row add).  tools/gemm_stamps.py prices a 384-deep tile of k_gemm_nt
+// at 23 k cycles of which 5.5 k are set-up (addresses, constants, the first two stages requested) and 4 k the wait for them: a
+// workgroup here walks tiles L, L + grid, ... and requests the NEXT tile's constants and first STAGES - 1 stages right after its
+// main loop, in front of the epilogue -- whose arithmetic (8-9 k cycles of the vector ALU) then covers their latency.  The
+// register-direct epilogue does not touch the operand ring, and the hand-counted waits stay valid: the epilogue's few stores are
+// NEWER than the prefetched stages, so vmcnt(LPT) at the next tile's first hand-off covers both (at most over-waiting for stores
+// that are long done).  fp32-output layers stay on k_gemm_nt: their 96 stores per lane would sit in the in-order queue in front of
+// the next tile's K-steps, and a workgroup that ENDS lets the hardware drain them under the next workgroup's start instead.
+template <int TN>
+__global__ void __launch_bounds__(256, 2)
+k_gemm_ntq(const uint8_t* __restrict__ A, int64_t lda_b, const uint8_t* __restrict__ Bm, int64_t ldb_b, int64_t M, int64_t N,
+           int64_t Kb, const float* __restrict__ scale, const float* __restrict__ bias, const float* __restrict__ residual,
+           int64_t ldr, float* __restrict__ out, int64_t ldo, float alpha, int out_mode, const float* __restrict__ oqp,
+           int64_t rows_per_batch) {
+    constexpr int DT = 0, TM = 2, BM = 128, BN = 64 * TN, NA = 2, NB = TN, LPT = NA + NB;
+    constexpr int STAGES = EDADM_GEMM_STAGES, TILE = (BM + BN) * 64, RA = 1;
+    constexpr int EC_BYTES = (2 + RA) * BN * 4 + 16;
+    __shared__ __attribute__((aligned(16))) uint8_t smem[STAGES * TILE + EC_BYTES];
+    float* ec = reinterpret_cast<float*>(smem + STAGES * TILE);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int sr = tid >> 2, sc = (tid & 3) ^ ((tid >> 4) & 3);      // staging row / logical 16-byte chunk (k_gemm_nt's LDS image)
+    const int fr = lane & 31, fh = lane >> 5;
+    const uint8_t* zero_row = g_pad_rows;
+    const unsigned nx = (unsigned)(N / BN), T = nx * (unsigned)(M / BM);
+    const int64_t nk = (Kb + 63) / 64;
+
+    // per-tile state in plain scalars (arrays of pointers captured by the lambdas below went to scratch -- and a scratch load in
+    // front of every DMA piece is a vmcnt(0))
+    int64_t m0 = 0, n0 = 0, a_off = 0, b_off = 0;
+    float ks = 0.f, kbias = 0.f, koq = 0.f;
+    auto setup = [&](unsigned L) {                             // tile L in the XCD-aware order (xcd_tile), its addresses and constants
+        unsigned t = L;
+        if (EDADM_XCD_ORDER && T >= 16) {
+            const unsigned k = L & 7, j = L >> 3, q = T >> 3, r = T & 7;
+            t = k * q + (k < r ? k : r) + j;
+        }
+        const unsigned by = t / nx, bx = t - by * nx;
+        m0 = (int64_t)by * BM;
+        n0 = (int64_t)bx * BN;
+        a_off = (m0 + sr) * lda_b + sc * 16;
+        b_off = (n0 + sr) * ldb_b + sc * 16;
+        koq = tid < 3 ? oqp[tid] : 0.f;
+        if (tid < BN) {
+            ks = scale ? scale[n0 + tid] : alpha;
+            kbias = bias ? bias[n0 + tid] : 0.f;
+        }
+    };
+    auto issue_tile = [&](int stage, int64_t kb) {
+        const bool kin = kb + sc * 16 < Kb;
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            glds16(kin ? A + a_off + 64 * i * lda_b + kb : zero_row, lds0 + (uint32_t)(stage * TILE + i * 4096 + wave * 1024));
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            glds16(kin ? Bm + b_off + 64 * i * ldb_b + kb : zero_row, lds0 + (uint32_t)(stage * TILE + BM * 64 + i * 4096 + wave * 1024));
+    };
+    auto prologue = [&]() {
+#pragma unroll
+        for (int p = 0; p < STAGES - 1; ++p)
+            if (p < nk) issue_tile(p, (int64_t)p * 64);
+    };
+    auto land = [&](int64_t t) {
+        const int64_t ahead = nk - 1 - t < STAGES - 2 ? nk - 1 - t : STAGES - 2;
+        if (ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPT) : "memory");
+        else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + STAGES - 1 < nk) issue_tile((int)((t + STAGES - 1) % STAGES), (t + STAGES - 1) * 64);
+    };
+    typename Acc<DT>::type acc[TM][TN];
+    uint4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+    auto rd = [&](const uint8_t* As, const uint8_t* Bs, int ks_, uint4 (&fa)[TM], uint4 (&fb)[TN]) {
+        const int c = 2 * ks_ + fh;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int r = wm * (TM * 32) + i * 32 + fr;
+            fa[i] = *reinterpret_cast<const uint4*>(As + (r * 4 + (c ^ ((r >> 2) & 3))) * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int r = wn * (TN * 32) + j * 32 + fr;
+            fb[j] = *reinterpret_cast<const uint4*>(Bs + (r * 4 + (c ^ ((r >> 2) & 3))) * 16);
+        }
+    };
+    auto mm = [&](uint4 (&fa)[TM], uint4 (&fb)[TN]) {      // operands swapped: the transposed block of the quantising epilogue
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) mma_step<DT>(fb[j], fa[i], acc[i][j]);
+    };
+
+    unsigned L = blockIdx.x;
+    if (L >= T) return;
+    setup(L);
+    prologue();
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+        land(0);
+        rd(smem, smem + BM * 64, 0, fa0, fb0);
+        for (int64_t kt = 0; kt + 1 < nk; ++kt) {
+            const uint8_t* As = smem + (int)(kt % STAGES) * TILE;
+            rd(As, As + BM * 64, 1, fa1, fb1);
+            mm(fa0, fb0);
+            land(kt + 1);
+            const uint8_t* An = smem + (int)((kt + 1) % STAGES) * TILE;
+            rd(An, An + BM * 64, 0, fa0, fb0);
+            mm(fa1, fb1);
+        }
+        const uint8_t* Al = smem + (int)((nk - 1) % STAGES) * TILE;
+        rd(Al, Al + BM * 64, 1, fa1, fb1);
+        mm(fa0, fb0);
+        mm(fa1, fb1);
+        // this tile's constants to LDS (every wave passed a hand-off barrier since the previous epilogue read them)
+        const int64_t m0c = m0, n0c = n0;
+        if (tid < 3) ec[(2 + RA) * BN + tid] = koq;
+        if (tid < BN) {
+            ec[tid] = ks;
+            ec[BN + tid] = kbias;
+            ec[2 * BN + tid] = 0.f;
+        }
+        __syncthreads();                                       // constants visible; every wave is done with the operand ring
+        const unsigned Ln = L + gridDim.x;
+        const bool more = Ln < T;
+        if (more) {                                            // next tile: addresses, constants, first stages -- before the epilogue
+            setup(Ln);
+            prologue();
+        }
+        gemm_epilogue_qdirect<DT, TM, TN, BN, RA>(acc, ec, lane, m0c + wm * (TM * 32), n0c + wn * (TN * 32), wn * (TN * 32), out, ldo,
+                                                  out_mode, residual, ldr, rows_per_batch, N);
+        if (!more) break;
+        L = Ln;
+    }
 }
 
 // ---- 8-wave variant for the large-M layers: 256 x (64*TN) tile, 128-byte K rows (full cache lines per
@@ -1733,6 +1888,32 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
             EDADM_GEMMP_CASE(3, 128)
             EDADM_GEMMP_CASE(2, 128)
 #undef EDADM_GEMMP_CASE
+        }
+    }
+    if constexpr (DT == 0) {
+        // quantised-output dense layers on full tiles: the persistent 4-wave kernel (next tile's first stages requested in front
+        // of the epilogue); two workgroups per CU, each walks its share of the tiles
+        static const int64_t ntq = EDADM_TUNE_I("EDADM_GEMM_NTQ", 1);
+        const bool aligned_out = out_mode == 4 || ((((uintptr_t)out) & 15) == 0 && ((ldo * (out_mode == 1 ? 2 : 1)) & 15) == 0);
+        if (ntq && force == 0 && out_mode != 0 && g.mode == 0 && batch == 1 && inner == 1 && !rowadd && !gn_ws && tn >= 2 &&
+            M % 128 == 0 && N % (64 * tn) == 0 && Kb >= 64 && aligned_out && (!residual || !(ldr & 3)) &&
+            (M / 128) * (N / (64 * tn)) >= 512) {
+            static int ncu_q = 0;
+            if (!ncu_q) {
+                int dev = 0;
+                (void)hipGetDevice(&dev);
+                (void)hipDeviceGetAttribute(&ncu_q, hipDeviceAttributeMultiprocessorCount, dev);
+                ncu_q = ncu_q >= 8 ? ncu_q & ~7 : 8;
+            }
+            const int64_t tiles = (M / 128) * (N / (64 * tn));
+            const unsigned gq = (unsigned)(tiles < 2 * ncu_q ? tiles : 2 * ncu_q);
+            if (tn == 3)
+                hipLaunchKernelGGL((k_gemm_ntq<3>), dim3(gq), dim3(256), 0, st, (const uint8_t*)A, lda_b, (const uint8_t*)Bm, ldb_b, M, N, Kb,
+                                   scale, bias, residual, ldr, out, ldo, alpha, out_mode, oqp, rpb);
+            else
+                hipLaunchKernelGGL((k_gemm_ntq<2>), dim3(gq), dim3(256), 0, st, (const uint8_t*)A, lda_b, (const uint8_t*)Bm, ldb_b, M, N, Kb,
+                                   scale, bias, residual, ldr, out, ldo, alpha, out_mode, oqp, rpb);
+            return edadm_launch_status();
         }
     }
     // K <= 2048 (the 192-channel 3x3 convolutions, ff.net.2): with the register-direct epilogues the 4-wave tile at two
