@@ -520,6 +520,17 @@ __device__ __forceinline__ void gemm_epilogue_qdirect(typename Acc<DT>::type (&a
         };
         float4 rnext = make_float4(0.f, 0.f, 0.f, 0.f);
         if (residual) rnext = res_piece(0);
+        // column constants of group q + 1 are read from LDS before group q is processed (EDADM_EPI_CONST_AHEAD): each group is
+        // its own basic block (the exact-division branch), so a read placed where it is used waits out the LDS latency alone
+        constexpr int QN = TN * TM * 4;
+        auto const_pair = [&](int q, float4& s4, float4& b4) {
+            const int j = q / (TM * 4), g = q & 3;
+            const int ecol = ecol0 + j * 32 + 8 * g + fh4;
+            s4 = *reinterpret_cast<const float4*>(ec + ecol);
+            b4 = *reinterpret_cast<const float4*>(ec + BN + ecol);
+        };
+        float4 s4n, b4n;
+        const_pair(0, s4n, b4n);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
 #pragma unroll
@@ -528,9 +539,11 @@ __device__ __forceinline__ void gemm_epilogue_qdirect(typename Acc<DT>::type (&a
                 const int64_t ro = rbase + (int64_t)(i * 32) * ldo;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int ecol = ecol0 + j * 32 + 8 * g + fh4;
-                    const float4 s4 = *reinterpret_cast<const float4*>(ec + ecol);
-                    const float4 b4 = *reinterpret_cast<const float4*>(ec + BN + ecol);
+                    const float4 s4 = s4n, b4 = b4n;
+                    {
+                        const int qc = (j * TM + i) * 4 + g;
+                        if (qc + 1 < QN) const_pair(qc + 1, s4n, b4n);
+                    }
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -546,7 +559,6 @@ __device__ __forceinline__ void gemm_epilogue_qdirect(typename Acc<DT>::type (&a
                     v[0] = fmaf(v[0], s4.x, b4.x); v[1] = fmaf(v[1], s4.y, b4.y); v[2] = fmaf(v[2], s4.z, b4.z); v[3] = fmaf(v[3], s4.w, b4.w);
                     if (residual) {                        // the lane's four columns are one 16-byte piece of its row
                         const float4 r4 = rnext;
-                        constexpr int QN = TN * TM * 4;
                         const int q = (j * TM + i) * 4 + g;
                         if (q + 1 < QN) rnext = res_piece(q + 1);
                         v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
@@ -695,6 +707,9 @@ __device__ __forceinline__ void xcd_tile(unsigned& bx, unsigned& by) {
     bx = t - by * nx;
 }
 
+#ifndef EDADM_NTQ_DEFAULT
+#define EDADM_NTQ_DEFAULT 1
+#endif
 #ifndef EDADM_NT_PIPELINED
 #define EDADM_NT_PIPELINED 1
 #endif
@@ -1866,7 +1881,8 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
         // on k_gemm_nt8.
         const int kstep = force == 6 ? 128 : 64;
         const int64_t ptiles = (M / 256) * (N / (64 * tn));
-        if (force != 2 && force != 3 && !gn_ws && batch == 1 && inner == 1 && tn >= 2 && M % 256 == 0 && N % (64 * tn) == 0 &&
+        static const int64_t use_p = EDADM_TUNE_I("EDADM_GEMM_P", 1);          // diagnostic build only
+        if (use_p && force != 2 && force != 3 && !gn_ws && batch == 1 && inner == 1 && tn >= 2 && M % 256 == 0 && N % (64 * tn) == 0 &&
             (Kb + kstep - 1) / kstep >= 3 && (!rowadd || rpb >= 64) && (out_mode == 0 || (!rowadd && (!residual || !(ldr & 3)))) &&
             (force >= 5 || (ptiles >= 224 && Kb <= 512 && N >= 1024)) && (g.mode == 0 || (int64_t)g.B * g.H * g.W * g.Cin < (1ll << 31))) {
             static int ncu = 0;
@@ -1893,7 +1909,7 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
     if constexpr (DT == 0) {
         // quantised-output dense layers on full tiles: the persistent 4-wave kernel (next tile's first stages requested in front
         // of the epilogue); two workgroups per CU, each walks its share of the tiles
-        static const int64_t ntq = EDADM_TUNE_I("EDADM_GEMM_NTQ", 1);
+        static const int64_t ntq = EDADM_TUNE_I("EDADM_GEMM_NTQ", EDADM_NTQ_DEFAULT);
         const bool aligned_out = out_mode == 4 || ((((uintptr_t)out) & 15) == 0 && ((ldo * (out_mode == 1 ? 2 : 1)) & 15) == 0);
         if (ntq && force == 0 && out_mode != 0 && g.mode == 0 && batch == 1 && inner == 1 && !rowadd && !gn_ws && tn >= 2 &&
             M % 128 == 0 && N % (64 * tn) == 0 && Kb >= 64 && aligned_out && (!residual || !(ldr & 3)) &&

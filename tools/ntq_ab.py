@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) == 1:
     for rep in range(2):
         for f in ("1", "0"):
-            env = dict(os.environ, EDADM_GEMM_NTQ=f, EDADM_LIB_PATH=os.path.join(ROOT, "eda-dm_amd", "csrc", "libedadm_diag.so"))
+            env = dict(os.environ, EDADM_GEMM_NTQ=f, EDADM_GEMM_P=os.environ.get("EDADM_GEMM_P", "1"), EDADM_LIB_PATH=os.path.join(ROOT, "eda-dm_amd", "csrc", "libedadm_diag.so"))
             r = subprocess.run([sys.executable, os.path.abspath(__file__), f], env=env, capture_output=True, text=True)
             print(r.stdout, end="")
             if r.returncode:
@@ -29,7 +29,7 @@ def timeit(fn, n=10):
 oqp = torch.tensor([0.05, 128.0, 255.0, 0.0], device=dev)
 row = ["NTQ=%s" % sys.argv[1]]
 ref = {}
-for M, N, K, mode, res in ((102400, 384, 384, 1, 0), (102400, 384, 384, 2, 0), (25600, 576, 576, 1, 0), (6400, 960, 960, 1, 0), (102400, 384, 1536, 2, 1),
+for M, N, K, mode, res in ((102400, 3072, 384, 3, 0), (102400, 384, 384, 1, 0), (102400, 384, 384, 2, 0), (25600, 576, 576, 1, 0), (6400, 960, 960, 1, 0), (102400, 384, 1536, 2, 1),
                            (25600, 576, 2304, 2, 1), (6400, 960, 3840, 2, 1), (25600, 4608, 576, 3, 0), (6400, 7680, 960, 3, 0)):
     a = torch.randint(-128, 128, (M, K), dtype=torch.int8, device=dev)
     w = torch.randint(-8, 9, (N, K), dtype=torch.int8, device=dev)
