@@ -1094,14 +1094,15 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
 // NEWER than the prefetched stages, so vmcnt(LPT) at the next tile's first hand-off covers both (at most over-waiting for stores
 // that are long done).  fp32-output layers stay on k_gemm_nt: their 96 stores per lane would sit in the in-order queue in front of
 // the next tile's K-steps, and a workgroup that ENDS lets the hardware drain them under the next workgroup's start instead.
-template <int TN>
-__global__ void __launch_bounds__(256, 2)
+template <int TN, int STAGES, int WGS>
+__global__ void __launch_bounds__(256, WGS)
 k_gemm_ntq(const uint8_t* __restrict__ A, int64_t lda_b, const uint8_t* __restrict__ Bm, int64_t ldb_b, int64_t M, int64_t N,
            int64_t Kb, const float* __restrict__ scale, const float* __restrict__ bias, const float* __restrict__ residual,
            int64_t ldr, float* __restrict__ out, int64_t ldo, float alpha, int out_mode, const float* __restrict__ oqp,
            int64_t rows_per_batch) {
     constexpr int DT = 0, TM = 2, BM = 128, BN = 64 * TN, NA = 2, NB = TN, LPT = NA + NB;
-    constexpr int STAGES = EDADM_GEMM_STAGES, TILE = (BM + BN) * 64, RA = 1;
+    constexpr int TILE = (BM + BN) * 64, RA = 1;
+    static_assert((STAGES - 2) * LPT <= 63, "vmcnt is a 6-bit counter");
     constexpr int EC_BYTES = (2 + RA) * BN * 4 + 16;
     __shared__ __attribute__((aligned(16))) uint8_t smem[STAGES * TILE + EC_BYTES];
     float* ec = reinterpret_cast<float*>(smem + STAGES * TILE);
@@ -1152,10 +1153,14 @@ k_gemm_ntq(const uint8_t* __restrict__ A, int64_t lda_b, const uint8_t* __restri
     };
     auto land = [&](int64_t t) {
         const int64_t ahead = nk - 1 - t < STAGES - 2 ? nk - 1 - t : STAGES - 2;
-        if (ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPT) : "memory");
-        else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        switch ((int)ahead) {                                   // at most `ahead` newer tiles' pieces may still be in flight
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT < 63 ? 2 * LPT : 63) : "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPT < 63 ? 3 * LPT : 63) : "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * LPT < 63 ? 4 * LPT : 63) : "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * LPT < 63 ? 5 * LPT : 63) : "memory"); break;
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (t + STAGES - 1 < nk) issue_tile((int)((t + STAGES - 1) % STAGES), (t + STAGES - 1) * 64);
@@ -1923,12 +1928,14 @@ static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm,
             }
             const int64_t tiles = (M / 128) * (N / (64 * tn));
             const unsigned gq = (unsigned)(tiles < 2 * ncu_q ? tiles : 2 * ncu_q);
+            // (measured and dropped: one workgroup per CU with a 7-stage ring, k_gemm_ntq<3, 7, 1> -- 41 -> 68 us on 102400 x 384 x 384,
+            // 155 -> 205 us at K = 1536: one wave per SIMD does not keep the matrix pipe fed however deep the prefetch)
             if (tn == 3)
-                hipLaunchKernelGGL((k_gemm_ntq<3>), dim3(gq), dim3(256), 0, st, (const uint8_t*)A, lda_b, (const uint8_t*)Bm, ldb_b, M, N, Kb,
-                                   scale, bias, residual, ldr, out, ldo, alpha, out_mode, oqp, rpb);
+                hipLaunchKernelGGL((k_gemm_ntq<3, EDADM_GEMM_STAGES, 2>), dim3(gq), dim3(256), 0, st, (const uint8_t*)A, lda_b, (const uint8_t*)Bm,
+                                   ldb_b, M, N, Kb, scale, bias, residual, ldr, out, ldo, alpha, out_mode, oqp, rpb);
             else
-                hipLaunchKernelGGL((k_gemm_ntq<2>), dim3(gq), dim3(256), 0, st, (const uint8_t*)A, lda_b, (const uint8_t*)Bm, ldb_b, M, N, Kb,
-                                   scale, bias, residual, ldr, out, ldo, alpha, out_mode, oqp, rpb);
+                hipLaunchKernelGGL((k_gemm_ntq<2, EDADM_GEMM_STAGES, 2>), dim3(gq), dim3(256), 0, st, (const uint8_t*)A, lda_b, (const uint8_t*)Bm,
+                                   ldb_b, M, N, Kb, scale, bias, residual, ldr, out, ldo, alpha, out_mode, oqp, rpb);
             return edadm_launch_status();
         }
     }

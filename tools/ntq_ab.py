@@ -3,7 +3,7 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) == 1:
     for rep in range(2):
-        for f in ("1", "0"):
+        for f in os.environ.get("NTQ_SET", "1,0").split(","):
             env = dict(os.environ, EDADM_GEMM_NTQ=f, EDADM_GEMM_P=os.environ.get("EDADM_GEMM_P", "1"), EDADM_LIB_PATH=os.path.join(ROOT, "eda-dm_amd", "csrc", "libedadm_diag.so"))
             r = subprocess.run([sys.executable, os.path.abspath(__file__), f], env=env, capture_output=True, text=True)
             print(r.stdout, end="")
