@@ -125,7 +125,11 @@ class FusedAdam:
             t = self.t + k
             lr = self.lr0 * (1 + math.cos(math.pi * t / self.t_max)) / 2
             rows.append([lr / (1 - b1 ** (t + 1)), math.sqrt(1 - b2 ** (t + 1)), b1, b2])
-        self.table, self.t0 = torch.tensor(rows, dtype=torch.float32).to(self.hyper.device), self.t
+        host = torch.tensor(rows, dtype=torch.float32)
+        if self.hyper.is_cuda:                               # pinned staging: the copy is asynchronous, the unit's set-up does not block
+            host = host.pin_memory()
+        self.table, self.t0 = host.to(self.hyper.device, non_blocking=True), self.t
+        self._table_host = host                              # keeps the pinned buffer alive until the copy has run
         return self.table
 
     def prepare_row(self):
@@ -355,7 +359,8 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
     # work and launches save (measured on LDM-4: 8x8 units 7.5 -> 5.2 ms per iteration, 16x16 and 32x32 8.9 -> 7.4, but 64x64 7.5 -> 9.2)
     if batched and cached_outs.dim() == 4 and cached_outs.shape[-1] * cached_outs.shape[-2] >= BATCH_FORWARDS_BELOW_PIXELS:
         batched = False
-    STATE["batched"] = batched
+    STATE["batched"] = batched                                # mirror of the LAST unit for the parity tests' mask replay ...
+    unit.recon_batched = batched                              # ... the unit carries its own flag (interleaved reconstructions)
 
     def body():
         idx_t = idx_buf
@@ -413,7 +418,21 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
     # drawn / computed for ALL iterations up front (same `random.sample` sequence) and sits in device tables: an iteration is two
     # or three asynchronous device-to-device row copies + one graph replay, the host runs ahead and the stream never drains
     # between iterations (a pageable host-to-device copy per iteration blocked on the previous replay).
-    idx_all = torch.tensor([random.sample(range(sz), batch_size) for _ in range(iters)], dtype=torch.long).to(idx_buf.device)
+    # every minibatch draw of the unit up front (the reference's random.sample stream, block_recon.py:137), in chunks of 1024
+    # iterations through pinned memory: bounded host memory for the reference's default of 20000 iterations, no blocking copy
+    IDX_CHUNK = 1024
+    idx_host, idx_dev = [], []
+    for c0 in range(0, iters, IDX_CHUNK):
+        h = torch.tensor([random.sample(range(sz), batch_size) for _ in range(min(IDX_CHUNK, iters - c0))], dtype=torch.long).reshape(-1, batch_size)
+        if idx_buf.is_cuda:
+            h = h.pin_memory()
+        idx_host.append(h)
+        idx_dev.append(h.to(idx_buf.device, non_blocking=True))
+
+    class _Idx:
+        def __getitem__(self, it):
+            return idx_dev[it // IDX_CHUNK][it % IDX_CHUNK]
+    idx_all = _Idx()
     for o in (w_opt, a_opt):
         if o:
             o.schedule(iters)
