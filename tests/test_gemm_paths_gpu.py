@@ -304,6 +304,36 @@ def test_implicit_gemm_groupnorm_partials_equal_the_direct_convolutions(ops, B, 
         assert torch.equal(out_d, out) and torch.equal(ws_d, ws)
 
 
+@pytest.mark.parametrize("M,N,K,mode,res", [(65536, 384, 384, 1, False), (65536, 384, 384, 2, False), (32768, 384, 1536, 2, True),
+                                            (16384, 4608, 576, 3, False), (65536, 384, 384, 4, False), (40960, 256, 320, 1, False)])
+def test_persistent_quantised_output_kernel_bit_identical_to_per_tile_launches(ops, M, N, K, mode, res):
+    """k_gemm_ntq (csrc/gemm.hip): launches of >= 512 full tiles with a quantised output walk their tiles persistently and request
+    the next tile's operands in front of the epilogue; the same rows in slices of fewer than 512 tiles take k_gemm_nt (one tile per
+    workgroup).  Integer accumulation and one epilogue: the same bytes, for f16 codes, int8 codes (+ residual), GEGLU and the
+    transposed f16 form (quant_layer.py:406-437 + the consumer's quantiser, quant_block.py:128-162)."""
+    g = torch.Generator().manual_seed(M // 128 + N + K + mode)
+    a = torch.randint(-128, 128, (M, K), generator=g, dtype=torch.int8).cuda()
+    w = torch.randint(-8, 9, (N, K), generator=g, dtype=torch.int8).cuda()
+    scale, bias = (torch.rand(N, generator=g) * 2e-3 + 1e-4).cuda(), torch.randn(N, generator=g).cuda()
+    r = torch.randn(M, N, generator=g).cuda() if res else None
+    oqp = ops.qp_tensor([(0.03, 117.0, 255.0)], torch.device("cuda"))
+    tn = 192 if N % 192 == 0 else 128
+    assert (M // 128) * (N // tn) >= 512
+    rpb = 1024 if mode == 4 else 1
+    big = ops.qgemm_i8_q(a, w, M, N, K, scale, bias, mode, oqp, residual=r, rows_per_batch=rpb)
+    rows = 128 * max(1, 511 // (N // tn))                     # slices of < 512 tiles
+    if mode == 4:
+        rows = max(rpb, rows // rpb * rpb)
+    parts = []
+    for m0 in range(0, M, rows):
+        m1 = min(M, m0 + rows)
+        parts.append(ops.qgemm_i8_q(a[m0:m1], w, m1 - m0, N, K, scale, bias, mode, oqp, residual=None if r is None else r[m0:m1],
+                                    rows_per_batch=rpb))
+    small = torch.cat(parts)
+    assert big.shape == small.shape and torch.equal(big, small)
+    assert float(big.float().abs().sum()) > 0
+
+
 @pytest.mark.parametrize("M,N,K1,K2", [(1024, 192, 192, 192), (2048, 384, 576, 384), (640, 960, 960, 960), (4096, 192, 384, 192), (256, 576, 1152, 384)])
 def test_split_quantiser_layer_in_one_launch_bit_identical_to_two(M, N, K1, K2):
     """K4s (csrc/gemm.hip, edadm_qgemm_i8_split2): the 1x1 skip convolution over [h | skip] with two activation / weight quantisers
