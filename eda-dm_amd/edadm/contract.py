@@ -89,6 +89,48 @@ def _matmul_nt(a2d, w2d, bias=None, amax=None):
 
 
 WGRAD_SWAP = True
+# The weight gradient of a layer depends on nothing the rest of backward produces: its kernels (operand transposition / expansion, the
+# split-K product, the slab sum) go to a second HIP stream, forked after dY is known and joined at the end of the layer's backward, next
+# to the input gradient on the current stream.  Same kernels on the same data -- same bits.  Inside a graph capture the fork / join
+# become parallel branches of the captured iteration.  Measured (tools/recon_time.py, SIDE_WGRAD=1 / 0): ResBlocks 3-5 % faster at
+# every level (192 @ 64x64 5.78 -> 5.53 ms, 960 @ 8x8 2.66 -> 2.54, the up block 384 -> 192 @ 64x64 14.28 -> 13.74).
+SIDE_WGRAD = True
+SIDE_LINEAR_MAX_ROWS = 4096
+_SIDE = {}
+
+
+def _side_stream(dev):
+    s = _SIDE.get(dev.index)
+    if s is None:
+        s = _SIDE[dev.index] = torch.cuda.Stream(dev)
+    return s
+
+
+class _Fork:
+    """with _Fork(t, on): ...  runs the body on the side stream of t's device, ordered after everything enqueued so far on the current
+    stream; join() makes the current stream wait for it."""
+
+    def __init__(self, t, on):
+        self.on = bool(on) and t.is_cuda
+        if self.on:
+            self.cur = torch.cuda.current_stream(t.device)
+            self.side = _side_stream(t.device)
+            self.ctx = torch.cuda.stream(self.side)
+
+    def __enter__(self):
+        if self.on:
+            self.side.wait_stream(self.cur)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        if self.on:
+            self.ctx.__exit__(*a)
+        return False
+
+    def join(self):
+        if self.on:
+            self.cur.wait_stream(self.side)
 
 
 def _wgrad_product(gt, at, S, O, K, Ms):
@@ -174,13 +216,18 @@ class _LinearFn(torch.autograd.Function):
         pg = _amax(gy2p) if gy2p is gy2 else None
         gx = gw = gb = None
         FLOPS[0] += 2.0 * gy2.shape[0] * wp.shape[0] * K * (int(ctx.needs_input_grad[0]) + int(ctx.needs_input_grad[1]))
+        # linear layers: only where the two halves leave the GPU under-filled (the 8x8 level: tools/recon_time.py, transformer block
+        # 960 @ 8x8 5.08 -> 4.88 ms; at 16x16 / 32x32 the side stream costs 1 %)
+        fork = _Fork(gy2, SIDE_WGRAD and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and gy2.shape[0] <= SIDE_LINEAR_MAX_ROWS)
+        if ctx.needs_input_grad[1]:
+            with fork:
+                gw = _wgrad(gy2, x2p, amax_g=pg, amax_a=ctx.px)[:, :K].contiguous()
         if ctx.needs_input_grad[0]:
             wT, _ = _pad4(ops.transpose_f32(wp))                                   # [Kp][O]
             gx = _matmul_nt(gy2p, wT, amax=pg)[:, :K].reshape(xshape)
-        if ctx.needs_input_grad[1]:
-            gw = _wgrad(gy2, x2p, amax_g=pg, amax_a=ctx.px)[:, :K].contiguous()
         if has_bias and ctx.needs_input_grad[2]:
             gb = gy2.sum(0)
+        fork.join()
         return gx, gw, gb
 
 
@@ -232,6 +279,14 @@ class _Conv2dFn(torch.autograd.Function):
         pg = _amax(gyh)
         gx = gw = gb = None
         FLOPS[0] += 2.0 * B * Ho * Wo * O * KH * KW * C * (int(ctx.needs_input_grad[0]) + int(ctx.needs_input_grad[1]))
+        fork = _Fork(gyh, SIDE_WGRAD and ctx.needs_input_grad[0] and ctx.needs_input_grad[1])
+        if ctx.needs_input_grad[1]:
+            with fork:
+                if one:
+                    gw2 = _wgrad(gyh, xh.reshape(B * H * W, Cp), amax_g=pg, amax_a=ctx.px)
+                else:                                                                     # [O][KH*KW*Cp]
+                    gw2 = _wgrad(gyh, None, amax_g=pg, amax_a=ctx.px, conv=(xh, (KH, KW, stride, pad, Ho, Wo)))
+                gw = gw2.reshape(O, KH, KW, Cp)[..., :C].permute(0, 3, 1, 2).contiguous()
         if ctx.needs_input_grad[0]:
             M = B * Ho * Wo
             big = ((B * H * W + 127) // 128) * ((Cp + 127) // 128) >= 512      # few tiles: the split-K GEMM + col2im wins
@@ -254,14 +309,9 @@ class _Conv2dFn(torch.autograd.Function):
                 dxh = dcols.reshape(B, H, W, Cp) if one else ops.col2im_f32(dcols, B, H, W, Cp, KH, KW, stride, pad, Ho, Wo)
             dxh = dxh[..., :C].contiguous() if Cp != C else dxh
             gx = dxh.permute(0, 3, 1, 2) if CHANNELS_LAST else ops.nhwc_to_nchw(dxh)
-        if ctx.needs_input_grad[1]:
-            if one:
-                gw2 = _wgrad(gyh, xh.reshape(B * H * W, Cp), amax_g=pg, amax_a=ctx.px)
-            else:                                                                     # [O][KH*KW*Cp]
-                gw2 = _wgrad(gyh, None, amax_g=pg, amax_a=ctx.px, conv=(xh, (KH, KW, stride, pad, Ho, Wo)))
-            gw = gw2.reshape(O, KH, KW, Cp)[..., :C].permute(0, 3, 1, 2).contiguous()
         if has_bias and ctx.needs_input_grad[2]:
             gb = gyh.sum(0)
+        fork.join()
         return gx, gw, gb, None, None
 
 

@@ -14,6 +14,8 @@ if os.environ.get("DIRECT_SMALL"):
     contract.DIRECT_SMALL = os.environ["DIRECT_SMALL"] != "0"
 if os.environ.get("WGRAD_SWAP"):
     contract.WGRAD_SWAP = os.environ["WGRAD_SWAP"] != "0"
+if os.environ.get("SIDE_WGRAD"):
+    contract.SIDE_WGRAD = os.environ["SIDE_WGRAD"] != "0"
 if os.environ.get("MIN_NK"):
     contract.F16X3_MIN_NK = int(os.environ["MIN_NK"])
 g = torch.Generator().manual_seed(3)
