@@ -29,10 +29,13 @@ def _w(conv):
 
 
 class DecoderEngine:
-    def __init__(self, decoder, post_quant_conv=None, codebook=None, chunk_pixels=1 << 20):
+    def __init__(self, decoder, post_quant_conv=None, codebook=None, chunk_pixels=25 << 16):
         self.dec, self.pq = decoder, post_quant_conv
         self.codebook = None if codebook is None else codebook.detach().float().contiguous()
-        self.chunk_pixels = chunk_pixels            # output pixels per batch chunk: keeps every activation under the gather's 2 GiB (32-bit byte offsets) and bounds the attention scores
+        # output pixels per batch chunk: keeps every activation under the gather's 2 GiB (32-bit byte offsets) and bounds the attention
+        # scores.  25 images of 256 x 256 (the largest tensor, 256^2 x 256 channels fp32, is 1.68 GB): a 50-image batch decodes as
+        # 25 + 25 (2.148 -> 2.113 ms per image against 13 + 13 + 12 + 12 under the 16-image cap of round 3, tools/decoder_time.py)
+        self.chunk_pixels = chunk_pixels
         self._wc = {}
         self.fuse_gn_split = True                   # norm -> swish -> conv: the conv's f16 operand straight from the GroupNorm pass
 
