@@ -2047,7 +2047,7 @@ __global__ void __launch_bounds__(512)
 k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, int64_t M, int64_t N, int B, int H, int W,
                int Cin, int padval, int ups, const float* __restrict__ scale, const float* __restrict__ bias,
                const float* __restrict__ rowadd, int64_t rows_per_batch, const float* __restrict__ residual, int64_t ldr,
-               float* __restrict__ out, int64_t ldo, float* __restrict__ gn_ws) {
+               float* __restrict__ out, int64_t ldo, float* __restrict__ gn_ws, int tile0) {
     constexpr int BM = 128 * TM, BN = 64 * TN, LBM = TM == 4 ? 9 : TM == 2 ? 8 : 7;
     constexpr int PPWMAX = TM == 4 ? 6 : 4;                 // patch pieces per wave and chunk (512-pixel tiles: 10 x 66 pixels = 42 pieces)
     STAMP(t_kernel);
@@ -2066,7 +2066,7 @@ k_conv3_direct(const uint8_t* __restrict__ A, const uint8_t* __restrict__ Wdc, i
     const int fr = lane & 31, fh = lane >> 5;
     unsigned bx_, by_;
     xcd_tile(bx_, by_);
-    const int64_t tile = by_;
+    const int64_t tile = (int64_t)by_ + tile0;                // tile0: first tile of a tail launch (launch_conv3_direct)
     const int64_t m0 = tile * BM, n0 = (int64_t)bx_ * BN;
     const int HW = H * W;
     // tile geometry: TR image rows of IMGS images starting at (b0, y0).  W is 8 .. 64 and H * W divides or is a multiple of
@@ -2353,10 +2353,39 @@ static int launch_conv3_direct(const void* A, const void* Wdc, int64_t B, int64_
     const int64_t M = B * H * W;
     if (!rowadd) rows_per_batch = M;
     ensure_pad_rows((hipStream_t)stream);
-#define CONV3_LAUNCH(TN_, TM_)                                                                                                     \
-    hipLaunchKernelGGL((k_conv3_direct<DT, TN_, TM_>), dim3((unsigned)((N + 64 * TN_ - 1) / (64 * TN_)), (unsigned)(M / (128 * TM_))), dim3(512), 0, \
+#define CONV3_LAUNCH_AT(TN_, TM_, GY_, T0_)                                                                                        \
+    hipLaunchKernelGGL((k_conv3_direct<DT, TN_, TM_>), dim3((unsigned)((N + 64 * TN_ - 1) / (64 * TN_)), (unsigned)(GY_)), dim3(512), 0, \
                        (hipStream_t)stream, (const uint8_t*)A, (const uint8_t*)Wdc, M, N, (int)B, (int)H, (int)W, (int)Cin, padval,    \
-                       ups ? 1 : 0, scale, bias, rowadd, rows_per_batch, residual, ldr, out, ldo, gn_ws)
+                       ups ? 1 : 0, scale, bias, rowadd, rows_per_batch, residual, ldr, out, ldo, gn_ws, (int)(T0_))
+#define CONV3_LAUNCH(TN_, TM_) CONV3_LAUNCH_AT(TN_, TM_, M / (128 * TM_), 0)
+    if constexpr (DT == 0) {
+        // Tail re-tiling (as k_gemm_nt8 does): one workgroup per CU means rounds of #CU tiles, and a last round that is mostly empty
+        // costs a full one -- 800 tiles at 32 x 32 are 3.125 rounds, 300 at 16 x 16 are 1.17.  The tiles that fill whole rounds
+        // stay 256-pixel ones; the remaining rows go to a second launch of 128-pixel tiles (half the duration, twice as many:
+        // 3.5 / 1.5 rounds).  Same integer sums, same per-slab GroupNorm partials whichever tile owns a slab.
+        static const int64_t tails = EDADM_TUNE_I("EDADM_CONV3_TAILSPLIT", 1);
+        if (tails && tile == 256 && conv3_tile_fits(B, H, W, 128)) {
+            static int ncu_c = 0;
+            if (!ncu_c) {
+                int dev = 0;
+                (void)hipGetDevice(&dev);
+                (void)hipDeviceGetAttribute(&ncu_c, hipDeviceAttributeMultiprocessorCount, dev);
+            }
+            const int64_t bn_ = conv3_bn(N), ntn = (N + bn_ - 1) / bn_, mt = M / 256, tiles = mt * ntn;
+            const int64_t rounds = tiles / ncu_c, rem = tiles % ncu_c;
+            const int64_t mt_main = rounds * ncu_c / ntn;
+            if (rounds >= 1 && rem > 0 && rem * 10 <= (int64_t)ncu_c * 6 && mt_main > 0 && mt_main < mt) {
+                if (bn_ == 192) {
+                    CONV3_LAUNCH_AT(3, 2, mt_main, 0);
+                    CONV3_LAUNCH_AT(3, 1, (mt - mt_main) * 2, mt_main * 2);
+                } else {
+                    CONV3_LAUNCH_AT(2, 2, mt_main, 0);
+                    CONV3_LAUNCH_AT(2, 1, (mt - mt_main) * 2, mt_main * 2);
+                }
+                return edadm_launch_status();
+            }
+        }
+    }
     if (tile == 512) {
         if constexpr (DT == 3) {
             if (rowadd || gn_ws) return EDADM_EINVAL;
@@ -2372,6 +2401,7 @@ static int launch_conv3_direct(const void* A, const void* Wdc, int64_t B, int64_
         else CONV3_LAUNCH(2, 1);
     }
 #undef CONV3_LAUNCH
+#undef CONV3_LAUNCH_AT
     return edadm_launch_status();
 }
 #endif

@@ -304,6 +304,32 @@ def test_implicit_gemm_groupnorm_partials_equal_the_direct_convolutions(ops, B, 
         assert torch.equal(out_d, out) and torch.equal(ws_d, ws)
 
 
+@pytest.mark.parametrize("B,H,Cin,N", [(50, 32, 384, 384), (100, 16, 576, 576), (25, 64, 192, 192)])
+def test_direct_conv3_tail_retiling_same_bits_and_partials(ops, B, H, Cin, N):
+    """launch_conv3_direct (csrc/gemm.hip): when the 256-pixel tiles leave a mostly empty last round of workgroups, the rows beyond the
+    last full round go to a second launch of 128-pixel tiles.  Output and GroupNorm partials are those of the implicit GEMM on the same
+    layer, bit for bit (integer sums; one order of partial sums per 64-row slab whichever tile owns it)."""
+    g = torch.Generator().manual_seed(B + H + N)
+    x = torch.randint(-128, 128, (B, H, H, Cin), generator=g, dtype=torch.int8).cuda()
+    w = torch.randint(-8, 9, (N, 9 * Cin), generator=g, dtype=torch.int8).cuda()
+    scale, bias = (torch.rand(N, generator=g) * 1e-2 + 1e-3).cuda(), torch.randn(N, generator=g).cuda()
+    M, HW, K = B * H * H, H * H, 9 * Cin
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    tiles = (M // 256) * (N // 192)
+    assert ops.conv3_direct_tile(B, H, H, Cin, N) == 256 and tiles > ncu and 0 < tiles % ncu <= 0.6 * ncu      # the split is taken
+    rowadd = torch.randn(B, N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).cuda()
+    geom = ops.make_geom(B, H, H, Cin, H, H, 3, 3, 1, 1, False, 7)
+    ws_g = torch.full((M // 64, N, 2), float("nan"), device="cuda")
+    ref = ops.qgemm_i8(x, w, M, N, K, scale, bias, torch.empty(M, N, device="cuda"), geom=geom, rowadd=rowadd, rows_per_batch=HW,
+                       residual=res, gn_ws=ws_g, gn_hw=HW)
+    ws_d = torch.full((M // 64, N, 2), float("nan"), device="cuda")
+    got = ops.qconv3_i8_direct(x, ops.conv3_pack_w(w, N, Cin), B, H, H, Cin, N, 7, scale, bias, torch.empty(M, N, device="cuda"),
+                               rowadd=rowadd, rows_per_batch=HW, residual=res, gn_ws=ws_d)
+    assert torch.equal(got, ref)
+    assert torch.equal(ws_d, ws_g)
+
+
 @pytest.mark.parametrize("M,N,K,mode,res", [(65536, 384, 384, 1, False), (65536, 384, 384, 2, False), (32768, 384, 1536, 2, True),
                                             (16384, 4608, 576, 3, False), (65536, 384, 384, 4, False), (40960, 256, 320, 1, False)])
 def test_persistent_quantised_output_kernel_bit_identical_to_per_tile_launches(ops, M, N, K, mode, res):
