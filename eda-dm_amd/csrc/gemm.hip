@@ -2358,7 +2358,7 @@ static int launch_conv3_direct(const void* A, const void* Wdc, int64_t B, int64_
                        (hipStream_t)stream, (const uint8_t*)A, (const uint8_t*)Wdc, M, N, (int)B, (int)H, (int)W, (int)Cin, padval,    \
                        ups ? 1 : 0, scale, bias, rowadd, rows_per_batch, residual, ldr, out, ldo, gn_ws, (int)(T0_))
 #define CONV3_LAUNCH(TN_, TM_) CONV3_LAUNCH_AT(TN_, TM_, M / (128 * TM_), 0)
-    if constexpr (DT == 0) {
+    if (DT == 0 || (DT == 3 && W <= 64)) {
         // Tail re-tiling (as k_gemm_nt8 does): one workgroup per CU means rounds of #CU tiles, and a last round that is mostly empty
         // costs a full one -- 800 tiles at 32 x 32 are 3.125 rounds, 300 at 16 x 16 are 1.17.  The tiles that fill whole rounds
         // stay 256-pixel ones; the remaining rows go to a second launch of 128-pixel tiles (half the duration, twice as many:
