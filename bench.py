@@ -512,7 +512,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "ImageNet LDM-4 256x256 W4A8: 50-image batches x 20 DDIM steps x CFG (100 UNet rows/call), "
                                    "400.9M-param cin256-v2 UNet, random-init weights, latents+context resident in HBM, each batch decoded by "
-                                   "the VQ-f4 first stage (55.3M params, fp32) on a second stream; the one-token "
+                                   "the VQ-f4 first stage (55.3M params, fp32) -- issued on a second stream, but NOT hidden: both want the same CUs and "
+                                   "the decode is ~20 % of a step (`first_stage_decode`); the one-token "
                                    "cross-attention vectors (a function of the context alone) and the time-embedding rows of "
                                    "the 20 timesteps are evaluated once per batch inside the timed sample() call, and the "
                                    "attention-free leading blocks (identical for the two halves of a guidance pair) once "
@@ -523,7 +524,8 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": I8_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / I8_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "frac_definition": "dominant kernel GROUP: executed flops of every int8 GEMM launch of one UNet call / their summed "
-                                            "device time (each launch re-played 5x between HIP events) / dense int8 MFMA peak",
+                                            "device time (each launch timed COLD: 3 repetitions between HIP events, a 320 MB buffer rewritten in front of each so that "
+                                            "no operand is left in L2 / the Infinity Cache from the previous one) / dense int8 MFMA peak",
                          "frac_survey_8d": {"definition": "SURVEY 8(d): images/s x algorithmic FLOP/image / peak, on the per-GPU rate",
                                             "unet_flop_per_image": 40 * UNET_GFLOP_PER_ROW * 1e9,
                                             "sampling_only": ips_unet / world * 40 * UNET_GFLOP_PER_ROW * 1e9 / (I8_PEAK_TFLOPS * 1e12),
