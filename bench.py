@@ -473,8 +473,11 @@ def main():
                 continue
             # bytes of all int8 GEMM launches of one UNet call / the GEMM calls timed above (a split or tail-re-tiled
             # layer is two device launches of one call)
-            traffic = tj["hbm_bytes_per_launch"] * tj["launches"] / tj.get("unet_calls", 4) / max(len(i8), 1)
-            traffic_src = "profiles/" + name
+            if "hbm_bytes_per_unet_call" in tj:               # round 5 format: kernels selected by the engine's launch list
+                traffic = tj["hbm_bytes_per_unet_call"] / max(len(i8), 1)
+            else:
+                traffic = tj["hbm_bytes_per_launch"] * tj["launches"] / tj.get("unet_calls", 4) / max(len(i8), 1)
+            traffic_src = "profiles/%s (rocprofv3 --pmc passes of tools/prof_traffic.sh on this csrc/gemm.hip, committed; not re-measured in this run)" % name
             break
         except Exception:
             pass
@@ -585,6 +588,18 @@ def main():
     # reconstruction loops run replicated with rank 0's learned parameters broadcast after each unit -- and the wall-clock is the
     # max over ranks between two barriers.
     calib_out = {}
+    if world > 1 and args.calib == "full":
+        # A rank that fails inside the job skips the collectives the others are blocked in.  It cannot tell them, so it leaves with a
+        # non-zero status (below) and the launcher tears the group down; rank 0 answers the launcher's SIGTERM by printing the line
+        # it has -- sampling numbers plus calibration.error -- and leaves non-zero too: no rank exits 0 after a failed job.
+        import signal
+
+        def _torn_down(signum, frame):
+            if rank == 0:
+                line["calibration"]["error"] = "a rank failed inside the %d-rank calibration job (its traceback is on stderr); torn down" % world
+                print(json.dumps(line), flush=True)
+            os._exit(14)
+        signal.signal(signal.SIGTERM, _torn_down)
     if args.calib != "none" and (world == 1 or args.calib == "full"):
         try:
             if args.calib == "bounded":
@@ -629,6 +644,13 @@ def main():
         except Exception as e:
             import traceback
             calib_out["error"] = repr(e) + " | " + traceback.format_exc()[-600:]
+            if world > 1:
+                sys.stderr.write("rank %d: calibration failed: %s\n" % (rank, calib_out["error"]))
+                sys.stderr.flush()
+                if rank == 0:
+                    line["calibration"].update(calib_out)
+                    print(json.dumps(line), flush=True)
+                os._exit(13)                                   # no collective after a failure: the launcher ends the other ranks
     if rank == 0:
         line["calibration"].update(calib_out)
         print(json.dumps(line))

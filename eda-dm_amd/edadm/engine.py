@@ -126,6 +126,7 @@ class Engine:
         self.qnn = qnn
         self.net = qnn.model
         self.dev = next(qnn.parameters()).device
+        ops.init_device(self.dev)
         self.layers = {}
         for name, m in self.net.named_modules():
             if isinstance(m, QuantModule):

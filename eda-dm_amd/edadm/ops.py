@@ -58,7 +58,22 @@ def mem_restore(y, cl):
     return y.permute(0, 3, 1, 2) if cl else y
 
 
+_inited_devices = set()
+
+
+def init_device(device):
+    """Per-device constant tables of the library, filled eagerly (edadm_init_device) before any stream capture can exist."""
+    if device.type != "cuda":
+        raise lib.EdadmError("edadm ops need a device (no CPU fallback)")
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _inited_devices:
+        with torch.cuda.device(idx):
+            lib.call("edadm_init_device")
+        _inited_devices.add(idx)
+
+
 def workspace(device, floats=None):
+    init_device(device)
     n = int(lib.load().edadm_reduce_ws_floats()) if floats is None else int(floats)
     # one buffer per (device, stream): launches on different streams may run concurrently (a decoder on a side stream next to
     # the sampling graph), and a graph captured on its capture stream keeps the buffer of that stream to itself

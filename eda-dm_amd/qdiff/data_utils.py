@@ -128,6 +128,14 @@ def hbm_scale(device, log=True):
     free, total = torch.cuda.mem_get_info(device)
     free += torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
     scale = max(0.0, min(1.0, (free / 2 ** 30 - HBM_RESERVE_GB) / want))
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        # every rank walks with the SAME budgets (the tightest rank's): the number of prefix passes per unit is then equal on all
+        # ranks, and the reported wall-clock belongs to one stated scale
+        t = torch.tensor([scale], dtype=torch.float64, device=device if dist.get_backend() != "gloo" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        scale = float(t.item())
+    STATS["hbm_scale"] = scale
     if log and scale < 1.0:
         logger.warning("calibration caches scaled to %.0f %% of their budgets: %.0f GB of HBM free (of %.0f), %.0f GB wanted + %.0f reserved"
                        % (100 * scale, free / 2 ** 30, total / 2 ** 30, want, HBM_RESERVE_GB))

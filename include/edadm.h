@@ -237,6 +237,17 @@ int edadm_qgemm_i8_gn(const int8_t* A, int64_t lda, const int8_t* Wt, int64_t ld
  * the word and returns 0 or -EIO; clear != 0 resets it.  Callers check it where they synchronise anyway (end of a sampling
  * run, end of a calibration unit).  Never call it inside a stream capture. */
 int edadm_device_status(int clear, void* stream);
+/* Per-device set-up of the library's constant tables (the padding-row table the LDS-DMA gathers of the GEMM / convolution
+ * kernels read "padding" from), filled synchronously for the CURRENT device.  Call once per device before the first stream
+ * capture of the process: the lazy fill on a first launch is a synchronous copy, which is illegal while another stream is in a
+ * global-mode capture.  The reference has no counterpart (its padding is F.conv2d's, quant_layer.py:434).  Idempotent. */
+int edadm_init_device(void);
+/* Diagnostics for the measurement tools (tools/unet_prof.py -> tools/pmc_traffic.py): the kernel structures the int8 GEMM /
+ * convolution entry points launched on this host thread since the last call, in launch order, as tags (1 k_gemm_nt, 2 k_gemm_nt8,
+ * 3 k_gemm_p, 4 k_gemm_ntq, 5 k_conv3_direct, 6 k_gemm_split2, 7 k_gemm_geglu); writes up to 8 of them, returns their number and forgets them.
+ * Lets a tool attribute each layer's ALGORITHMIC bytes to the kernel that ran it, so the PMC traffic per kernel name has its own
+ * denominator.  No reference counterpart. */
+int edadm_diag_launch_kernels(int32_t* tags8);
 /* Batched f16 NT GEMM for the attention products (integer-valued f16 operands, exact in fp32):
  * C[z][m][n] = alpha * sum_k A[z][m][k] * B[z][n][k], z = outer*inner + head with two-level
  * element strides (outer = batch sample, inner = attention head inside a [B][N][heads*d] tensor).

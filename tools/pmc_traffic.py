@@ -1,8 +1,21 @@
-"""Aggregate rocprofv3 --pmc counter CSVs (separate FETCH_SIZE and WRITE_SIZE passes) into HBM bytes per launch of
-the int8 GEMM kernels: python tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json>
-Corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes: counters are in KB (x1024); on gfx950 FETCH_SIZE
-reports half of a wide (16 B/lane) streaming read (x2); WRITE_SIZE is exact."""
-import csv, glob, json, os, sys
+"""HBM bytes per launch of the int8 GEMM / convolution kernels from rocprofv3 --pmc counter CSVs (separate FETCH_SIZE and
+WRITE_SIZE passes), per kernel, against each kernel's own ALGORITHMIC bytes:
+    python tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json> <launch_list.json>
+The kernels are selected by the ENGINE'S launch list (tools/unet_prof.py LAUNCH_LIST=...: every int8 layer launch of one UNet
+call with the kernel structure the library picked), not by a hand-kept substring list: a kernel the list names that the profile
+does not hold, a profile row of the GEMM family that no launch claims, or a launch count that is not a whole number of UNet calls
+fails the run (round 4 silently dropped k_gemm_ntq).  Corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes:
+counters are in KB (x1024); on gfx950 FETCH_SIZE reports half of a wide (16 B/lane) streaming read (x2); WRITE_SIZE is exact."""
+import csv, glob, hashlib, json, os, re, sys
+
+# kernel structure (tag of edadm_diag_launch_kernels) -> pattern of its int8 instantiations in a kernel trace
+PATTERNS = {
+    "k_gemm_nt": r"\bk_gemm_nt<0,", "k_gemm_nt8": r"\bk_gemm_nt8<0,", "k_gemm_p": r"\bk_gemm_p<0,", "k_gemm_ntq": r"\bk_gemm_ntq<",
+    "k_conv3_direct": r"\bk_conv3_direct<0,", "k_gemm_split2": r"\bk_gemm_split2<", "k_gemm_geglu": r"\bk_gemm_geglu<",
+}
+# the same templates on other operand types (f16 attention products, fp32 / three-product f16 calibration graph): not int8 layers
+OTHER = r"\bk_(gemm_nt|gemm_nt8|gemm_p|conv3_direct)<[123],"
+FAMILY = r"\bk_(gemm|conv3_direct)"
 
 
 def load(d, counter):
@@ -11,34 +24,99 @@ def load(d, counter):
         for r in csv.DictReader(open(f)):
             if r.get("Counter_Name") != counter:
                 continue
-            k = r["Kernel_Name"]
-            c = per.setdefault(k, [0, 0.0])
+            c = per.setdefault(r["Kernel_Name"], [0, 0.0])
             c[0] += 1
             c[1] += float(r["Counter_Value"])
     return per
 
 
-fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
-is_i8 = lambda k: ("k_gemm_nt8<0" in k) or ("k_gemm_nt<0" in k) or ("k_gemm_p<0" in k) or ("k_conv3_direct<0" in k) or ("k_gemm_split2" in k)
-nl = sum(v[0] for k, v in fetch.items() if is_i8(k))
-fkb = sum(v[1] for k, v in fetch.items() if is_i8(k))
-wkb = sum(v[1] for k, v in write.items() if is_i8(k))
-out = {
-    "kernel": "int8 GEMM launches of edadm_qgemm_i8 / _q / edadm_qconv3_i8_direct (k_gemm_nt8<0,*>, k_gemm_p<0,*>, k_gemm_nt<0,*>, k_conv3_direct<0,3,2> / <0,3,1>, k_gemm_split2<3,1>)",
-    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, in a separate pass, --pmc WRITE_SIZE) --output-format csv -- python "
-               "tools/unet_prof.py  [N_CALLS=2: 4 eager UNet calls of the frozen LDM-4 engine as a DDIM step issues them, 100 rows]",
-    "launches": nl, "unet_calls": int(sys.argv[4]) if len(sys.argv) > 4 else 4, "FETCH_SIZE_sum_KB": fkb, "WRITE_SIZE_sum_KB": wkb,
-    "correction": "MI355X_MICROARCH.md HBM: FETCH_SIZE reports 1/2 of a wide (16 B/lane) streaming read on gfx950 -> x2; WRITE_SIZE exact; unit KB -> x1024",
-    "fetch_bytes_per_launch_corrected": fkb * 2 * 1024 / max(nl, 1),
-    "write_bytes_per_launch": wkb * 1024 / max(nl, 1),
-    "hbm_bytes_per_launch": (fkb * 2 + wkb) * 1024 / max(nl, 1),
-    "per_kernel": {k: {"launches": v[0], "fetch_KB": v[1], "write_KB": write.get(k, [0, 0.0])[1]}
-                   for k, v in sorted(fetch.items(), key=lambda kv: -kv[1][1])[:24]},
-}
-# the sources these bytes belong to: bench.py drops the file (roofline.traffic = null) when csrc/gemm.hip has changed since
-import hashlib
-_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-with open(os.path.join(_root, "eda-dm_amd", "csrc", "gemm.hip"), "rb") as _fh:
-    out["gemm_hip_sha256"] = hashlib.sha256(_fh.read()).hexdigest()
-json.dump(out, open(sys.argv[3], "w"), indent=1)
-print(json.dumps({k: out[k] for k in ("launches", "hbm_bytes_per_launch", "fetch_bytes_per_launch_corrected", "write_bytes_per_launch")}))
+def classify(name):
+    hits = [k for k, p in PATTERNS.items() if re.search(p, name)]
+    if len(hits) > 1:
+        raise SystemExit("kernel name matches two structures: %s %s" % (name, hits))
+    if hits:
+        return hits[0]
+    if re.search(FAMILY, name) and not re.search(OTHER, name):
+        raise SystemExit("a GEMM-family kernel that no launch-list structure claims (add it to PATTERNS): " + name)
+    return None
+
+
+def main():
+    fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+    lst = json.load(open(sys.argv[4]))
+    # per structure: launches and algorithmic bytes of ONE UNet call (a launch that issued two kernels -- tail re-tiling -- is
+    # split between them by launch count only: its bytes stay with the first, stated in the output)
+    alg = {}
+    for r in lst["rows"]:
+        if r["type"] != "i8":
+            continue
+        if not r["kernels"] or "?" in r["kernels"]:
+            raise SystemExit("launch without a known kernel tag: %r" % r)
+        b = sum(r["bytes"].values())
+        for i, k in enumerate(r["kernels"]):
+            a = alg.setdefault(k, {"launches": 0, "bytes": 0.0, "flop": 0.0})
+            a["launches"] += 1
+            if i == 0:
+                a["bytes"] += b
+                a["flop"] += r["flop"]
+    pmc = {}
+    for name, (n, kb) in fetch.items():
+        k = classify(name)
+        if k is None:
+            continue
+        p = pmc.setdefault(k, {"launches": 0, "fetch_KB": 0.0, "write_KB": 0.0, "names": []})
+        p["launches"] += n
+        p["fetch_KB"] += kb
+        p["write_KB"] += write.get(name, [0, 0.0])[1]
+        p["names"].append(name.split("(")[0])
+    for k in alg:
+        if k not in pmc:
+            raise SystemExit("the launch list names %s, the profile holds no such kernel" % k)
+    for k in pmc:
+        if k not in alg:
+            raise SystemExit("the profile holds int8 %s launches, the launch list names none" % k)
+    calls = None
+    per_kernel = {}
+    for k, a in sorted(alg.items()):
+        p = pmc[k]
+        c = p["launches"] / a["launches"]
+        if abs(c - round(c)) > 1e-9 or (calls is not None and round(c) != calls):
+            raise SystemExit("%s: %d profiled launches are not a whole / the same number of UNet calls of %d launches (others: %s)"
+                             % (k, p["launches"], a["launches"], calls))
+        calls = int(round(c))
+        hbm = (p["fetch_KB"] * 2 + p["write_KB"]) * 1024 / calls
+        per_kernel[k] = {"names": sorted(set(p["names"])), "launches_per_unet_call": a["launches"],
+                         "fetch_bytes_per_call_corrected": p["fetch_KB"] * 2 * 1024 / calls, "write_bytes_per_call": p["write_KB"] * 1024 / calls,
+                         "hbm_bytes_per_call": hbm, "algorithmic_bytes_per_call": a["bytes"], "traffic_over_algorithmic": hbm / a["bytes"] if a["bytes"] else None,
+                         "algorithmic_flop_per_call": a["flop"]}
+    nl = sum(a["launches"] for a in alg.values())
+    hbm_call = sum(v["hbm_bytes_per_call"] for v in per_kernel.values())
+    alg_call = sum(a["bytes"] for a in alg.values())
+    out = {
+        "kernel": "every int8 GEMM / convolution launch of one UNet call of the frozen LDM-4 engine (%s)" % ", ".join(sorted(per_kernel)),
+        "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, in a separate pass, --pmc WRITE_SIZE) --output-format csv -- python3 "
+                   "tools/unet_prof.py  [100 rows = one guidance pair of 50; LAUNCH_LIST: the engine's launch list]",
+        "unet_calls": calls, "launches_per_unet_call": nl,
+        "correction": "MI355X_MICROARCH.md HBM: FETCH_SIZE reports 1/2 of a wide (16 B/lane) streaming read on gfx950 -> x2; WRITE_SIZE exact; unit KB -> x1024",
+        "hbm_bytes_per_unet_call": hbm_call, "algorithmic_bytes_per_unet_call": alg_call, "traffic_over_algorithmic": hbm_call / alg_call,
+        "hbm_bytes_per_launch": hbm_call / nl, "algorithmic_bytes_per_launch": alg_call / nl,
+        "fetch_bytes_per_launch_corrected": sum(v["fetch_bytes_per_call_corrected"] for v in per_kernel.values()) / nl,
+        "write_bytes_per_launch": sum(v["write_bytes_per_call"] for v in per_kernel.values()) / nl,
+        "launches": nl * calls,
+        "per_kernel": per_kernel,
+        "tail_note": "a layer launch that issued two kernels (tail re-tiling: k_gemm_nt8 + k_gemm_nt, two k_conv3_direct tiles) counts its "
+                     "algorithmic bytes with the first",
+    }
+    # the sources these bytes belong to: bench.py drops the file (roofline.traffic = null) when csrc/gemm.hip has changed since
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "eda-dm_amd", "csrc", "gemm.hip"), "rb") as fh:
+        out["gemm_hip_sha256"] = hashlib.sha256(fh.read()).hexdigest()
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    print(json.dumps({k: out[k] for k in ("unet_calls", "launches_per_unet_call", "hbm_bytes_per_launch", "algorithmic_bytes_per_launch", "traffic_over_algorithmic")}))
+    for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]["hbm_bytes_per_call"]):
+        print("%-16s %4d launches/call  hbm %8.1f MB  algorithmic %8.1f MB  x%.3f" % (k, v["launches_per_unet_call"], v["hbm_bytes_per_call"] / 1e6,
+                                                                                     v["algorithmic_bytes_per_call"] / 1e6, v["traffic_over_algorithmic"]))
+
+
+if __name__ == "__main__":
+    main()
