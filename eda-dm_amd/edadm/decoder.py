@@ -31,7 +31,10 @@ def _w(conv):
 class DecoderEngine:
     def __init__(self, decoder, post_quant_conv=None, codebook=None, chunk_pixels=25 << 16):
         self.dec, self.pq = decoder, post_quant_conv
-        ops.init_device(next(decoder.parameters()).device)
+        for mod in (decoder, post_quant_conv):
+            if mod is not None:
+                ops.init_device(next(mod.parameters()).device)
+                break
         self.codebook = None if codebook is None else codebook.detach().float().contiguous()
         # output pixels per batch chunk: keeps every activation under the gather's 2 GiB (32-bit byte offsets) and bounds the attention
         # scores.  25 images of 256 x 256 (the largest tensor, 256^2 x 256 channels fp32, is 1.68 GB): a 50-image batch decodes as

@@ -1,0 +1,314 @@
+"""-m gpu: the 400.9 M-parameter LDM-4 int8 engine against the ORACLE at the production launch shapes (round-4 review, item 2a).
+
+The oracle (oracle/qdiff_oracle.py: the reference's fake-quant forward restated, quant_model.py:69, quant_layer.py:406-437) runs the
+full-size UNet on ONE guidance pair (2 rows, t = 501) with the product's own scales loaded, recording every layer's input and output.
+Every check below feeds the engine the ORACLE's tensors (teacher forcing: no accumulated flips) replicated to 100 rows -- the row
+count of a DDIM step -- so that the kernels the bench times are the ones that run (`k_conv3_direct` 256-pixel tiles, `k_gemm_nt8`,
+`k_gemm_ntq`, the GEGLU kernel, `k_gemm_split2`, `k_attn_wide16_i8`); which ones ran is asserted from the library's launch tags
+(edadm_diag_launch_kernels) and the entry-point counter (lib.CALLS).
+
+ (i)   every int8 layer with an fp32 output: <= 2e-5 of the layer's output range against the oracle's output (integer accumulation is
+       exact; what is left is the fp32 epilogue against the oracle's fp32 convolution), all 100 rows, replicas bit-identical;
+ (ii)  the quantised-output epilogues (q / k / v projections, GEGLU, ff.net.2 + residual): the int8 / f16 CODES against the oracle's
+       quantiser applied to the oracle's fp32 output -- off-by-one codes only, counted (an fp32 value within rounding of a .5
+       boundary), never by more;
+ (iii) a whole transformer block per attention level through Engine.ldm_tblock (wide / small fused attention kernels included) against
+       the oracle's block output;
+ (iv)  the whole-network code census of tests/test_blocks_gpu.py at full size: the engine's operand of every layer in ONE 100-row
+       forward against the oracle's codes at the same place.
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pytestmark = pytest.mark.gpu
+
+TAGS = {1: "k_gemm_nt", 2: "k_gemm_nt8", 3: "k_gemm_p", 4: "k_gemm_ntq", 5: "k_conv3_direct", 6: "k_gemm_split2", 7: "k_gemm_geglu"}
+REP = 50                                                    # the oracle's guidance pair x 50 = the 100 rows of a DDIM step
+
+
+class _Tags:
+    """kernel structures launched since the last take() (edadm_diag_launch_kernels)"""
+
+    def __init__(self):
+        from edadm import lib
+        self.fn = lib.load().edadm_diag_launch_kernels
+        self.buf = (ctypes.c_int32 * 8)()
+        self.fn(self.buf)
+
+    def take(self):
+        n = self.fn(self.buf)
+        return [TAGS.get(int(self.buf[i]), "?") for i in range(n)]
+
+
+@pytest.fixture(scope="module")
+def world():
+    import bench
+    from oracle import qdiff_oracle as O
+    from edadm.state import quant_state_dict
+    dev = torch.device("cuda", 0)
+    qnn, sd_cpu, _ = bench.build_quantised_unet(dev, calib_rows=16)
+    net = O.OUNet(sd_cpu, bench.WQ, bench.AQ, 8, **bench.LDM4)
+    net.set_first_last_layer_to_8bit()
+    net.disable_network_output_quantization()
+    net.split_shortcut = True
+    g = torch.Generator().manual_seed(7)
+    x1 = torch.randn(1, 3, 64, 64, generator=g)
+    x = torch.cat([x1, x1])                                  # a guidance pair: the same latent, two contexts
+    c = torch.randn(2, 1, 512, generator=g)
+    t = torch.tensor([501, 501])
+    with torch.no_grad():
+        net(x, t, c)                                         # FP pass: creates the split quantizers
+    net.load_qparams({"qp/" + k: v for k, v in quant_state_dict(qnn).items()}, prefix="qp/model.")
+    net.set_quant_state(True, True)
+    rec, blocks = {}, {}
+    orig_l, orig_b = O.OLayer.__call__, O.OTransformerBlock.__call__
+
+    def hooked_l(self, xx, split=0):
+        out = orig_l(self, xx, split)
+        rec.setdefault(self.name, []).append((xx.detach().clone(), out.detach().clone()))
+        return out
+
+    def hooked_b(self, xx, context=None):
+        out = orig_b(self, xx, context)
+        blocks[self.name] = (xx.detach().clone(), None if context is None else context.detach().clone(), out.detach().clone())
+        return out
+
+    O.OLayer.__call__, O.OTransformerBlock.__call__ = hooked_l, hooked_b
+    try:
+        with torch.no_grad():
+            out_ref = net(x, t, c)
+    finally:
+        O.OLayer.__call__, O.OTransformerBlock.__call__ = orig_l, orig_b
+    eng = qnn.freeze()
+    return dict(dev=dev, qnn=qnn, eng=eng, net=net, rec=rec, blocks=blocks, out_ref=out_ref, x=x, t=t, c=c,
+                olayers={l.name: l for l in net.all_layers()}, oquant={q.name: q for q in net.all_quantizers()})
+
+
+def _rep(a):
+    return a.repeat((REP,) + (1,) * (a.dim() - 1)).contiguous()
+
+
+def _codes(q, v):
+    """the oracle quantiser's integer codes of v (quant_layer.py:266-270)"""
+    return torch.clamp(torch.round(v / q.delta) + q.zero_point, 0, q.n_levels - 1)
+
+
+def test_every_int8_layer_on_the_oracle_inputs_at_production_rows(world):
+    from qdiff.quant_layer import QuantModule
+    from edadm import lib
+    eng, rec = world["eng"], world["rec"]
+    mods = {n: m for n, m in world["qnn"].model.named_modules() if isinstance(m, QuantModule)}
+    assert set(rec) == set(mods), sorted(set(rec) ^ set(mods))[:5]
+    tags, seen, worst, modes, shapes = _Tags(), {}, (0.0, None), {}, set()
+    lib.CALLS = {}
+    try:
+        for name, m in mods.items():
+            L = eng.L(m)
+            modes[L.mode] = modes.get(L.mode, 0) + 1
+            for x_in, out_ref in rec[name]:
+                tags.take()
+                out = eng.run_layer(m, _rep(x_in).cuda())
+                for k in tags.take():
+                    seen[k] = seen.get(k, 0) + 1
+                if getattr(L, "geglu_interleaved", False):
+                    out = torch.cat([out[..., 0::2], out[..., 1::2]], dim=-1)
+                o = out.reshape((REP, x_in.shape[0]) + tuple(out.shape[1:]))
+                assert bool((o == o[:1]).all()), name           # 50 replicas of the pair: the same bits in every tile position
+                ref = out_ref.double().numpy()
+                rng = np.abs(ref).max()
+                e = np.abs(o[0].cpu().double().numpy() - ref).max() / max(rng, 1e-30)
+                if e > worst[0]:
+                    worst = (e, name)
+                assert e <= 2e-5, (name, L.mode, e)
+                shapes.add((L.kind, out.numel() // L.N, L.N, L.K))
+    finally:
+        calls, lib.CALLS = lib.CALLS, None
+    print("full-size LDM-4, %d layers %s x %d rows: worst %.2e of range at %s" % (len(mods), modes, 2 * REP, worst[0], worst[1]))
+    print("   kernel structures:", seen)
+    print("   entry points:", {k: v for k, v in calls.items() if "gemm" in k or "conv" in k})
+    # the structures the bench's UNet call takes for its fp32-output layers
+    for k in ("k_conv3_direct", "k_gemm_nt", "k_gemm_split2"):
+        assert seen.get(k, 0) > 0, (k, seen)
+    assert calls.get("edadm_qconv3_i8_direct", 0) >= 40 and calls.get("edadm_qgemm_i8_split2", 0) >= 6
+    assert (("conv3", 409600, 192, 1728) in shapes or any(s[1] == 409600 for s in shapes)), sorted(shapes)[:5]
+
+
+def _tblock_names(world):
+    return sorted(world["blocks"])
+
+
+def test_quantised_output_epilogues_codes_at_production_rows(world):
+    """q / k / v, GEGLU and ff.net.2 (+ residual) emit their consumer's operand from the epilogue: the codes against the oracle's
+    quantiser on the oracle's fp32 tensors.  Exact integer accumulation against an fp32 convolution: a value within rounding of a
+    .5 boundary may land on the other side -- off by ONE code, counted; never by more."""
+    from edadm import lib
+    eng, rec, qnn = world["eng"], world["rec"], world["qnn"]
+    mods = dict(qnn.model.named_modules())
+    tags, seen = _Tags(), {}
+    tot = off1 = 0
+    lib.CALLS = {}
+
+    def check(label, got_codes, ref_codes):
+        nonlocal tot, off1
+        d = (got_codes.reshape(REP, -1)[0].cpu().double() - ref_codes.reshape(-1).double()).abs()
+        assert float(d.max()) <= 1.0, (label, float(d.max()))
+        # replicas: bit-identical
+        gc = got_codes.reshape(REP, -1)
+        assert bool((gc == gc[:1]).all()), label
+        tot += d.numel()
+        off1 += int((d == 1).sum())
+        assert float((d == 1).sum()) / d.numel() <= 2e-4, (label, float((d == 1).sum()) / d.numel())
+
+    def launch(fn):
+        tags.take()
+        r = fn()
+        for k in tags.take():
+            seen[k] = seen.get(k, 0) + 1
+        return r
+
+    try:
+        for bname in _tblock_names(world):
+            blk = mods[bname]
+            a1 = blk.attn1
+            x_q, out_q = rec[bname + ".attn1.to_q"][0]
+            x_k, out_k = rec[bname + ".attn1.to_k"][0]
+            x_v, out_v = rec[bname + ".attn1.to_v"][0]
+            B2, N, C = x_q.shape
+            Lq, Lk, Lv = eng.L(a1.to_q), eng.L(a1.to_k), eng.L(a1.to_v)
+            xq = _rep(x_q).reshape(-1, C).cuda()
+            oq, ok, ov = eng._quant(Lq, xq), eng._quant(Lk, xq), eng._quant(Lv, xq)
+            M = xq.shape[0]
+            from edadm import ops
+            d_ = Lq.N // a1.heads
+            i8 = (eng.fused_attention and eng.attention_i8_scores and ops.attention_i8qk_ok(a1.heads, d_, N, N))
+            qq, qk, qv = (world["oquant"][bname + ".attn1.act_quantizer_" + s] for s in "qkv")
+            if i8:
+                q8 = launch(lambda: eng._gemm(Lq, oq, M, out_mode=2, oqp=eng._aq(a1.act_quantizer_q)[0]))
+                k8 = launch(lambda: eng._gemm(Lk, ok, M, out_mode=2, oqp=eng._aq(a1.act_quantizer_k)[0]))
+                check(bname + ".to_q(i8)", q8.float() + 128.0, _codes(qq, out_q))
+                check(bname + ".to_k(i8)", k8.float() + 128.0, _codes(qk, out_k))
+            else:
+                qh = launch(lambda: eng._gemm(Lq, oq, M, out_mode=1, oqp=eng._aq(a1.act_quantizer_q)[0]))
+                kh = launch(lambda: eng._gemm(Lk, ok, M, out_mode=1, oqp=eng._aq(a1.act_quantizer_k)[0]))
+                check(bname + ".to_q(f16)", qh.float() + float(qq.zero_point), _codes(qq, out_q))
+                check(bname + ".to_k(f16)", kh.float() + float(qk.zero_point), _codes(qk, out_k))
+            vh = launch(lambda: eng._gemm(Lv, ov, M, out_mode=1, oqp=eng._aq(a1.act_quantizer_v)[0], rpb=N))
+            check(bname + ".to_v(f16)", vh.float() + float(qv.zero_point), _codes(qv, out_v))
+            # GEGLU: ff.net.0.proj's epilogue emits ff.net.2's operand
+            ff0, ff2 = blk.ff.net[0].proj, blk.ff.net[2]
+            L0, L2 = eng.L(ff0), eng.L(ff2)
+            x0, _ = rec[bname + ".ff.net.0.proj"][0]
+            x2, out2 = rec[bname + ".ff.net.2"][0]
+            assert getattr(L0, "geglu_interleaved", False)
+            of = eng._quant(L0, _rep(x0).reshape(-1, C).cuda())
+            gcodes = launch(lambda: eng._gemm(L0, of, M, out_mode=3, oqp=L2.qp))
+            o2 = world["olayers"][bname + ".ff.net.2"]
+            check(bname + ".geglu", gcodes.float() + 128.0, _codes(o2.act_quantizer, x2))
+            # ff.net.2 + residual -> proj_out's operand
+            xin, _, bout = world["blocks"][bname]
+            resid = (bout - out2).reshape(-1, C)                      # the residual stream in front of the feed-forward
+            sname = bname.rsplit(".transformer_blocks", 1)[0]
+            Lp = eng.L(mods[sname + ".proj_out"])
+            op = world["olayers"][sname + ".proj_out"]
+            a2 = eng._quant(L2, _rep(x2).reshape(-1, x2.shape[-1]).cuda())
+            pc = launch(lambda: eng._gemm(L2, a2, M, residual=_rep(resid.reshape(B2, N, C)).reshape(-1, C).cuda(), out_mode=2, oqp=Lp.qp))
+            ref_sum = out2 + resid.reshape(out2.shape)               # the oracle's fp32 sum, in its order of operations
+            check(bname + ".ff2+res", pc.float() + 128.0, _codes(op.act_quantizer, ref_sum))
+    finally:
+        calls, lib.CALLS = lib.CALLS, None
+    print("quantised-output epilogues at %d rows: %d codes, %d off by one (%.2e), none by more" % (2 * REP, tot, off1, off1 / max(tot, 1)))
+    print("   kernel structures:", seen)
+    assert tot > 5e6
+    assert seen.get("k_gemm_ntq", 0) > 0 and (seen.get("k_gemm_p", 0) + seen.get("k_gemm_geglu", 0)) > 0, seen
+    assert calls.get("edadm_qgemm_i8_q", 0) >= 5 * len(_tblock_names(world))
+
+
+def test_transformer_blocks_on_the_oracle_inputs_at_production_rows(world):
+    """A whole QuantBasicTransformerBlock per attention level (Engine.ldm_tblock: LayerNorm + quantise, q / k / v, the fused
+    attention kernel of the level -- k_attn_wide16_i8 at 32 x 32 --, to_out + residual, the one-token cross-attention branch, GEGLU,
+    ff.net.2) on the oracle's block input against the oracle's block output.  Inside a block nothing is teacher-forced, so the
+    off-by-one codes of (ii) do propagate: bound in units of the output range."""
+    from edadm import lib
+    eng, qnn = world["eng"], world["qnn"]
+    mods = dict(qnn.model.named_modules())
+    lib.CALLS = {}
+    worst = {}
+    try:
+        for bname in _tblock_names(world):
+            xin, ctx, bout = world["blocks"][bname]
+            B2, N, C = xin.shape
+            t = _rep(xin).reshape(-1, C).cuda()
+            eng.ctx_r = None
+            out, emitted = eng.ldm_tblock(mods[bname], t, B2 * REP, N, C, _rep(ctx).cuda())
+            assert not emitted
+            o = out.reshape(REP, B2 * N * C)
+            assert bool((o == o[:1]).all()), bname
+            ref = bout.reshape(-1).double()
+            err = (o[0].cpu().double() - ref).abs() / ref.abs().max()
+            worst[bname] = (float(err.max()), float(err.mean()), N)
+            assert float(err.max()) <= 2e-2 and float(err.mean()) <= 5e-4, (bname, worst[bname])
+    finally:
+        calls, lib.CALLS = lib.CALLS, None
+    for k, v in worst.items():
+        print("   %-52s N=%4d  max %.2e  mean %.2e of range" % (k, v[2], v[0], v[1]))
+    print("   entry points:", {k: v for k, v in calls.items() if "attention" in k})
+    assert calls.get("edadm_attention_fused_i8qk", 0) > 0, calls            # the 32 x 32 level's wide head on the int8 score kernel
+
+
+def test_whole_network_code_census_at_full_size(world):
+    """ONE 100-row forward of the engine (the oracle's pair x 50), every layer's integer operand against the oracle's codes at the
+    same place: operands in front of the first flip bit-identical, then off-by-one codes in a counted fraction."""
+    from edadm import ops
+    eng, rec, olayers = world["eng"], world["rec"], world["olayers"]
+    dev = world["dev"]
+    eng.one_token_context = False
+    eng.ctx_r = eng.emb_r = None
+    eng.cfg_pair = False
+    eng.tap = {}
+    try:
+        with torch.no_grad():
+            out = eng(_rep(world["x"]).to(dev), _rep(world["t"]).to(dev), _rep(world["c"]).to(dev))
+    finally:
+        tap, eng.tap = eng.tap, None
+        eng.one_token_context = True
+    n_layers = n_exact = tot = tot1 = totn = 0
+    first = None
+    for name in tap:
+        L, ol = eng.L(dict(world["qnn"].model.named_modules())[name]), olayers[name]
+        if L.mode != "i8" or len(tap[name]) != len(rec[name]):
+            continue
+        for a, (x_in, _) in zip(tap[name], rec[name]):
+            if ol.split:
+                c = torch.cat([_codes(ol.act_quantizer, x_in[:, :ol.split]), _codes(ol.act_quantizer_0, x_in[:, ol.split:])], 1)
+            else:
+                c = _codes(ol.act_quantizer, x_in)
+            if ol.kind == "conv2d":
+                c = c.permute(0, 2, 3, 1)
+            ea = a.reshape(REP, -1)[0].cpu().float() + 128.0           # replica 0 = the oracle's pair
+            if ea.numel() != c.numel():
+                continue
+            d = (ea - c.reshape(-1).float()).abs()
+            n_layers += 1
+            n_exact += int(d.max() == 0)
+            if first is None and d.max() > 0:
+                first = (name, int((d > 0).sum()), float(d.max()), d.numel())
+            tot += d.numel()
+            tot1 += int((d == 1).sum())
+            totn += int((d > 1).sum())
+    ref = world["out_ref"]
+    err = (out.reshape((REP,) + tuple(ref.shape))[0].cpu().double() - ref.double()).abs() / ref.abs().max()
+    print("full-size LDM-4 census: %d operands compared, %d bit-identical; codes off by one: %.5f of all, by more: %.6f | output: max %.3f "
+          "mean %.4f of range" % (n_layers, n_exact, tot1 / max(tot, 1), totn / max(tot, 1), err.max(), err.mean()))
+    print("   first operand that differs:", first)
+    assert n_layers >= 100, n_layers
+    assert n_exact >= 3
+    assert first is None or (first[1] <= max(8, first[3] // 2000) and first[2] == 1.0), first
+    assert tot1 / tot <= 0.2 and totn / tot <= 0.06
+    assert float(err.mean()) <= 1e-2 and float(err.max()) <= 1e-1

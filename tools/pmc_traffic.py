@@ -14,7 +14,8 @@ PATTERNS = {
     "k_conv3_direct": r"\bk_conv3_direct<0,", "k_gemm_split2": r"\bk_gemm_split2<", "k_gemm_geglu": r"\bk_gemm_geglu<",
 }
 # the same templates on other operand types (f16 attention products, fp32 / three-product f16 calibration graph): not int8 layers
-OTHER = r"\bk_(gemm_nt|gemm_nt8|gemm_p|conv3_direct)<[123],"
+# ... and the packed-nibble kernel of the few-row layers (launch-list type "w4": weights are its traffic, a group of its own)
+OTHER = r"\bk_(gemm_nt|gemm_nt8|gemm_p|conv3_direct)<[123],|\bk_gemm_w4\b"
 FAMILY = r"\bk_(gemm|conv3_direct)"
 
 
