@@ -33,6 +33,9 @@
 #ifndef EDADM_USE_NT8
 #define EDADM_USE_NT8 1
 #endif
+#ifndef EDADM_RES_DEPTH
+#define EDADM_RES_DEPTH 4        // residual pieces in flight per lane in the quantising epilogues of the 4-wave kernels
+#endif
 #ifndef EDADM_GEMM_STAGES
 #define EDADM_GEMM_STAGES 3
 #endif
@@ -494,7 +497,12 @@ __device__ __forceinline__ void gemm_epilogue_direct(typename Acc<DT>::type (&ac
 // (lane%32) and four consecutive columns 8g + 4 (lane/32) + e per register group -- the four codes of an int8
 // dword, the two half2 of an f16 store or the two (value, gate) pairs of GEGLU are all in one lane; the column
 // constants come from LDS as float4 broadcasts.
-template <int DT, int TM, int TN, int BN, int RA>
+// RD: residual pieces (16 bytes per lane) in flight.  One piece leaves every register group waiting out a memory round trip; the
+// pieces of a whole row block (RD = 4: all requested before the previous block's store, so the in-order vmcnt never makes one wait
+// behind a store) keep 32 KB per CU in flight at two workgroups per CU: ff.net.2 + residual 141.7 -> 139.2 us at 102400 x 384 x
+// 1536, 70.2 -> 66.7 at 25600 x 576 x 2304, 45.3 -> 43.5 at 6400 x 960 x 3840 (tools/gemm_table.py, same codes).  The
+// 168-register persistent kernel keeps RD = 1 (it has no register to spare).
+template <int DT, int TM, int TN, int BN, int RA, int RD = 1>
 __device__ __forceinline__ void gemm_epilogue_qdirect(typename Acc<DT>::type (&acc)[TM][TN], const float* ec, int lane,
                                                       int64_t row0, int64_t col0, int ecol0, void* __restrict__ outv,
                                                       int64_t ldo, int out_mode, const float* __restrict__ residual = nullptr,
@@ -518,8 +526,14 @@ __device__ __forceinline__ void gemm_epilogue_qdirect(typename Acc<DT>::type (&a
             const int j = q / (TM * 4), i = (q / 4) % TM, g = q & 3;
             return *reinterpret_cast<const float4*>(residual + (row0 + i * 32 + fr) * ldr + col0 + j * 32 + 8 * g + fh4);
         };
-        float4 rnext = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (residual) rnext = res_piece(0);
+        constexpr int QN_ = TN * TM * 4;
+        float4 rq[RD];
+#pragma unroll
+        for (int u = 0; u < RD; ++u) rq[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (residual) {
+#pragma unroll
+            for (int u = 0; u < RD && u < QN_; ++u) rq[u] = res_piece(u);
+        }
         // column constants of group q + 1 are read from LDS before group q is processed (EDADM_EPI_CONST_AHEAD): each group is
         // its own basic block (the exact-division branch), so a read placed where it is used waits out the LDS latency alone
         constexpr int QN = TN * TM * 4;
@@ -558,9 +572,9 @@ __device__ __forceinline__ void gemm_epilogue_qdirect(typename Acc<DT>::type (&a
                     }
                     v[0] = fmaf(v[0], s4.x, b4.x); v[1] = fmaf(v[1], s4.y, b4.y); v[2] = fmaf(v[2], s4.z, b4.z); v[3] = fmaf(v[3], s4.w, b4.w);
                     if (residual) {                        // the lane's four columns are one 16-byte piece of its row
-                        const float4 r4 = rnext;
                         const int q = (j * TM + i) * 4 + g;
-                        if (q + 1 < QN) rnext = res_piece(q + 1);
+                        const float4 r4 = rq[q % RD];
+                        if (q + RD < QN) rq[q % RD] = res_piece(q + RD);
                         v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
                     }
                     if constexpr (MODE == 3) {             // GEGLU on interleaved (a, gate) columns -> two int8 codes
@@ -1077,7 +1091,7 @@ k_gemm_nt(const uint8_t* __restrict__ A, int64_t lda_b, int64_t strideA_b, const
 #endif
 
     if (qdirect) {
-        gemm_epilogue_qdirect<DT, TM, TN, BN, RA>(acc, ec, lane, m0 + wm * (TM * 32), n0 + wn * (TN * 32), wn * (TN * 32), out, ldo,
+        gemm_epilogue_qdirect<DT, TM, TN, BN, RA, EDADM_RES_DEPTH>(acc, ec, lane, m0 + wm * (TM * 32), n0 + wn * (TN * 32), wn * (TN * 32), out, ldo,
                                                   out_mode, residual, ldr, rows_per_batch, N);
         stamp_out();
         return;
@@ -1249,7 +1263,7 @@ k_gemm_ntq(const uint8_t* __restrict__ A, int64_t lda_b, const uint8_t* __restri
             setup(Ln);
             prologue();
         }
-        gemm_epilogue_qdirect<DT, TM, TN, BN, RA>(acc, ec, lane, m0c + wm * (TM * 32), n0c + wn * (TN * 32), wn * (TN * 32), out, ldo,
+        gemm_epilogue_qdirect<DT, TM, TN, BN, RA, EDADM_RES_DEPTH>(acc, ec, lane, m0c + wm * (TM * 32), n0c + wn * (TN * 32), wn * (TN * 32), out, ldo,
                                                   out_mode, residual, ldr, rows_per_batch, N);
         if (!more) break;
         L = Ln;

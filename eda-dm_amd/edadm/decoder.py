@@ -32,8 +32,9 @@ class DecoderEngine:
     def __init__(self, decoder, post_quant_conv=None, codebook=None, chunk_pixels=25 << 16):
         self.dec, self.pq = decoder, post_quant_conv
         for mod in (decoder, post_quant_conv):
-            if mod is not None:
-                ops.init_device(next(mod.parameters()).device)
+            prm = next(mod.parameters(), None) if isinstance(mod, torch.nn.Module) else None
+            if prm is not None:
+                ops.init_device(prm.device)
                 break
         self.codebook = None if codebook is None else codebook.detach().float().contiguous()
         # output pixels per batch chunk: keeps every activation under the gather's 2 GiB (32-bit byte offsets) and bounds the attention

@@ -1585,10 +1585,14 @@ def g20_f16x3_units(threads=None, fname="g20_f16x3_units"):
     checks = []
     orig_step, orig_sample, orig_rand_like = torch.optim.Adam.step, random.sample, torch.rand_like
 
+    grad0 = {}
+
     def step(self, *a, **k):
-        r = orig_step(self, *a, **k)
         ps = [p for gr in self.param_groups for p in gr["params"]]
         key = "%s/%s" % (cur["name"], "a" if ps[0].numel() == 1 else "w")
+        if key not in grad0:                     # iteration 0: the gradients the first Adam step sees (block_recon.py:197-201)
+            grad0[key] = torch.cat([p.grad.detach().flatten() for p in ps]).clone()
+        r = orig_step(self, *a, **k)
         traj.setdefault(key, []).append(torch.cat([p.detach().flatten() for p in ps]).clone())
         return r
 
@@ -1686,6 +1690,12 @@ def g20_f16x3_units(threads=None, fname="g20_f16x3_units"):
         d["final/%s/count" % name] = np.int64(tw.shape[1])
         d["traj/%s/w" % name] = tw[:, ::_g20.STRIDE].clone()
         d["traj/%s/a" % name] = ta
+        # iteration-0 gradients: every STRIDE-th d loss / d alpha, the norm of all of them, every d loss / d delta
+        gw, ga = grad0[name + "/w"], grad0[name + "/a"]
+        d["grad0/%s/w" % name] = gw[::_g20.STRIDE].clone()
+        d["grad0/%s/w_norm" % name] = np.float64(gw.double().norm())
+        d["grad0/%s/w_nonzero" % name] = np.int64((gw != 0).sum())
+        d["grad0/%s/a" % name] = ga.clone()
         d["idx/" + name] = np.array(idx_log[name])
         for k, v in qparams_of(qnn).items():
             if k.startswith("qp/model.%s." % name) and "act_quantizer" in k:
@@ -1695,7 +1705,7 @@ def g20_f16x3_units(threads=None, fname="g20_f16x3_units"):
     d["rand/log"] = np.array(["%s|%s|%d|%s" % (o, p, c, "x".join(map(str, s))) for o, p, c, s in rep.log])
     d["rand/check"] = np.array(checks, dtype=np.float64).reshape(-1, 3)
     if threads:
-        d = {k: v for k, v in d.items() if k.startswith(("final/res/", "final/tf/", "first/")) or (k.startswith("traj/") and k.endswith("/a"))}
+        d = {k: v for k, v in d.items() if k.startswith(("final/res/", "final/tf/", "first/", "grad0/")) or (k.startswith("traj/") and k.endswith("/a"))}
         d["threads"] = np.int64(threads)
     save(fname, d)
 
