@@ -181,7 +181,13 @@ def instrumented_walk(qnn, cali, kwargs, n_calib):
     return dict(units=units, calib_samples=n_calib, iters_per_unit=iters, wall_s=total, caching_s=t_cache[0],
                 loop_s=loop, steady_iterations_s=timing["iter_s"], unit_setup_s=setup, fp_features_s=feat,
                 s_per_iteration_all_units=per_iter_all_units,
-                per_unit_ms=[{"unit": u, "weights": n, "ms_per_iteration": ms} for u, n, ms in timing.get("per_unit", [])],
+                per_unit_ms=[{"unit": u, "weights": n, "ms_per_iteration": ms, "positions_per_row": pos, "data_parallel_eligible": pos >= er.DP_MIN_POSITIONS}
+                             for (u, n, ms), pos in zip(timing.get("per_unit", []), timing.get("per_unit_positions", []))],
+                # steady-state loop seconds of the units whose iterations split over the ranks of a multi-rank job (edadm.recon.DP_LOOP:
+                # >= DP_MIN_POSITIONS feature-map positions / tokens per row, the 64 x 64 and 32 x 32 levels) -- measured per unit
+                dp_eligible_loop_s=sum(ms * 1e-3 * (iters - 1) for (u, n, ms), pos in zip(timing.get("per_unit", []), timing.get("per_unit_positions", []))
+                                       if pos >= er.DP_MIN_POSITIONS),
+                dp_stats=dict(er.DP_STATS),
                 graphed_units=timing.get("graphed_units", 0),
                 h1_roofline={"bound": "mfma", "what": "contractions of the steady-state reconstruction iterations (forward x2-3, input and "
                              "weight gradients; attention products included), executed fp32-equivalent flops counted on the host as they "
@@ -626,19 +632,24 @@ def main():
                 calib_out["metric"] = "full calibration+recon wall-clock, W4A8 LDM-4 ImageNet 256x256, %d x MI355X" % world
                 calib_out["value_s"] = full["wall_s"]
                 st = full["stages"]
-                sharded = st["tdac_s"] + st["caching_s"]
+                dp_loop = full.get("dp_eligible_loop_s", 0.0)
+                sharded = st["tdac_s"] + st["caching_s"] + dp_loop
                 rest = full["wall_s"] - sharded
                 calib_out["multi_rank"] = {
                     "ranks": world,
                     "sharded_stages": "TDAC trajectory batches (one gather of the calibration latents), activation caching of every unit "
-                                      "(one gather per cached slab)",
-                    "replicated_stages": "scale initialisation (the activation ranges are an EMA over the batch sequence), reconstruction "
-                                         "loops (rank 0's alphas / step sizes broadcast after each unit)",
-                    "sharded_s_this_run": sharded, "replicated_s_this_run": rest,
+                                      "(one gather per cached slab), and the reconstruction iterations of the units with >= 1024 positions "
+                                      "per row (64 x 64 and 32 x 32 levels: the 32-row minibatch split over the ranks, partial gradient slabs "
+                                      "all-gathered and added in rank order, SURVEY 8e(2))",
+                    "replicated_stages": "scale initialisation (the activation ranges are an EMA over the batch sequence), the iterations of the "
+                                         "16 x 16 / 8 x 8 / single-layer units (launch-latency bound), per-unit set-up",
+                    "sharded_s_this_run": sharded, "of_which_data_parallel_loop_s": dp_loop, "replicated_s_this_run": rest,
                     # what N ranks can gain at best with this split: the stages of THIS run, sharded ones divided by N / this N
                     "ceiling": {str(n): (rest + sharded * world) / (rest + sharded * world / n) for n in (1, 2, 4, 8)},
-                    "ceiling_note": "speed-up over one rank if the sharded stages scaled perfectly; the loops (three quarters of the job) "
-                                    "would need data parallelism over the 32-row minibatch (SURVEY 8e(2)): DESIGN.md section 7 prices it"}
+                    "ceiling_note": "speed-up over one rank if the sharded stages scaled perfectly, from the per-stage / per-unit seconds "
+                                    "measured in THIS run (collectives and the smaller per-rank kernels' efficiency not priced: an upper "
+                                    "bound); no multi-GPU node was available to this build -- the N-rank path is exercised by the "
+                                    "2-process tests only"}
             if rank == 0:
                 calib_out["h1_contraction"] = time_h1_contraction(dev)
         except Exception as e:

@@ -139,16 +139,56 @@ class FusedAdam:
     def launch(self):
         """device half: gradients into the slab (one multi-tensor copy), one kernel over the flat slab (capturable: reads
         the hyper vector from device memory)"""
+        self.collect()
+        self.apply()
+
+    def collect(self):
+        """gradients into the slab (one multi-tensor copy)"""
         have = [(v, p.grad) for v, p in zip(self.grad_views, self.params) if p.grad is not None]
         if len(have) != len(self.params):
             self.grad.zero_()                                # a parameter without gradient this iteration: a zero one
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+
+    def apply(self):
         ops.adam_step(self.flat, self.grad, self.m, self.v, self.hyper)
+
+    # ---- data-parallel iterations (reconstruct(): DP_LOOP): every rank holds the partial gradient of its rows in `grad`
+    def dp_gather(self, rank, world):
+        """partials of all ranks into dp_buf [world][n] (RCCL: one all_gather_into_tensor over the direct xGMI links; gloo: staged
+        through the host, CPU tests and the two-processes-on-one-GPU test)"""
+        import torch.distributed as dist
+        if getattr(self, "dp_buf", None) is None:
+            self.dp_buf = torch.empty(world, self.grad.numel(), dtype=torch.float32, device=self.grad.device)
+        if dist.get_backend() == "gloo":
+            parts = [torch.empty(self.grad.numel(), dtype=torch.float32) for _ in range(world)]
+            dist.all_gather(parts, self.grad.detach().cpu())
+            for r in range(world):
+                self.dp_buf[r].copy_(parts[r])
+        else:
+            dist.all_gather_into_tensor(self.dp_buf.reshape(-1), self.grad)
+        DP_STATS["gather_bytes"] += self.dp_buf.numel() * 4
+
+    def dp_sum(self):
+        """the full-batch gradient = the partials added in RANK ORDER: one fixed order of fp32 sums for a given world size, the same on
+        every rank (they hold the same dp_buf), so the replicas stay bit-identical without waiting for the end-of-unit broadcast"""
+        self.grad.copy_(self.dp_buf[0])
+        for r in range(1, self.dp_buf.shape[0]):
+            self.grad.add_(self.dp_buf[r])
 
     def step(self):
         self.prepare()
         self.launch()
+
+
+# Data-parallel reconstruction iterations (SURVEY 8e(2), block_recon.py:133-217): with several ranks, a unit whose rows are large
+# (DP_MIN_POSITIONS feature-map positions / tokens per row: the 64 x 64 and 32 x 32 levels of LDM-4) splits every minibatch over the
+# ranks -- rank r forwards / backwards rows r, r + N, ... of the SAME drawn minibatch with the loss scaled by 1 / N, the partial
+# d loss / d alpha and d loss / d delta slabs are all-gathered and added in rank order, and every rank takes the same Adam step.
+# Smaller units stay replicated (their iterations are bound by launch latency, not by work).  One rank: nothing changes.
+DP_LOOP = True
+DP_MIN_POSITIONS = 1024
+DP_STATS = {"units": 0, "iters": 0, "gather_bytes": 0}
 
 
 def _as_param(q):
@@ -272,6 +312,7 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
     save_fn = save_fn or save_inp_oup_data
     # the device-side mask epoch counts graph replays; every unit starts from 0 so that a calibration is a function of
     # (random.seed, seed_mask_rng) alone, however many replays earlier units ran (edadm.h: epoch 0 leaves seeds as passed)
+    rank, world = edist.world()
     ops.rng_epoch(0)
     unit.set_quant_state(True, act_quant)
     round_mode = 'learned_hard_sigmoid'
@@ -361,9 +402,17 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
         batched = False
     STATE["batched"] = batched                                # mirror of the LAST unit for the parity tests' mask replay ...
     unit.recon_batched = batched                              # ... the unit carries its own flag (interleaved reconstructions)
+    positions = (cached_outs.shape[-1] * cached_outs.shape[-2]) if cached_outs.dim() == 4 else (cached_outs.shape[1] if cached_outs.dim() == 3 else 1)
+    dp = bool(DP_LOOP and world > 1 and batch_size % world == 0 and positions >= DP_MIN_POSITIONS and (w_opt or a_opt) and cached_outs.is_cuda)
+    unit.recon_dp = dp
+    if dp:
+        # every rank draws its own masks: the device-side epoch (mixed into every kernel seed) starts from a rank-specific value
+        ops.rng_epoch(rank << 20)
+        DP_STATS["units"] += 1
+        DP_STATS["iters"] += iters
 
-    def body():
-        idx_t = idx_buf
+    def body(apply=True):
+        idx_t = idx_buf[rank::world] if dp else idx_buf          # data parallel: rows r, r + N, ... of the drawn minibatch
         cur_out = cached_outs[idx_t]
         if resblock:
             cur_inp, cur_sym = cached_inps[0][0][idx_t], cached_inps[1][0][idx_t]
@@ -407,10 +456,15 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
             for j in range(len(module_r) - 1):
                 m_loss = m_loss + lp_loss(module_q[j], module_r[j], p=2)
         loss = loss_func(out_quant, cur_out) + add_loss * m_loss
+        if dp:
+            loss = loss / world                                  # both terms are means over the rows: the partials add up to the minibatch's
         loss.backward()
         for o in (w_opt, a_opt):
             if o:
-                o.launch()
+                if apply:
+                    o.launch()
+                else:
+                    o.collect()
         for h in hooks:                       # tensors of this iteration must not outlive it (they would pin the autograd
             h.out = h.feature = None          # graph of a captured iteration past the end of the capture)
 
@@ -444,6 +498,40 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
         for o in (w_opt, a_opt):
             if o:
                 o.prepare_row()
+        if dp:
+            # forward / backward of this rank's rows (graph A once captured) -> all-gather of the partial slabs (eager: a collective)
+            # -> rank-ordered sum + Adam (graph B)
+            if graph is not None:
+                graph[0].replay()
+            elif use_graph and it >= GRAPH_WARMUP:
+                ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                from . import contract
+                f0 = contract.FLOPS[0]
+                with torch.cuda.graph(ga, capture_error_mode="thread_local"):
+                    ops.rng_epoch(1, add=True)
+                    body(apply=False)
+                if TIMING is not None:
+                    TIMING["flops"] = TIMING.get("flops", 0.0) + (contract.FLOPS[0] - f0) * (iters - t_first)
+                with torch.cuda.graph(gb, capture_error_mode="thread_local"):
+                    for o in (w_opt, a_opt):
+                        if o:
+                            o.dp_sum()
+                            o.apply()
+                graph = (ga, gb)
+                graph[0].replay()
+            else:
+                body(apply=False)
+            for o in (w_opt, a_opt):
+                if o:
+                    o.dp_gather(rank, world)
+            if graph is not None:
+                graph[1].replay()
+            else:
+                for o in (w_opt, a_opt):
+                    if o:
+                        o.dp_sum()
+                        o.apply()
+            continue
         if graph is not None:
             graph.replay()
             continue
@@ -469,6 +557,7 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
         TIMING["graphed_units"] = TIMING.get("graphed_units", 0) + int(use_graph)
         TIMING.setdefault("per_unit", []).append((type(unit).__name__, sum(p.numel() for p in w_para),
                                                   1e3 * (time.time() - _t_steady) / (iters - t_first)))
+        TIMING.setdefault("per_unit_positions", []).append(int(positions))
     for module in modules:
         if isinstance(module, QuantModule):
             module.weight_quantizer.soft_targets = False

@@ -1554,7 +1554,7 @@ class _G20Host(nn.Module):
                                         context_dim=_g20.TF["context_dim"], gated_ff=True, checkpoint=False)
 
 
-def g20_f16x3_units(threads=None, fname="g20_f16x3_units"):
+def g20_f16x3_units(threads=None, fname="g20_f16x3_units", input_ulp=False, iters=None):
     """G20: qdiff_control.block_reconstruction (qdiff_control/block_recon.py:13-243) on ONE LDM-4-sized ResBlock (192 -> 384 at
     32 x 32) and ONE transformer block (d = 384, 1024 tokens), 32-row minibatches, the shipped ImageNet hyper-parameters and
     0.5 / 0.5 masks -- the size at which the product contracts on its three-product f16 kernels.  Weights, cached unit inputs
@@ -1616,12 +1616,16 @@ def g20_f16x3_units(threads=None, fname="g20_f16x3_units"):
         return torch.from_numpy(u)
 
     kwargs = dict(_g20.HYPER)
-    kwargs.update(cali_data=None, iters=_g20.ITERS)
+    kwargs.update(cali_data=None, iters=iters or _g20.ITERS)
     for name in ("res", "tf"):
         t0 = time.time()
         unit = getattr(qnn.model, name)
         cq, cf = _g20.caches(name)
         cq, cf = [torch.from_numpy(a) for a in cq], [torch.from_numpy(a) for a in cf]
+        if input_ulp:
+            # the conditioning probe: every cached input moved by (at most) one unit in the last place, nothing else changed
+            cq = [a * np.float32(1 + 2.0 ** -23) for a in cq]
+            cf = [a * np.float32(1 + 2.0 ** -23) for a in cf]
         # initial scales the reference's way (set_quantize_params.py:48-69 / :9-46 on the unit): weight quantizers from one
         # forward in the (True, False) state, activation quantizers over two batches of 32 of the quantised-prefix inputs
         uaqs = [(n, m) for n, m in unit.named_modules() if isinstance(m, UniformAffineQuantizer)]
@@ -1644,6 +1648,22 @@ def g20_f16x3_units(threads=None, fname="g20_f16x3_units"):
         for n, m in uaqs:
             if m.leaf_param:
                 m.set_inited(True)
+        if input_ulp:
+            # the probe moves the INPUTS only: the scales are the unperturbed run's (an MSE search over 100 candidates may pick
+            # another candidate for a one-ulp change -- a 1 % step, not a rounding effect)
+            base = np.load(os.path.join(HERE, "g20_f16x3_units.npz"))
+            with torch.no_grad():
+                for n, m in uaqs:
+                    k = "init/qp/model.%s.%s" % (name, n)
+                    if k + "/delta" not in base.files:           # a wrapper's own (unused, never initialised) quantizer
+                        continue
+                    for attr, key in (("delta", k + "/delta"), ("zero_point", k + "/zero_point")):
+                        cur = getattr(m, attr)
+                        new = torch.as_tensor(base[key]).reshape(cur.shape).to(cur.dtype)
+                        if isinstance(cur, torch.nn.Parameter):
+                            cur.copy_(new)
+                        else:
+                            setattr(m, attr, new)
         print(name, "scales initialised %.0f s" % (time.time() - t0))
         for k, v in qparams_of(qnn).items():
             if k.startswith("qp/model.%s." % name):
@@ -1707,6 +1727,9 @@ def g20_f16x3_units(threads=None, fname="g20_f16x3_units"):
     if threads:
         d = {k: v for k, v in d.items() if k.startswith(("final/res/", "final/tf/", "first/", "grad0/")) or (k.startswith("traj/") and k.endswith("/a"))}
         d["threads"] = np.int64(threads)
+    if input_ulp:
+        d = {k: v for k, v in d.items() if k.startswith("grad0/")}
+        d["input_scale"] = np.float32(1 + 2.0 ** -23)
     save(fname, d)
 
 
@@ -1717,13 +1740,22 @@ def g20_noise_floor():
     g20_f16x3_units(threads=3, fname="g20_reference_3threads")
 
 
+def g20_ulp_floor():
+    """How well is the reference's OWN iteration-0 gradient defined?  The G20 run (scales initialised, then ONE iteration) with every
+    cached unit input multiplied by 1 + 2^-23 -- a perturbation of one unit in the last place, the size of any fp32 rounding
+    difference between two correct implementations.  The gradient is a function of pred - target through 8-bit fake-quantisers
+    whose codes flip at .5 boundaries, so it is far less well conditioned than its inputs: the distance between the two REFERENCE
+    gradients is the floor the product's gradient can be held to (tests/test_fullsize_gpu.py)."""
+    g20_f16x3_units(fname="g20_reference_ulp", input_ulp=True, iters=1)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     jobs = dict(g1=g1_weight_init, g2=g2_act_init, g3=g3_uaq_forward, g4=g4_adaround, g5=g5_loss,
                 g6=g6_quant_module, g7=g7_blocks, g8=g8_g12_recon, g9=g9_tdac, g10=g10_steps,
                 g13c=g13_cifar_unet, g13i=lambda: g13_ldm_unet("imagenet"), g13h=lambda: g13_ldm_unet("church"), g14=g14_plms, g15=g15_decoder,
                 g17=g17_tdac_imagenet, g7b=g7b_blocks, g13w8=lambda: g13_cifar_unet(8, "g13_cifar_w8", 1301), g13sd=g13_ldm_sd, g16=g16_layer_recon,
-                g8b=g8b_recon_masks, g8c=g8c_recon_caches, g18=g18_church_driver, g19=g19_tdac_others, g1b=g1b_max_init, g20=g20_f16x3_units, g20n=g20_noise_floor)
+                g8b=g8b_recon_masks, g8c=g8c_recon_caches, g18=g18_church_driver, g19=g19_tdac_others, g1b=g1b_max_init, g20=g20_f16x3_units, g20n=g20_noise_floor, g20u=g20_ulp_floor)
     for k, fn in jobs.items():
         if not only or k in only:
             print("==", k)

@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _calibrate(world_rank=None):
+def _calibrate(world_rank=None, dp=False):
     for p in (os.path.join(ROOT, "tests"), os.path.join(ROOT, "eda-dm_amd"), ROOT):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -49,28 +49,37 @@ def _calibrate(world_rank=None):
     # iterations >= GRAPH_MIN_ITERS: from the third one on the iteration is captured into a HIP graph and replayed WHILE the
     # process group of the two ranks is alive (capture in thread-local error mode, edadm/recon.py)
     import edadm.recon as recon
-    old = recon.GRAPH_MIN_ITERS
+    old = recon.GRAPH_MIN_ITERS, recon.DP_MIN_POSITIONS
     recon.GRAPH_MIN_ITERS = 4
+    if dp:
+        recon.DP_MIN_POSITIONS = 1           # the toy unit (8 x 8) takes the data-parallel iterations of the 64 x 64 / 32 x 32 levels
+        recon.DP_STATS.update(units=0, iters=0, gather_bytes=0)
     try:
-        block_reconstruction(qnn, qnn.model.rb, cali_data=cali, iters=8, act_quant=True, asym=True, opt_mode="mse", lr_a=1e-4,
-                             lr_w=5e-2, p=2.0, weight=0.0001, b_range=(20, 2), warmup=0.2, batch_size=16, input_prob=0.5,
+        # dp: no stochastic masks (input_prob 1, quantizer prob 1) -- what is compared is the arithmetic of the split minibatch
+        block_reconstruction(qnn, qnn.model.rb, cali_data=cali, iters=24 if dp else 8, act_quant=True, asym=True, opt_mode="mse", lr_a=1e-4,
+                             lr_w=5e-2, p=2.0, weight=0.0001, b_range=(20, 2), warmup=0.2, batch_size=16, input_prob=1.0 if dp else 0.5,
                              add_loss=0.8, recon_w=True, recon_a=True)
     finally:
-        recon.GRAPH_MIN_ITERS = old
+        recon.GRAPH_MIN_ITERS, recon.DP_MIN_POSITIONS = old
     torch.cuda.synchronize()
+    alphas = torch.cat([m.alpha.detach().flatten() for m in qnn.model.rb.modules() if type(m).__name__ == "AdaRoundQuantizer"])
+    from qdiff.quant_layer import UniformAffineQuantizer
+    deltas = torch.cat([m.delta.detach().flatten() for m in qnn.model.rb.modules() if isinstance(m, UniformAffineQuantizer) and m.leaf_param and m.delta is not None])
     return {"inp_q": ci[0][0].cpu().numpy(), "temb_q": ci[0][1].cpu().numpy(), "inp_fp": ci[1][0].cpu().numpy(),
             "out_fp": co.cpu().numpy(), "alpha": qnn.model.rb.conv1.weight_quantizer.alpha.detach().cpu().numpy(),
-            "delta": qnn.model.rb.conv2.act_quantizer.delta.detach().cpu().numpy()}
+            "delta": qnn.model.rb.conv2.act_quantizer.delta.detach().cpu().numpy(),
+            "all_alpha": alphas.cpu().numpy(), "all_delta": deltas.cpu().numpy(), "dp_units": recon.DP_STATS["units"] if dp else 0,
+            "dp_flag": bool(getattr(qnn.model.rb, "recon_dp", False))}
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, dp=False):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         sys.path.insert(0, os.path.join(ROOT, "eda-dm_amd"))
         from edadm import dist as ed
         ed.GATHER_STATS.update(bytes=0, calls=0)
-        out = _calibrate()
+        out = _calibrate(dp=dp)
         out["gathered_bytes"], out["gather_calls"] = ed.GATHER_STATS["bytes"], ed.GATHER_STATS["calls"]
         ret[rank] = out
     finally:
@@ -94,6 +103,30 @@ def test_two_ranks_shard_the_caching_and_end_identical():
     # the loop itself is deterministic given (idx stream, mask seeds): the two-rank run equals the one-rank run
     assert np.array_equal(r0["alpha"], alone["alpha"]) and np.array_equal(r0["delta"], alone["delta"])
     assert r0["gather_calls"] >= 5 and r0["gathered_bytes"] > 0
+
+
+def test_two_ranks_split_the_minibatch_of_a_reconstruction_iteration():
+    """SURVEY 8e(2) / block_recon.py:133-217 on two ranks: each rank forwards / backwards its 8 of the 16 drawn rows (loss / 2), the
+    partial d loss / d alpha and d loss / d delta slabs are all-gathered and added in rank order, both ranks take the same Adam step
+    -- eager for the first iterations, then as two HIP graphs around the collective.  Both ranks end with the same bits; against
+    the one-rank loop (the whole minibatch in one forward) only the order of the fp32 sums over the rows differs: the final hard
+    roundings agree except for alphas that end next to zero, the step sizes to 1e-3."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), ret, True), nprocs=2, join=True)
+    alone = _calibrate(dp=True)                                    # one process: world 1, the plain loop on the same draws
+    r0, r1 = ret[0], ret[1]
+    assert r0["dp_flag"] and r1["dp_flag"] and r0["dp_units"] == 1 and not alone["dp_flag"]
+    assert np.array_equal(r0["all_alpha"], r1["all_alpha"]) and np.array_equal(r0["all_delta"], r1["all_delta"])
+    a, b = r0["all_alpha"], alone["all_alpha"]
+    flips = (a >= 0) != (b >= 0)
+    near = (np.abs(a) < 0.05) & (np.abs(b) < 0.05)
+    rel = np.abs(r0["all_delta"] - alone["all_delta"]) / np.abs(alone["all_delta"])
+    print("data-parallel iterations, 2 ranks vs 1: %d of %d hard roundings differ (%d not next to zero), alpha max |diff| %.2e, "
+          "step sizes max rel %.2e" % (int(flips.sum()), a.size, int((flips & ~near).sum()), float(np.abs(a - b).max()), float(rel.max())))
+    assert int((flips & ~near).sum()) == 0
+    assert flips.mean() <= 2e-3
+    assert rel.max() <= 1e-3
 
 
 def _tdac_real():

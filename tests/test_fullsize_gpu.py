@@ -221,7 +221,9 @@ def _g20_run(name, g, caches, f16x3):
     got_log = sorted("%s|%s|%d|%s" % (o, p, c, "x".join(map(str, s))) for o, p, c, s in rep.log)
     tw, ta = torch.stack(traj_w), torch.stack(traj_a)
     return dict(tw=tw, ta=ta.cpu().numpy(), alpha0=torch.cat(alpha0), calls=calls, log=got_log, batched=recon.STATE["batched"],
-                g0w=grad0["w"].cpu().double().numpy(), g0a=grad0["a"].cpu().double().numpy())
+                g0w=grad0["w"].cpu().double().numpy(), g0a=grad0["a"].cpu().double().numpy(),
+                sizes=[(qn, m.alpha.numel()) for qn, m in unit.named_modules() if isinstance(m, AdaRoundQuantizer)],
+                a_names=[qn for qn, m in unit.named_modules() if isinstance(m, UniformAffineQuantizer) and m.leaf_param])
 
 
 @pytest.mark.parametrize("name", ["res", "tf"])
@@ -286,6 +288,17 @@ def test_recon_unit_f16x3_vs_exact_fp32_vs_reference(golden, name):
         print("G20 %s [%s] iteration-0 gradients vs REFERENCE: d loss / d alpha rel L2 %.2e over %d strided alphas (norm of all %d: rel %.2e); "
               "d loss / d delta rel L2 %.2e, worst element %.2e of the largest"
               % (name, label, r["gw_rel"], pw.size, r["g0w"].size, r["gw_norm_rel"], r["ga_rel"], r["ga_worst"]))
+        # per layer: where the distance sits
+        pos, off, rows = np.arange(0, r["g0w"].size, _g20.STRIDE), 0, []
+        for qn, k in r["sizes"]:
+            sel = (pos >= off) & (pos < off + k)
+            if sel.any():
+                rows.append("%s %.1e (|g| %.1e)" % (qn.replace(".weight_quantizer", ""), np.linalg.norm(pw[sel] - rw[sel]) / max(np.linalg.norm(rw[sel]), 1e-30),
+                                                  np.linalg.norm(rw[sel])))
+            off += k
+        print("   per layer d alpha rel L2:", "; ".join(rows))
+        if len(r["a_names"]) == pa.size:
+            print("   per quantiser d delta (product / reference):", "; ".join("%s %.4g/%.4g" % (n_.split(".", 2)[-1], a_, b_) for n_, a_, b_ in zip(r["a_names"], pa, ra)))
         print("   not next to zero:", [(i, float(af[i]), bool(ref_sign[i]), bool(ref_near[i])) for i in far[:8]])
     extra = bad[True] - bad[False]
     print("G20 %s: disagreements with the reference -- f16x3 %d, exact fp32 %d, in f16x3 only %d, in exact only %d"

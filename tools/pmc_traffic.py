@@ -1,6 +1,6 @@
 """HBM bytes per launch of the int8 GEMM / convolution kernels from rocprofv3 --pmc counter CSVs (separate FETCH_SIZE and
 WRITE_SIZE passes), per kernel, against each kernel's own ALGORITHMIC bytes:
-    python tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json> <launch_list.json>
+    python tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json> <launch_list.json> [N_CALLS]
 The kernels are selected by the ENGINE'S launch list (tools/unet_prof.py LAUNCH_LIST=...: every int8 layer launch of one UNet
 call with the kernel structure the library picked), not by a hand-kept substring list: a kernel the list names that the profile
 does not hold, a profile row of the GEMM family that no launch claims, or a launch count that is not a whole number of UNet calls
@@ -20,15 +20,38 @@ FAMILY = r"\bk_(gemm|conv3_direct)"
 
 
 def load(d, counter):
-    per = {}
+    """[(dispatch id, kernel name, counter value)] in dispatch order"""
+    rows = []
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if r.get("Counter_Name") != counter:
-                continue
-            c = per.setdefault(r["Kernel_Name"], [0, 0.0])
-            c[0] += 1
-            c[1] += float(r["Counter_Value"])
-    return per
+            if r.get("Counter_Name") == counter:
+                rows.append((int(r["Dispatch_Id"]), r["Kernel_Name"], float(r["Counter_Value"])))
+    rows.sort()
+    return rows
+
+
+def tail_sums(rows, per_call, calls):
+    """per structure: the LAST calls x per_call[structure] dispatches of the run -- the UNet calls unet_prof.py issues after its
+    MARK.  Everything earlier (scale initialisation, the hoisted one-token context branches and time-embedding rows, warm-up calls,
+    the launch-list pass) is left out by construction instead of by arithmetic on launch counts."""
+    by = {}
+    for _, name, v in rows:
+        k = classify(name)
+        if k is not None:
+            by.setdefault(k, []).append((name, v))
+    out = {}
+    for k, n in per_call.items():
+        if k not in by:
+            raise SystemExit("the launch list names %s, the profile holds no such kernel" % k)
+        want = n * calls
+        if len(by[k]) < want:
+            raise SystemExit("%s: %d dispatches in the profile, %d needed for %d UNet calls" % (k, len(by[k]), want, calls))
+        tail = by[k][-want:]
+        out[k] = {"launches": want, "KB": sum(v for _, v in tail), "names": sorted(set(nm.split("(")[0] for nm, _ in tail))}
+    for k in by:
+        if k not in per_call:
+            raise SystemExit("the profile holds int8 %s launches, the launch list names none" % k)
+    return out
 
 
 def classify(name):
@@ -45,6 +68,7 @@ def classify(name):
 def main():
     fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
     lst = json.load(open(sys.argv[4]))
+    calls = int(sys.argv[5]) if len(sys.argv) > 5 else 2       # N_CALLS of unet_prof.py: the calls after its MARK
     # per structure: launches and algorithmic bytes of ONE UNet call (a launch that issued two kernels -- tail re-tiling -- is
     # split between them by launch count only: its bytes stay with the first, stated in the output)
     alg = {}
@@ -60,42 +84,13 @@ def main():
             if i == 0:
                 a["bytes"] += b
                 a["flop"] += r["flop"]
-    # launches of the same kernels OUTSIDE the UNet call (the one-token context branches and time-embedding rows a sampling loop
-    # hoists: M = 100 rows, issued `hoisted_issued` times by unet_prof.py): counted out of the launch arithmetic; their bytes
-    # (< 0.1 % of a call's) stay in the sums
-    hoisted = {}
-    for r in lst.get("hoisted_rows", []):
-        if r["type"] == "i8":
-            for k in r["kernels"]:
-                hoisted[k] = hoisted.get(k, 0) + int(lst.get("hoisted_issued", 1))
-    pmc = {}
-    for name, (n, kb) in fetch.items():
-        k = classify(name)
-        if k is None:
-            continue
-        p = pmc.setdefault(k, {"launches": 0, "fetch_KB": 0.0, "write_KB": 0.0, "names": []})
-        p["launches"] += n
-        p["fetch_KB"] += kb
-        p["write_KB"] += write.get(name, [0, 0.0])[1]
-        p["names"].append(name.split("(")[0])
-    for k in alg:
-        if k not in pmc:
-            raise SystemExit("the launch list names %s, the profile holds no such kernel" % k)
-    for k in pmc:
-        if k not in alg:
-            raise SystemExit("the profile holds int8 %s launches, the launch list names none" % k)
-    calls = None
+    per_call = {k: a["launches"] for k, a in alg.items()}
+    fs, ws = tail_sums(fetch, per_call, calls), tail_sums(write, per_call, calls)
     per_kernel = {}
     for k, a in sorted(alg.items()):
-        p = pmc[k]
-        c = (p["launches"] - hoisted.get(k, 0)) / a["launches"]
-        if abs(c - round(c)) > 1e-9 or (calls is not None and round(c) != calls):
-            raise SystemExit("%s: %d profiled launches are not a whole / the same number of UNet calls of %d launches (others: %s)"
-                             % (k, p["launches"], a["launches"], calls))
-        calls = int(round(c))
-        hbm = (p["fetch_KB"] * 2 + p["write_KB"]) * 1024 / calls
-        per_kernel[k] = {"names": sorted(set(p["names"])), "launches_per_unet_call": a["launches"],
-                         "fetch_bytes_per_call_corrected": p["fetch_KB"] * 2 * 1024 / calls, "write_bytes_per_call": p["write_KB"] * 1024 / calls,
+        hbm = (fs[k]["KB"] * 2 + ws[k]["KB"]) * 1024 / calls
+        per_kernel[k] = {"names": fs[k]["names"], "launches_per_unet_call": a["launches"],
+                         "fetch_bytes_per_call_corrected": fs[k]["KB"] * 2 * 1024 / calls, "write_bytes_per_call": ws[k]["KB"] * 1024 / calls,
                          "hbm_bytes_per_call": hbm, "algorithmic_bytes_per_call": a["bytes"], "traffic_over_algorithmic": hbm / a["bytes"] if a["bytes"] else None,
                          "algorithmic_flop_per_call": a["flop"]}
     nl = sum(a["launches"] for a in alg.values())
