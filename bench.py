@@ -17,6 +17,7 @@ stage by stage (`calibration.stages`), with the reconstruction loop's roofline (
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -321,6 +322,77 @@ def cpu_baseline(qnn, sd_cpu):
                                "note": "a forward costs the same at every timestep: images/s = 1 / (20 x mean forward time)"})
 
 
+def calibration_cpu_baseline():
+    """The calibration half of the metric on this box's host cores (SURVEY 8(d) CPU plan (ii)-(iv)): the oracle -- the CPU
+    restatement of qdiff_control/block_recon.py:133-217, qdiff/quant_layer.py:234-244 and qdiff/data_utils.py:133-139 on the
+    reference's own torch operators -- on ONE reconstruction unit of the headline model, the LDM-4 ResBlock 192 -> 384 at 32 x 32 (2.36 M
+    AdaRound alphas), at the shipped minibatch of 32 rows and the shipped hyper-parameters: seconds per reconstruction iteration
+    (three forwards + backward + two Adam steps), seconds per batch of the activation-scale initialisation (the MSE search of every
+    activation quantiser of the unit) and of the FP target forward.  Random-init weights; a bounded sample: two iterations."""
+    import random
+    from oracle import qdiff_oracle as O
+    g = torch.Generator().manual_seed(11)
+    shapes = {"in_layers.0.weight": (192,), "in_layers.0.bias": (192,), "in_layers.2.weight": (384, 192, 3, 3), "in_layers.2.bias": (384,),
+              "emb_layers.1.weight": (384, 768), "emb_layers.1.bias": (384,), "out_layers.0.weight": (384,), "out_layers.0.bias": (384,),
+              "out_layers.3.weight": (384, 384, 3, 3), "out_layers.3.bias": (384,), "skip_connection.weight": (384, 192, 1, 1),
+              "skip_connection.bias": (384,)}
+    sd = {}
+    for k, shp in shapes.items():
+        if len(shp) == 1:
+            sd["res." + k] = (torch.ones(shp) if k.endswith("0.weight") else torch.zeros(shp)) + 0.1 * torch.randn(shp, generator=g)
+        else:
+            fan = int(np.prod(shp[1:]))
+            sd["res." + k] = torch.randn(shp, generator=g) / math.sqrt(fan)
+    unit = O.OResBlock(O._Builder(sd, WQ, AQ, 8), "res", "res", 192, 384)
+    rows = 32
+    x, emb = torch.randn(rows, 192, 32, 32, generator=g), torch.randn(rows, 768, generator=g)
+    xq, eq = x + 0.05 * torch.randn(x.shape, generator=g), emb + 0.02 * torch.randn(emb.shape, generator=g)
+    t = {}
+    with torch.no_grad():
+        unit.set_quant_state(False, False)
+        t0 = time.time()
+        out_fp = unit(x, emb)
+        t["fp_target_forward_s_per_batch"] = time.time() - t0
+        unit.set_quant_state(True, False)                      # weight scales: per-channel MSE search on the first quantised forward
+        t0 = time.time()
+        unit(xq, eq)
+        t["weight_scale_init_s"] = time.time() - t0
+        for l in unit.layers():
+            l.weight_quantizer.inited = True
+        unit.set_quant_state(True, True)                       # activation scales: MSE search per quantiser on this batch
+        t0 = time.time()
+        unit(xq, eq)
+        t["act_scale_init_s_per_batch"] = time.time() - t0
+        for l in unit.layers():
+            for q in l.quantizers():
+                q.inited = True
+    stamps = [time.time()]
+
+    class _Stop(Exception):
+        pass
+
+    def trace(it, wp, ap, loss):
+        stamps.append(time.time())
+        if len(stamps) == 3:
+            raise _Stop
+
+    random.seed(7)
+    try:
+        O.reconstruct_unit(None, unit, "block", cali=None, iters=1000, act_quant=True, lr_a=SHIPPED_RECON["lr_a"], lr_w=SHIPPED_RECON["lr_w"], p=2.0,
+                           batch_size=rows, input_prob=SHIPPED_RECON["input_prob"], add_loss=SHIPPED_RECON["add_loss"], recon_w=True,
+                           recon_a=True, caches=(True, (xq, eq), (x, emb), out_fp), trace=trace)
+    except _Stop:
+        pass
+    it_s = [b - a for a, b in zip(stamps[:-1], stamps[1:])]
+    per_iter = float(np.mean(it_s))
+    return dict(value=per_iter, unit="s per reconstruction iteration (one unit, 32 rows)", cores=torch.get_num_threads(), kind="port",
+                sample="LDM-4 ResBlock 192 -> 384 at 32 x 32 (2 359 296 alphas), shipped hyper-parameters (input_prob 0.5, quantizer prob 0.5, add_loss "
+                       "0.8): %d iterations timed, %.1f s of CPU work in all" % (len(it_s), sum(it_s) + sum(t.values())),
+                iterations_s=it_s, **t,
+                note="the job runs 1000 such iterations on each of 80 units (this one is a mid-sized one: 4.97 ms per iteration on the GPU, "
+                     "`per_unit_ms`) after 32 batches of scale initialisation and 2 x 32 cached forward batches per unit")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -563,6 +635,11 @@ def main():
             except Exception as e:      # the baseline is a report, never a reason to lose the bench line
                 line["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": torch.get_num_threads(),
                                         "kind": "port", "sample": "failed: %r" % (e,)}
+            try:
+                line["calibration"]["cpu_baseline"] = calibration_cpu_baseline()
+            except Exception as e:
+                line["calibration"]["cpu_baseline"] = {"value": None, "unit": "s per reconstruction iteration", "cores": torch.get_num_threads(),
+                                                       "kind": "port", "sample": "failed: %r" % (e,)}
     # ---- configs 2, 3, 5 at full size, timed by THIS run (tools/config_bench.py::quick_call_numbers): one UNet call each at the shipped
     # rows per call on the frozen int8 executor
     if rank == 0 and world == 1 and not args.no_configs:
@@ -575,14 +652,29 @@ def main():
             import gc
             gc.collect()
             torch.cuda.empty_cache()
-            for kind, label in (("cifar", "2: CIFAR-10 DDIM 32x32 W4A8, 500 rows per call"), ("church", "3: LSUN-Church LDM-8 256x256 W4A8, 100 rows per call"),
-                                ("sd", "5: Stable Diffusion v1-4 512x512 W4A8, 4 prompts x CFG = 8 rows per call")):
+            from types import SimpleNamespace
+            # the sampling loop of each configuration at full size (tools/config_bench.py: CIFAR 500 x 100 quad-skip DDIM steps,
+            # Church 100 x 20 of the shipped 500 steps, Stable Diffusion 4 prompts x CFG x 50 PLMS steps), ONE batch timed after a
+            # warm-up batch: images / s, the UNet call's time inside the loop and a roofline per configuration -- the algorithmic
+            # rate of the whole loop (images / s x FLOP / image) and the int8 GEMM group's executed rate, both from
+            # events / wall time of THIS run
+            for kind, fn in (("cifar", cb.run_cifar), ("church", cb.run_church), ("sd", cb.run_sd)):
                 t0c = time.time()
                 try:
-                    r = cb.quick_call_numbers(kind, dev)
+                    with torch.no_grad():
+                        r = fn(dev, SimpleNamespace(batch=0, steps=0, calls=0, batches=1))
+                    gg = r.get("gemm_group", {})
+                    r["roofline"] = {"bound": "mfma", "achieved": r["algorithmic_tflops"], "peak": I8_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                     "frac": r["algorithmic_tflops"] / I8_PEAK_TFLOPS,
+                                     "definition": "algorithmic conv / linear / attention matmul FLOPs of the loop's UNet calls (SURVEY 8(d) per-row "
+                                                   "figures) / wall time of the timed batch / dense int8 MFMA peak",
+                                     "int8_gemm_group": {"achieved": gg.get("int8_gemm_tflops"), "frac": gg.get("frac_of_int8_mfma_peak"),
+                                                         "launches": gg.get("int8_gemm_calls"), "ms": gg.get("int8_gemm_ms"),
+                                                         "definition": "executed flops of every int8 GEMM launch of one UNet call / their summed device "
+                                                                       "time (HIP events, warm)"}}
                 except Exception as e:
                     r = {"error": repr(e)}
-                r["config"], r["wall_s"] = label, time.time() - t0c
+                r["wall_s"] = time.time() - t0c
                 cfgs[kind] = r
                 gc.collect()
                 torch.cuda.empty_cache()

@@ -33,6 +33,9 @@
 #ifndef EDADM_USE_NT8
 #define EDADM_USE_NT8 1
 #endif
+#ifndef EDADM_P_DEPTH
+#define EDADM_P_DEPTH 2          // K-steps of 64 bytes a loader wave of the persistent kernel keeps in flight
+#endif
 #ifndef EDADM_RES_DEPTH
 #define EDADM_RES_DEPTH 4        // residual pieces in flight per lane in the quantising epilogues of the 4-wave kernels
 #endif
@@ -1540,7 +1543,10 @@ k_gemm_p(const uint8_t* __restrict__ A, int64_t lda_b, const uint8_t* __restrict
          float* __restrict__ out, int64_t ldo, float alpha, int out_mode, const float* __restrict__ oqp) {
     constexpr int TM = 2, BM = 256, BN = 64 * TN;
     constexpr int S = KSTEP == 64 ? 5 : 2;       // LDS ring slots (64-byte steps: 5 x 28 KiB = the whole K of a 384-wide layer)
-    constexpr int D = 128 / KSTEP;               // K-steps a loader wave keeps in flight in registers
+    // K-steps a loader wave keeps in flight in registers.  tools/geglu_stamps.py (round 5): on the 384-deep GEGLU projection the
+    // LOADER is the critical path -- 271 k of the launch's 481 k cycles in load issue, the MFMA waves wait 5.7 k cycles per tile --
+    // and it is bound by latency x bytes in flight (two 64-byte steps = 14 KB per wave), not by any bandwidth: EDADM_P_DEPTH steps
+    constexpr int D = KSTEP == 64 ? EDADM_P_DEPTH : 1;
     constexpr int CPR = KSTEP / 16;              // 16-byte chunks per operand row
     constexpr int RPP = 64 / CPR;                // rows per 1-KiB direct-to-LDS piece
     constexpr int NA = BM / RPP / 4, NB = BN / RPP / 4;      // pieces per loader wave per K-step
@@ -1608,7 +1614,7 @@ k_gemm_p(const uint8_t* __restrict__ A, int64_t lda_b, const uint8_t* __restrict
         constexpr int NEC = ((2 + RA) * BN + 255) / 256;             // epilogue constants per loader lane
         float ecv[NEC], ecq = 0.f;
         typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-        u32x4 buf0[PPW], buf1[D > 1 ? PPW : 1];                        // one register set per K-step in flight
+        u32x4 buf[D][PPW];                                             // one register set per K-step in flight
         typedef const __attribute__((address_space(1))) u32x4* gptr4;   // keep the loads global_load (not flat)
 
         auto setup_tile = [&](int T) {
@@ -1692,12 +1698,12 @@ k_gemm_p(const uint8_t* __restrict__ A, int64_t lda_b, const uint8_t* __restrict
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 const u32x4 v = *(gptr4)(uintptr_t)src[i];
-                if constexpr (SLOT == 0) buf0[i] = v; else buf1[i] = v;
+                buf[SLOT][i] = v;
             }
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 const u32x4 v = *(gptr4)(uintptr_t)(kin ? b_row[i] + off : zero_row);
-                if constexpr (SLOT == 0) buf0[NA + i] = v; else buf1[NA + i] = v;
+                buf[SLOT][NA + i] = v;
             }
             if (++kk_l == nk) { kk_l = 0; ++T_l; }
         };
@@ -1708,10 +1714,10 @@ k_gemm_p(const uint8_t* __restrict__ A, int64_t lda_b, const uint8_t* __restrict
             uint8_t* base = smem + st_w * TILE + lds_lane;
 #pragma unroll
             for (int i = 0; i < NA; ++i)
-                *reinterpret_cast<u32x4*>(base + (lw + 4 * i) * 1024) = SLOT == 0 ? buf0[i] : buf1[D > 1 ? i : 0];
+                *reinterpret_cast<u32x4*>(base + (lw + 4 * i) * 1024) = buf[SLOT][i];
 #pragma unroll
             for (int i = 0; i < NB; ++i)
-                *reinterpret_cast<u32x4*>(base + BM * KSTEP + (lw + 4 * i) * 1024) = SLOT == 0 ? buf0[NA + i] : buf1[D > 1 ? NA + i : 0];
+                *reinterpret_cast<u32x4*>(base + BM * KSTEP + (lw + 4 * i) * 1024) = buf[SLOT][NA + i];
             if (kk_w == 0) {                                         // the tile's epilogue constants ride along
                 float* ec = ec_all + (T_w % 3) * ECN;
 #pragma unroll
@@ -1727,11 +1733,17 @@ k_gemm_p(const uint8_t* __restrict__ A, int64_t lda_b, const uint8_t* __restrict
 
         // pipeline: loads run D steps ahead of the LDS writes, the writes S-1 steps ahead of the consumers.
         // Register slot of step x is x % D; the loops are written out per slot so every buffer index is static.
-        typedef std::integral_constant<int, 0> S0;
-        typedef std::integral_constant<int, D - 1> S1;
+        static_assert(D >= 1 && D <= 4, "register sets per loader wave");
         int nl = 0, nw = 0;
-        if (nl < G) { load_step(S0{}); ++nl; }
-        if (D > 1 && nl < G) { load_step(S1{}); ++nl; }
+#define EDADM_P_PRELOAD(K_)                                                                 \
+        if constexpr (D > K_) {                                                             \
+            if (nl < G) { load_step(std::integral_constant<int, (K_ < D ? K_ : 0)>{}); ++nl; }  \
+        }
+        EDADM_P_PRELOAD(0)
+        EDADM_P_PRELOAD(1)
+        EDADM_P_PRELOAD(2)
+        EDADM_P_PRELOAD(3)
+#undef EDADM_P_PRELOAD
 #ifdef EDADM_STAMPS
         unsigned long long l_wait = 0, l_bar = 0, l_issue = 0;
         const unsigned long long l_t0 = __builtin_amdgcn_s_memtime();
@@ -1753,13 +1765,11 @@ k_gemm_p(const uint8_t* __restrict__ A, int64_t lda_b, const uint8_t* __restrict
             { STAMP(ls3); l_bar += ls1 - ls0; l_wait += ls2 - ls1; l_issue += ls3 - ls2; }
 #endif
         };
-        if constexpr (D == 1) {
-            while (nw < G) turn(S0{});
-        } else {
-            while (nw < G) {
-                turn(S0{});
-                if (nw < G) turn(S1{});
-            }
+        while (nw < G) {
+            turn(std::integral_constant<int, 0>{});
+            if constexpr (D > 1) { if (nw < G) turn(std::integral_constant<int, (1 < D ? 1 : 0)>{}); }
+            if constexpr (D > 2) { if (nw < G) turn(std::integral_constant<int, (2 < D ? 2 : 0)>{}); }
+            if constexpr (D > 3) { if (nw < G) turn(std::integral_constant<int, (3 < D ? 3 : 0)>{}); }
         }
 #ifdef EDADM_STAMPS
         if (lw == 0) { STAMP_ADD(4, l_wait); STAMP_ADD(5, l_bar); STAMP_ADD(6, l_issue); STAMP_ADD(7, __builtin_amdgcn_s_memtime() - l_t0); }

@@ -1624,8 +1624,8 @@ def g20_f16x3_units(threads=None, fname="g20_f16x3_units", input_ulp=False, iter
         cq, cf = [torch.from_numpy(a) for a in cq], [torch.from_numpy(a) for a in cf]
         if input_ulp:
             # the conditioning probe: every cached input moved by (at most) one unit in the last place, nothing else changed
-            cq = [a * np.float32(1 + 2.0 ** -23) for a in cq]
-            cf = [a * np.float32(1 + 2.0 ** -23) for a in cf]
+            cq = [a * np.float32(1 + int(input_ulp) * 2.0 ** -23) for a in cq]
+            cf = [a * np.float32(1 + int(input_ulp) * 2.0 ** -23) for a in cf]
         # initial scales the reference's way (set_quantize_params.py:48-69 / :9-46 on the unit): weight quantizers from one
         # forward in the (True, False) state, activation quantizers over two batches of 32 of the quantised-prefix inputs
         uaqs = [(n, m) for n, m in unit.named_modules() if isinstance(m, UniformAffineQuantizer)]
@@ -1658,12 +1658,12 @@ def g20_f16x3_units(threads=None, fname="g20_f16x3_units", input_ulp=False, iter
                     if k + "/delta" not in base.files:           # a wrapper's own (unused, never initialised) quantizer
                         continue
                     for attr, key in (("delta", k + "/delta"), ("zero_point", k + "/zero_point")):
-                        cur = getattr(m, attr)
-                        new = torch.as_tensor(base[key]).reshape(cur.shape).to(cur.dtype)
-                        if isinstance(cur, torch.nn.Parameter):
-                            cur.copy_(new)
+                        have = getattr(m, attr)
+                        val = torch.as_tensor(base[key]).reshape(have.shape).to(have.dtype)
+                        if isinstance(have, torch.nn.Parameter):
+                            have.copy_(val)
                         else:
-                            setattr(m, attr, new)
+                            setattr(m, attr, val)
         print(name, "scales initialised %.0f s" % (time.time() - t0))
         for k, v in qparams_of(qnn).items():
             if k.startswith("qp/model.%s." % name):
@@ -1729,7 +1729,7 @@ def g20_f16x3_units(threads=None, fname="g20_f16x3_units", input_ulp=False, iter
         d["threads"] = np.int64(threads)
     if input_ulp:
         d = {k: v for k, v in d.items() if k.startswith("grad0/")}
-        d["input_scale"] = np.float32(1 + 2.0 ** -23)
+        d["input_scale"] = np.float32(1 + int(input_ulp) * 2.0 ** -23)
     save(fname, d)
 
 
@@ -1746,7 +1746,14 @@ def g20_ulp_floor():
     difference between two correct implementations.  The gradient is a function of pred - target through 8-bit fake-quantisers
     whose codes flip at .5 boundaries, so it is far less well conditioned than its inputs: the distance between the two REFERENCE
     gradients is the floor the product's gradient can be held to (tests/test_fullsize_gpu.py)."""
-    g20_f16x3_units(fname="g20_reference_ulp", input_ulp=True, iters=1)
+    g20_f16x3_units(fname="g20_reference_ulp", input_ulp=1, iters=1)
+
+
+def g20_ulp32_floor():
+    """the same probe with the inputs moved by 32 units in the last place (1 + 2^-18): the size of the difference between two correct
+    fp32 evaluations of a 400..1500-term dot product in different summation orders.  The response grows like the square root of the
+    perturbation (the number of flipped codes is proportional to it, their contributions add like noise)."""
+    g20_f16x3_units(fname="g20_reference_ulp32", input_ulp=32, iters=1)
 
 
 if __name__ == "__main__":
@@ -1755,7 +1762,7 @@ if __name__ == "__main__":
                 g6=g6_quant_module, g7=g7_blocks, g8=g8_g12_recon, g9=g9_tdac, g10=g10_steps,
                 g13c=g13_cifar_unet, g13i=lambda: g13_ldm_unet("imagenet"), g13h=lambda: g13_ldm_unet("church"), g14=g14_plms, g15=g15_decoder,
                 g17=g17_tdac_imagenet, g7b=g7b_blocks, g13w8=lambda: g13_cifar_unet(8, "g13_cifar_w8", 1301), g13sd=g13_ldm_sd, g16=g16_layer_recon,
-                g8b=g8b_recon_masks, g8c=g8c_recon_caches, g18=g18_church_driver, g19=g19_tdac_others, g1b=g1b_max_init, g20=g20_f16x3_units, g20n=g20_noise_floor, g20u=g20_ulp_floor)
+                g8b=g8b_recon_masks, g8c=g8c_recon_caches, g18=g18_church_driver, g19=g19_tdac_others, g1b=g1b_max_init, g20=g20_f16x3_units, g20n=g20_noise_floor, g20u=g20_ulp_floor, g20u32=g20_ulp32_floor)
     for k, fn in jobs.items():
         if not only or k in only:
             print("==", k)
