@@ -1545,7 +1545,11 @@ k_gemm_p(const uint8_t* __restrict__ A, int64_t lda_b, const uint8_t* __restrict
     constexpr int S = KSTEP == 64 ? 5 : 2;       // LDS ring slots (64-byte steps: 5 x 28 KiB = the whole K of a 384-wide layer)
     // K-steps a loader wave keeps in flight in registers.  tools/geglu_stamps.py (round 5): on the 384-deep GEGLU projection the
     // LOADER is the critical path -- 271 k of the launch's 481 k cycles in load issue, the MFMA waves wait 5.7 k cycles per tile --
-    // and it is bound by latency x bytes in flight (two 64-byte steps = 14 KB per wave), not by any bandwidth: EDADM_P_DEPTH steps
+    // whatever its epilogue (GEGLU 289 us, plain int8 codes 263, fp32 276 on the same operands).  More steps in flight per loader wave
+    // do not move it (EDADM_P_DEPTH 3: 236 vs 237 us on the real layer; 4: 260, the register sets spill), nor does a cheaper epilogue (a
+    // table-driven erf with 35 % fewer vector instructions per pair: epilogue 9.8 k -> 11.4 k cycles per tile on LDS bank conflicts, launch
+    // unchanged), nor 128-byte K-steps (EDADM_GEMM_FORCE=6: 284 vs 287 us cold): the intake per tile (168 KB for 256 x 192 outputs) is what
+    // a redesign has to cut -- the A block of an M tile resident in LDS across its 16 N tiles.
     constexpr int D = KSTEP == 64 ? EDADM_P_DEPTH : 1;
     constexpr int CPR = KSTEP / 16;              // 16-byte chunks per operand row
     constexpr int RPP = 64 / CPR;                // rows per 1-KiB direct-to-LDS piece
