@@ -462,6 +462,44 @@ extern "C" int edadm_lp_loss_bwd(const float* pred, const float* tgt, int64_t n,
     return edadm_launch_status();
 }
 
+// The fine-grained (per-module) loss terms of a block iteration as a gradient INJECTION (block_recon.py:186-189: add_loss x
+// lp_loss(module_q[j], module_r[j]) for every hooked module but the last).  Only the gradient of those terms is ever used; autograd
+// formed it as gather(target rows) -> k (p - t) -> zero-padded to the batched [x | x] tensor (fill + copy) -> added to the gradient
+// arriving from the next layer: four passes and 15 row-units of traffic per module.  Here it is ONE pass over the incoming gradient:
+//   gin[r] = gout[r] + (row0 <= r < row0 + nrows ? k (pred[r] - tgt[idx ? idx[r - row0] : r - row0]) : 0),   k = 2 inv_denom gscale[0]
+// -- the same two fp32 operations per element in the same order (this file is compiled without FMA contraction): the same bits.
+__global__ void __launch_bounds__(256) k_lp_inject(const float4* __restrict__ gout, const float4* __restrict__ pred,
+                                                   const float4* __restrict__ tgt, const int64_t* __restrict__ idx, int64_t rows_total,
+                                                   int64_t row0, int64_t nrows, int64_t re4, float inv_denom,
+                                                   const float* __restrict__ gscale, float4* __restrict__ gin) {
+    const float k = 2.0f * inv_denom * gscale[0];
+    const int64_t n4 = rows_total * re4, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const int64_t r = i / re4, lr = r - row0;
+        float4 g = gout[i];
+        if (lr >= 0 && lr < nrows) {
+            const int64_t tr = idx ? idx[lr] : lr;
+            const float4 a = pred[i], b = tgt[tr * re4 + (i - r * re4)];
+            const float vx = k * (a.x - b.x), vy = k * (a.y - b.y), vz = k * (a.z - b.z), vw = k * (a.w - b.w);
+            g.x += vx; g.y += vy; g.z += vz; g.w += vw;
+        }
+        gin[i] = g;
+    }
+}
+extern "C" int edadm_lp_loss_inject(const float* gout, const float* pred, const float* tgt, const int64_t* idx, int64_t rows_total,
+                                    int64_t row0, int64_t nrows, int64_t row_elems, float inv_denom, const float* gscale,
+                                    float* gin, void* stream) {
+    if (!gout || !pred || !tgt || !gscale || !gin || rows_total <= 0 || row0 < 0 || nrows <= 0 || row0 + nrows > rows_total ||
+        row_elems <= 0 || (row_elems & 3))
+        return EDADM_EINVAL;
+    if (((uintptr_t)gout | (uintptr_t)pred | (uintptr_t)tgt | (uintptr_t)gin) & 15) return EDADM_EINVAL;
+    const int64_t n4 = rows_total * (row_elems >> 2);
+    hipLaunchKernelGGL(k_lp_inject, dim3(edadm_grid(n4, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)gout,
+                       (const float4*)pred, (const float4*)tgt, idx, rows_total, row0, nrows, row_elems >> 2, inv_denom, gscale,
+                       (float4*)gin);
+    return edadm_launch_status();
+}
+
 // ------------------------------------------------------------------------------------------ K8
 __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float* __restrict__ g,
                                               float* __restrict__ m, float* __restrict__ v, int64_t n,

@@ -211,6 +211,17 @@ def lp_loss_bwd(pred, tgt, gscale, C=None):
     return g
 
 
+def lp_loss_inject(gout, pred, tgt_rows, idx, row0, nrows, inv_denom, gscale):
+    """gout, pred: [rows][...] contiguous in the same memory order; tgt_rows: [*][row elems] contiguous (gathered through idx [nrows],
+    int64, or taken row for row when idx is None) -> gout + the loss term's gradient on rows [row0, row0 + nrows)"""
+    rows = pred.shape[0]
+    re = pred.numel() // rows
+    gin = torch.empty_like(gout)
+    lib.call("edadm_lp_loss_inject", _pf(gout), _pf(pred), _pf(tgt_rows), None if idx is None else _p(idx, torch.int64), rows, int(row0),
+             int(nrows), re, float(inv_denom), _pf(gscale), _pf(gin), _stream())
+    return gin
+
+
 def adam_step(p, g, m, v, hyper):
     lib.call("edadm_adam_step", _pf(p), _pf(g), _pf(m), _pf(v), p.numel(), _pf(hyper), _stream())
 

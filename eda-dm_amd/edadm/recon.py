@@ -235,6 +235,51 @@ STATE = {"batched": False}           # whether the unit being reconstructed runs
 INJECT_MIX_UNIFORM = None
 
 
+# The fine-grained loss terms of a batched block iteration as gradient injections (csrc/elem.hip k_lp_inject): a hooked module's
+# output passes through an identity whose backward adds that module's loss gradient (rows [nb, 2 nb) of the batched [x | x] tensor
+# against the cached FP feature rows of the drawn samples) to the gradient arriving from the next layer -- one pass instead of
+# autograd's gather, loss backward, zero-padded slice gradient and accumulation add.  Same arithmetic per element, same bits; the
+# loss VALUE of these terms is never formed (nothing reads it).  Units that run the two quantised forwards separately keep the plain form.
+INJECT_MODULE_LOSS = True
+
+
+class _InjectLp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, spec):
+        ctx.spec = spec
+        ctx.save_for_backward(y)
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        sp = ctx.spec
+        ym, cl = ops.mem_view(y)
+        store, idx = sp["store"], sp["idx"]
+        if isinstance(store, RowsNHWC):
+            rows = store.t if cl else None
+        else:
+            rows = store if (not cl and store.is_contiguous()) else None
+        if rows is None:                                     # layouts differ (not the production path): gather, then bring to y's order
+            rows, idx = ops.mem_like(store[sp["idx"]], cl).contiguous(), None
+        nrows = sp["nrows"]
+        inv = 1.0 / (nrows * (ym.numel() // ym.shape[0]) / y.shape[1])
+        g = ops.lp_loss_inject(ops.mem_like(gy, cl), ym, rows, idx, sp["row0"], nrows, inv, sp["gscale"])
+        return ops.mem_restore(g, cl), None
+
+
+class _LossHook(AttentionMap):
+    """AttentionMap (utils.py:12-24) that can also route the module's output through _InjectLp (armed per iteration by reconstruct)"""
+    inject = None
+
+    def hook_fn(self, module, input, output):
+        if self.inject is not None:
+            self.out = self.feature = None
+            return _InjectLp.apply(output, self.inject)
+        self.out = output
+        self.feature = input
+
+
 class RowsNHWC:
     """Calibration rows of a feature map [N, C, H, W] kept in NHWC memory order (edadm/contract.py CHANNELS_LAST): a minibatch
     gather `rows[idx]` comes out as a channels_last tensor, the layout the unit's convolutions, GroupNorms and element-wise
@@ -321,7 +366,7 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
     for module in modules:
         if isinstance(module, QuantModule):
             if is_block:
-                hooks.append(AttentionMap(module))
+                hooks.append(_LossHook(module))
             if module.split == 0 or (control and not is_block):
                 module.weight_quantizer = AdaRoundQuantizer(uaq=module.weight_quantizer, round_mode=round_mode,
                                                             weight_tensor=module.org_weight.data)
@@ -411,8 +456,13 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
         DP_STATS["units"] += 1
         DP_STATS["iters"] += iters
 
+    # gradient injection of the per-module loss terms: batched units whose FP feature rows are cached
+    inject = bool(INJECT_MODULE_LOSS and batched and feats is not None and len(hooks) >= 2)
+    gscale = (torch.full((1,), float(add_loss), dtype=torch.float32, device=idx_buf.device) / (world if dp else 1)) if inject else None
+    unit.recon_inject = inject
+
     def body(apply=True):
-        idx_t = idx_buf[rank::world] if dp else idx_buf          # data parallel: rows r, r + N, ... of the drawn minibatch
+        idx_t = idx_buf[rank::world].contiguous() if dp else idx_buf     # data parallel: rows r, r + N, ... of the drawn minibatch
         cur_out = cached_outs[idx_t]
         if resblock:
             cur_inp, cur_sym = cached_inps[0][0][idx_t], cached_inps[1][0][idx_t]
@@ -434,13 +484,21 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
                 o.zero_grad()
         args_q = (cur_inp, temb_inp) if resblock else (cur_inp,)
         nb = cur_out.shape[0]
-        if batched:
+        if inject:
+            for h, f in zip(hooks[:-1], feats):
+                h.inject = {"store": f, "idx": idx_t, "row0": nb, "nrows": nb, "gscale": gscale}
+            try:
+                out_quant = unit(*(torch.cat([a, a]) for a in args_q))[:nb]
+            finally:
+                for h in hooks:
+                    h.inject = None
+        elif batched:
             out_quant = unit(*(torch.cat([a, a]) for a in args_q))[:nb]
             module_q = [h.out[nb:] for h in hooks]
         else:
             out_quant = unit(*args_q)
         m_loss = 0.0
-        if is_block and hooks:
+        if is_block and hooks and not inject:
             if feats is not None:
                 module_r = [f[idx_t] for f in feats] + [None]
             else:
@@ -490,65 +548,76 @@ def reconstruct(model, unit, cali_data, *, is_block, batch_size=32, iters=20000,
     for o in (w_opt, a_opt):
         if o:
             o.schedule(iters)
-    for it in range(iters):
-        if TIMING is not None and it == t_first:           # steady-state iterations only (bench.py): the first ones carry
-            torch.cuda.synchronize()                       # allocator warm-up, lazy initialisation and the graph capture
-            _t_steady = time.time()
-        idx_buf.copy_(idx_all[it], non_blocking=True)
-        for o in (w_opt, a_opt):
-            if o:
-                o.prepare_row()
-        if dp:
-            # forward / backward of this rank's rows (graph A once captured) -> all-gather of the partial slabs (eager: a collective)
-            # -> rank-ordered sum + Adam (graph B)
-            if graph is not None:
-                graph[0].replay()
-            elif use_graph and it >= GRAPH_WARMUP:
-                ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                from . import contract
-                f0 = contract.FLOPS[0]
-                with torch.cuda.graph(ga, capture_error_mode="thread_local"):
-                    ops.rng_epoch(1, add=True)
+    # The loop trains alphas and step sizes only (block_recon.py:44-117), but the FP model's biases (and any other parameter of the unit)
+    # still ask autograd for gradients nobody reads: a full-tensor reduction per biased layer and iteration (4 x 67 us in a transformer
+    # block at 32 x 32).  They are switched off for the duration of the loop; the trained parameters' gradients do not depend on them.
+    trained = {id(p) for p in w_para + a_para}
+    unread = [p for p in unit.parameters() if p.requires_grad and id(p) not in trained]
+    for p in unread:
+        p.requires_grad_(False)
+    try:
+        for it in range(iters):
+            if TIMING is not None and it == t_first:           # steady-state iterations only (bench.py): the first ones carry
+                torch.cuda.synchronize()                       # allocator warm-up, lazy initialisation and the graph capture
+                _t_steady = time.time()
+            idx_buf.copy_(idx_all[it], non_blocking=True)
+            for o in (w_opt, a_opt):
+                if o:
+                    o.prepare_row()
+            if dp:
+                # forward / backward of this rank's rows (graph A once captured) -> all-gather of the partial slabs (eager: a collective)
+                # -> rank-ordered sum + Adam (graph B)
+                if graph is not None:
+                    graph[0].replay()
+                elif use_graph and it >= GRAPH_WARMUP:
+                    ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                    from . import contract
+                    f0 = contract.FLOPS[0]
+                    with torch.cuda.graph(ga, capture_error_mode="thread_local"):
+                        ops.rng_epoch(1, add=True)
+                        body(apply=False)
+                    if TIMING is not None:
+                        TIMING["flops"] = TIMING.get("flops", 0.0) + (contract.FLOPS[0] - f0) * (iters - t_first)
+                    with torch.cuda.graph(gb, capture_error_mode="thread_local"):
+                        for o in (w_opt, a_opt):
+                            if o:
+                                o.dp_sum()
+                                o.apply()
+                    graph = (ga, gb)
+                    graph[0].replay()
+                else:
                     body(apply=False)
-                if TIMING is not None:
-                    TIMING["flops"] = TIMING.get("flops", 0.0) + (contract.FLOPS[0] - f0) * (iters - t_first)
-                with torch.cuda.graph(gb, capture_error_mode="thread_local"):
+                for o in (w_opt, a_opt):
+                    if o:
+                        o.dp_gather(rank, world)
+                if graph is not None:
+                    graph[1].replay()
+                else:
                     for o in (w_opt, a_opt):
                         if o:
                             o.dp_sum()
                             o.apply()
-                graph = (ga, gb)
-                graph[0].replay()
-            else:
-                body(apply=False)
-            for o in (w_opt, a_opt):
-                if o:
-                    o.dp_gather(rank, world)
+                continue
             if graph is not None:
-                graph[1].replay()
-            else:
-                for o in (w_opt, a_opt):
-                    if o:
-                        o.dp_sum()
-                        o.apply()
-            continue
-        if graph is not None:
-            graph.replay()
-            continue
-        if use_graph and it >= GRAPH_WARMUP:
-            graph = torch.cuda.CUDAGraph()
-            # thread_local: with several ranks the RCCL watchdog thread polls events while this thread captures; in the default
-            # (global) mode any such call from another thread invalidates the capture
-            from . import contract
-            f0 = contract.FLOPS[0]
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                ops.rng_epoch(1, add=True)
-                body()
-            if TIMING is not None:                         # executed fp32-equivalent flops of one iteration of this unit
-                TIMING["flops"] = TIMING.get("flops", 0.0) + (contract.FLOPS[0] - f0) * (iters - t_first)
-            graph.replay()                                 # capture does not execute: this runs iteration `it`
-            continue
-        body()
+                graph.replay()
+                continue
+            if use_graph and it >= GRAPH_WARMUP:
+                graph = torch.cuda.CUDAGraph()
+                # thread_local: with several ranks the RCCL watchdog thread polls events while this thread captures; in the default
+                # (global) mode any such call from another thread invalidates the capture
+                from . import contract
+                f0 = contract.FLOPS[0]
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    ops.rng_epoch(1, add=True)
+                    body()
+                if TIMING is not None:                         # executed fp32-equivalent flops of one iteration of this unit
+                    TIMING["flops"] = TIMING.get("flops", 0.0) + (contract.FLOPS[0] - f0) * (iters - t_first)
+                graph.replay()                                 # capture does not execute: this runs iteration `it`
+                continue
+            body()
+    finally:
+        for p in unread:
+            p.requires_grad_(True)
     del graph
     if TIMING is not None and iters > t_first:
         torch.cuda.synchronize()

@@ -87,6 +87,16 @@ int edadm_lp_loss_fwd(const float* pred, const float* tgt, int64_t n, float inv_
                       float* ws, void* stream);
 int edadm_lp_loss_bwd(const float* pred, const float* tgt, int64_t n, float inv_denom,
                       const float* gscale, float* gpred, void* stream);
+/* The per-module terms of the fine-grained loss (qdiff_control/block_recon.py:186-189, qdiff/block_recon.py:176-180: add_loss *
+ * lp_loss(module_q[j], module_r[j], p = 2)) as a gradient injection -- only their gradient is ever used.  ONE pass over the gradient
+ * arriving at a hooked module's output [rows_total][row_elems] (memory order):
+ *   gin[r] = gout[r] + (row0 <= r < row0 + nrows ? 2 inv_denom gscale[0] (pred[r] - tgt[idx ? idx[r - row0] : r - row0]) : 0)
+ * tgt: the FP feature rows (the cached per-sample maps, gathered through the minibatch indices idx[nrows], or the rows themselves
+ * when idx is null); row_elems % 4 == 0, 16-byte aligned pointers.  Replaces gather + edadm_lp_loss_bwd + autograd's zero-padded
+ * slice gradient + accumulation add with the same two fp32 operations per element in the same order (same bits). */
+int edadm_lp_loss_inject(const float* gout, const float* pred, const float* tgt, const int64_t* idx, int64_t rows_total,
+                         int64_t row0, int64_t nrows, int64_t row_elems, float inv_denom, const float* gscale, float* gin,
+                         void* stream);
 
 /* ---- K8: fused Adam step (torch.optim.Adam semantics as used at block_recon.py:112-117,199-206)
  * hyper = device float[4]: {lr/bias_corr1, sqrt(bias_corr2), beta1, beta2}; eps fixed 1e-8. */

@@ -191,6 +191,8 @@ def test_graph_replayed_iterations_equal_eager(golden):
     g = golden("g8_recon")
     x, t = torch.as_tensor(g["x"]).cuda(), torch.as_tensor(g["t"]).cuda()
 
+    took_inject = []
+
     def run(min_iters, prob, inp_prob):
         aq = dict(AQ8)
         aq["prob"] = prob
@@ -207,6 +209,7 @@ def test_graph_replayed_iterations_equal_eager(golden):
             ops.rng_epoch(0)
             layer_reconstruction(qnn, qnn.model.conv_in, **kw)
             block_reconstruction(qnn, qnn.model.rb, **kw)
+            took_inject.append(bool(getattr(qnn.model.rb, "recon_inject", False)))
             block_reconstruction(qnn, qnn.model.at, **kw)
         finally:
             recon.GRAPH_MIN_ITERS = old
@@ -227,3 +230,16 @@ def test_graph_replayed_iterations_equal_eager(golden):
     for k in a:
         assert torch.equal(a[k], b[k]), k
     assert any(not torch.equal(a[k], graphed[k]) for k in a)             # the masks do something
+    # the per-module loss terms as gradient injections (recon.INJECT_MODULE_LOSS, csrc/elem.hip k_lp_inject: one pass instead of
+    # gather + loss backward + zero-padded slice gradient + accumulation add) leave the bits of the plain autograd form, with and
+    # without masks, eager and replayed
+    assert recon.INJECT_MODULE_LOSS
+    recon.INJECT_MODULE_LOSS = False
+    try:
+        plain_eager, plain_masks = run(10 ** 9, 1.0, 1.0), run(4, 0.5, 0.5)
+    finally:
+        recon.INJECT_MODULE_LOSS = True
+    for k in eager:
+        assert torch.equal(eager[k], plain_eager[k]), (k, float((eager[k] - plain_eager[k]).abs().max()))
+        assert torch.equal(a[k], plain_masks[k]), (k, float((a[k] - plain_masks[k]).abs().max()))
+    assert took_inject[:4] == [True] * 4 and took_inject[4:] == [False, False], took_inject   # the residual block took the fused form

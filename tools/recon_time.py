@@ -16,6 +16,9 @@ if os.environ.get("WGRAD_SWAP"):
     contract.WGRAD_SWAP = os.environ["WGRAD_SWAP"] != "0"
 if os.environ.get("SIDE_WGRAD"):
     contract.SIDE_WGRAD = os.environ["SIDE_WGRAD"] != "0"
+if os.environ.get("INJECT"):
+    er.INJECT_MODULE_LOSS = os.environ["INJECT"] != "0"
+er.FP_FEAT_FORCE = True                     # short runs: the per-sample FP feature maps as the full-length job caches them
 if os.environ.get("MIN_NK"):
     contract.F16X3_MIN_NK = int(os.environ["MIN_NK"])
 g = torch.Generator().manual_seed(3)
