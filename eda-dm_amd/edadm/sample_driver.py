@@ -49,15 +49,34 @@ class ShardedSampler:
         return edist.shard_round_robin(self.n_batches, rank, world)
 
     def run(self, cond_fn, sink, limit=None):
+        """loop may be an edadm.sampling.InFlightSampler: its batches are sampled on alternating streams, n in flight, and a batch
+        is handed to `sink` (on the current stream, after waiting for the batch's stream) once n - 1 later ones are enqueued."""
         done = 0
+        flight = hasattr(self.loop, "submit")
+        pend = []
+
+        def deliver():
+            j, lat, st = pend.pop(0)
+            torch.cuda.current_stream().wait_stream(st)
+            lat.record_stream(torch.cuda.current_stream())
+            sink(j, lat)
+
         for i in self.my_batches():
             if limit is not None and done >= limit:
                 break
             x_T = batch_noise(self.seed, i, (self.batch,) + self.shape, self.device)
             labels = batch_labels(self.seed, i, self.batch, self.n_classes, self.device)
             cond, uncond = cond_fn(i, labels)
-            sink(i, self.loop.sample(x_T, cond, uncond))
+            if flight:
+                lat, st = self.loop.submit(x_T, cond, uncond)
+                pend.append((i, lat, st))
+                if len(pend) >= len(self.loop.loops):
+                    deliver()
+            else:
+                sink(i, self.loop.sample(x_T, cond, uncond))
             done += 1
+        while pend:
+            deliver()
         # kernels are asynchronous: a failure inside one (a persistent-GEMM hand-off that timed out) surfaces here, where the
         # run synchronises anyway, as an exception instead of silently wrong images
         if torch.device(self.device).type == "cuda":

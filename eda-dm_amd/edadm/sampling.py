@@ -14,12 +14,17 @@ class GraphedUNet:
     are a function of the context alone (Engine.context_branches): they get their own graph, replayed when the
     context changes -- once per sample batch -- and the per-step graph only adds their vectors."""
 
-    def __init__(self, engine, x, t, ctx, warmup=2, timesteps=None, cfg_pair=False):
+    def __init__(self, engine, x, t, ctx, warmup=2, timesteps=None, cfg_pair=False, capture_stream=None):
         """timesteps: the schedule of the run (one int per step, in call order).  With it the time-embedding path of all
         steps is one graph replayed by begin() at the start of a run (Engine.emb_tables), and a step -- called with
         its index -- copies its row of that table instead of recomputing 2 + 2 x 22 tiny launches."""
         # cfg_pair: the caller always passes x = [img, img] (a classifier-free-guidance pair): the context-independent
         # prefix of the network runs once for both halves (Engine.cfg_pair)
+        # capture_stream: the stream the three graphs are captured on.  The library's reduction workspaces are per (device,
+        # stream) and a captured graph keeps its capture stream's: two GraphedUNets that are REPLAYED concurrently (two sample
+        # batches in flight, InFlightSampler below) must therefore be captured on different streams (torch's default is one shared
+        # capture stream for every graph of the process)
+        gkw = {} if capture_stream is None else {"stream": capture_stream}
         self.engine = engine
         self.x, self.t = x.clone(), t.clone()
         self.ctx = None if ctx is None else ctx.clone()
@@ -45,20 +50,20 @@ class GraphedUNet:
         self.ctx_graph, self.ctx_r = None, None
         if getattr(engine, "ctx_r", None) is not None:
             self.ctx_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.ctx_graph):
+            with torch.cuda.graph(self.ctx_graph, **gkw):
                 self.ctx_r = engine.context_branches(self.ctx)
         engine.ctx_r = self.ctx_r
         emb_r = None
         if ts_all is not None and tabs is not None:
             self.emb_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.emb_graph):
+            with torch.cuda.graph(self.emb_graph, **gkw):
                 self.emb_tab, layout = engine.emb_tables(ts_all, len(timesteps))
             self.emb_stage = torch.empty_like(self.emb_tab[0])
             emb_r = {k: self.emb_stage[off:off + rows * n].view(rows, n) for k, (off, n) in layout.items()}
         engine.emb_r = emb_r
         self.graph = torch.cuda.CUDAGraph()
         try:
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, **gkw):
                 self.out = engine(self.x, self.t, self.ctx)
         finally:
             engine.ctx_r = None                       # eager calls of the engine keep evaluating both per call
@@ -94,7 +99,7 @@ class DDIMLoop:
     """S-step DDIM with classifier-free guidance on a frozen QuantModel."""
 
     def __init__(self, engine, shape, batch, steps=20, eta=0.0, scale=3.0, linear_start=0.0015, linear_end=0.0195,
-                 n_timesteps=1000, context_shape=None, use_graph=True, device="cuda"):
+                 n_timesteps=1000, context_shape=None, use_graph=True, device="cuda", capture_stream=None):
         self.engine, self.shape, self.batch, self.scale, self.eta = engine, tuple(shape), batch, scale, eta
         betas = make_beta_schedule("linear", n_timesteps, linear_start, linear_end)
         ac = np.cumprod(1.0 - betas, axis=0)
@@ -108,7 +113,7 @@ class DDIMLoop:
             x0 = torch.zeros((rows,) + self.shape, device=device)
             t0 = torch.zeros(rows, dtype=torch.long, device=device)
             c0 = None if context_shape is None else torch.zeros((rows,) + tuple(context_shape), device=device)
-            self.unet = GraphedUNet(engine, x0, t0, c0, timesteps=self._schedule(), cfg_pair=self.cfg)
+            self.unet = GraphedUNet(engine, x0, t0, c0, timesteps=self._schedule(), cfg_pair=self.cfg, capture_stream=capture_stream)
 
     def _schedule(self):
         """timesteps in call order, or None when the loop does not walk a fixed list (PLMS: extra evaluations)"""
@@ -137,6 +142,33 @@ class DDIMLoop:
             else:
                 img = ops.ddim_step(img.contiguous(), e, None, 1.0, coef)
         return img
+
+
+class InFlightSampler:
+    """Several independent sample batches IN FLIGHT on one GPU: n loops over the same frozen engine (each with its own captured
+    graphs and static buffers, captured on its own stream), batch i sampled on stream i mod n.  A UNet call is ~500 dependent
+    launches, a third of them at the 16 x 16 / 8 x 8 levels where a launch does not fill 256 CUs, and every dependent hand-off leaves
+    the chip idle for a few microseconds: a second batch's launches fill those holes.  The batches are independent (the loop of
+    sample_diffusion_ldm_imagenet.py:215-249 has no carried state), so each batch's bits are those of the serial loop."""
+
+    def __init__(self, make_loop, n=2, device="cuda"):
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(n)]
+        self.loops = [make_loop(torch.cuda.Stream(device=device)) for _ in range(n)]       # argument: the capture stream
+        self.k = 0
+
+    def submit(self, x_T, cond=None, uncond=None):
+        """Enqueue one batch on the next stream; returns (latents, stream) -- the latents are ready when the stream reaches here."""
+        i = self.k % len(self.loops)
+        self.k += 1
+        st = self.streams[i]
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            lat = self.loops[i].sample(x_T, cond, uncond)
+        return lat, st
+
+    def drain(self):
+        for st in self.streams:
+            torch.cuda.current_stream().wait_stream(st)
 
 
 class PLMSLoop(DDIMLoop):

