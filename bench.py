@@ -409,9 +409,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--inflight", type=int, default=3,
                     help="independent 50-image sample batches in flight per GPU (edadm.sampling.InFlightSampler: batch k on stream k mod n; "
-                         "measured 1 / 2 / 3: 94.9 / 107.4 / 109.0 decoded, 116.7 / 136.1 / 133.0 sampling-only images/s)")
+                         "measured 1 / 2 / 3 / 4 in flight: 94.9 / 105.2-107.4 / 108.0-109.0 / 107.4 decoded, 116.7 / 136.2 / 133.0-136.9 / 135.5 "
+                         "sampling-only images/s)")
     ap.add_argument("--calib", choices=["full", "bounded", "none"], default=None,
                     help="full (default at N = 1): the whole calibration job at the shipped size, measured (~8 min); with N > 1 every rank runs "
                          "it (TDAC and activation caching sharded) and the line carries the max-over-ranks wall-clock -- not the default there, "
@@ -684,7 +685,8 @@ def main():
                 t0c = time.time()
                 try:
                     with torch.no_grad():
-                        r = fn(dev, SimpleNamespace(batch=0, steps=0, calls=0, batches=1))
+                        r = fn(dev, SimpleNamespace(batch=0, steps=0, calls=0, batches=1, inflight=args.inflight))
+                    r["batches_in_flight"] = 1 if kind == "cifar" else args.inflight
                     gg = r.get("gemm_group", {})
                     r["roofline"] = {"bound": "mfma", "achieved": r["algorithmic_tflops"], "peak": I8_PEAK_TFLOPS, "unit": "TFLOP/s",
                                      "frac": r["algorithmic_tflops"] / I8_PEAK_TFLOPS,

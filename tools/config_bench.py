@@ -191,6 +191,30 @@ def quick_call_numbers(kind, dev):
             "frac_of_int8_mfma_peak": grp["frac_of_int8_mfma_peak"]}
 
 
+def _timed_batches(mk, nfl, noise, nb, dev, cond=None, uncond=None):
+    """seconds per batch over nb timed batches after nfl warm-up ones: serial (nfl = 1) or nfl batches in flight
+    (edadm.sampling.InFlightSampler, as bench.py samples the headline configuration)"""
+    if nfl > 1:
+        from edadm.sampling import InFlightSampler
+        fl = InFlightSampler(mk, n=nfl, device=dev)
+        run = lambda x: fl.submit(x, cond, uncond)[0]
+        fin = fl.drain
+    else:
+        loop = mk()
+        run = lambda x: loop.sample(x, cond, uncond)
+        fin = lambda: None
+    for i in range(nfl):
+        run(noise[i])
+    fin()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for i in range(nb):
+        out = run(noise[nfl + i])
+    fin()
+    torch.cuda.synchronize()
+    return (time.time() - t0) / nb, out
+
+
 def run_cifar(dev, a):
     from edadm.nets.ddpm_unet import Model
     from edadm.sampling import GraphedUNet
@@ -257,15 +281,12 @@ def run_church(dev, a):
             eng(xg, tg, None)
         torch.cuda.synchronize()
         return {"config": "church", "calls": a.calls}
-    loop = DDIMLoop(eng, (4, 32, 32), B, steps=S, eta=0.0, scale=1.0, linear_start=0.0015, linear_end=0.0155, context_shape=None, device=dev)
-    noise = [torch.randn(B, 4, 32, 32, generator=torch.Generator(device=dev).manual_seed(i), device=dev) for i in range(a.batches + 1)]
-    loop.sample(noise[0])
-    torch.cuda.synchronize()
-    t0 = time.time()
-    for i in range(a.batches):
-        out = loop.sample(noise[1 + i])
-    torch.cuda.synchronize()
-    dt = (time.time() - t0) / a.batches
+    nfl = int(getattr(a, "inflight", 1))
+    mk = lambda cs=None: DDIMLoop(eng, (4, 32, 32), B, steps=S, eta=0.0, scale=1.0, linear_start=0.0015, linear_end=0.0155, context_shape=None,
+                                  device=dev, capture_stream=cs)
+    nb = a.batches * nfl
+    noise = [torch.randn(B, 4, 32, 32, generator=torch.Generator(device=dev).manual_seed(i), device=dev) for i in range(nb + nfl)]
+    dt, out = _timed_batches(mk, nfl, noise, nb, dev)
     assert bool(torch.isfinite(out).all())
     xg, tg = torch.randn(B, 4, 32, 32, device=dev), torch.full((B,), 501, dtype=torch.long, device=dev)
     grp = _gemm_group(eng, lambda: eng(xg, tg, None))
@@ -295,18 +316,14 @@ def run_sd(dev, a):
             eng(xg, tg, cg)
         torch.cuda.synchronize()
         return {"config": "sd", "calls": a.calls}
-    loop = PLMSLoop(eng, (4, 64, 64), B, steps=S, scale=7.5, context_shape=(77, 768), device=dev)
+    nfl = int(getattr(a, "inflight", 1))
+    mk = lambda cs=None: PLMSLoop(eng, (4, 64, 64), B, steps=S, scale=7.5, context_shape=(77, 768), device=dev, capture_stream=cs)
     gen = torch.Generator(device=dev).manual_seed(9)
     cond = torch.randn(B, 77, 768, generator=gen, device=dev)
     uncond = torch.randn(1, 77, 768, generator=gen, device=dev).expand(B, 77, 768).contiguous()
-    noise = [torch.randn(B, 4, 64, 64, generator=gen, device=dev) for _ in range(a.batches + 1)]
-    loop.sample(noise[0], cond, uncond)
-    torch.cuda.synchronize()
-    t0 = time.time()
-    for i in range(a.batches):
-        out = loop.sample(noise[1 + i], cond, uncond)
-    torch.cuda.synchronize()
-    dt = (time.time() - t0) / a.batches
+    nb = a.batches * nfl
+    noise = [torch.randn(B, 4, 64, 64, generator=gen, device=dev) for _ in range(nb + nfl)]
+    dt, out = _timed_batches(mk, nfl, noise, nb, dev, cond, uncond)
     assert bool(torch.isfinite(out).all())
     xg = torch.randn(2 * B, 4, 64, 64, device=dev)
     tg = torch.full((2 * B,), 501, dtype=torch.long, device=dev)
@@ -324,6 +341,7 @@ def main():
     ap.add_argument("--batches", type=int, default=2)
     ap.add_argument("--steps", type=int, default=0, help="sampling steps to run (0: cifar 100, church 20 of 500, sd 50)")
     ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--inflight", type=int, default=2, help="sample batches in flight (church, sd)")
     ap.add_argument("--calls", type=int, default=0, help="profiling mode (rocprofv3 + tools/prof_diff.py): set up, then only N eager UNet calls")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
