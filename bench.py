@@ -670,7 +670,7 @@ def main():
         cfgs = {}
         try:
             import config_bench as cb
-            loop = eng = dec = prof = i8 = None                # the headline's engine, graphs and decoder leave HBM first
+            loop = eng = dec = prof = i8 = flight = None                # the headline's engine, graphs and decoder leave HBM first
             qnn.engine = None
             import gc
             gc.collect()
@@ -728,7 +728,7 @@ def main():
                 calib_out["reconstruction_bounded"] = time_calibration(qnn, dev)
             else:
                 # the sampling model, its engine, graphs and the decoder leave HBM first: the job needs ~175 GB
-                loop = eng = dec = prof = i8 = None
+                loop = eng = dec = prof = i8 = flight = None
                 qnn.engine = None
                 qnn = None
                 import gc
