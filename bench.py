@@ -206,6 +206,7 @@ def instrumented_walk(qnn, cali, kwargs, n_calib):
                              "peak_f16_three_product": 2516.0 / 3, "frac": tf / (2516.0 / 3),
                              "peak_fp32_mfma": 157.0, "frac_of_fp32_mfma": tf / 157.0},
                 fp_features={"s": feat, "units_cached": timing.get("feat_units", 0), "budget_gb_at_1024_samples": feat_gb},
+                hbm_budget_scale=du.STATS.get("hbm_scale"),     # < 1: the cache budgets were clamped to the free HBM (min over ranks)
                 fp_trace={"budget_gb_at_1024_samples": full_gb, "fp_prefix_sweeps": du.STATS["fp_captures"],
                           "units_served": du.STATS["units_served"], "memo_budget_gb_at_1024_samples": memo_gb,
                           "memo_hits": du.STATS["memo_hits"]},

@@ -190,3 +190,57 @@ extern "C" int edadm_vq_nearest(const float* z, const float* codebook, float* ou
 #undef VQ_CASE
     return EDADM_EINVAL;
 }
+
+// ---- TDAC step scores (scripts/calibration.py:47-69 of the reference): for every pair (i, j) of the T feature maps F[t] = [B][C][P]
+// (the mid-block attention input of sampling step t, P = H W positions) the mean squared difference -- the density test
+// `mean((F_i - F_j)^2) <= r` -- and the variety term sum over (b, p) of 1 - cos(F_i[b, :, p], F_j[b, :, p]), the cosine along the
+// channel axis with each norm clamped at eps (torch.nn.functional.cosine_similarity).  The reference runs T (T - 1) = 380 pairs x
+// five torch passes; here one workgroup per unordered pair reads the two maps once: a thread owns positions (b, p) and walks the
+// channels (coalesced over p), the per-thread partials are reduced in a FIXED order (wave butterfly, then waves 0..3): deterministic.
+// Both outputs are [T][T] (symmetric, zero diagonal); the host counts / adds them in the reference's order of j.
+__global__ void __launch_bounds__(256) k_tdac_pairs(const float* __restrict__ F, int T, int64_t B, int64_t C, int64_t P, float eps,
+                                                    float* __restrict__ mse, float* __restrict__ cosd) {
+    // unordered pair index -> (i, j), i < j
+    int i = 0, rem = (int)blockIdx.x;
+    while (rem >= T - 1 - i) { rem -= T - 1 - i; ++i; }
+    const int j = i + 1 + rem;
+    const int64_t per = B * C * P;
+    const float* a = F + (int64_t)i * per;
+    const float* b = F + (int64_t)j * per;
+    double sq = 0.0, cd = 0.0;
+    for (int64_t q = threadIdx.x; q < B * P; q += 256) {
+        const int64_t bb = q / P, p = q - bb * P;
+        const float* pa = a + bb * C * P + p;
+        const float* pb = b + bb * C * P + p;
+        float dot = 0.f, na = 0.f, nb = 0.f, s2 = 0.f;
+        for (int64_t c = 0; c < C; ++c) {
+            const float x = pa[c * P], y = pb[c * P];
+            dot = fmaf(x, y, dot);
+            na = fmaf(x, x, na);
+            nb = fmaf(y, y, nb);
+            const float d = x - y;
+            s2 = fmaf(d, d, s2);
+        }
+        sq += (double)s2;
+        cd += (double)(1.0f - dot / (fmaxf(sqrtf(na), eps) * fmaxf(sqrtf(nb), eps)));
+    }
+    __shared__ double sm[2][4];
+    sq = wave_sum_d(sq);
+    cd = wave_sum_d(cd);
+    if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = sq; sm[1][threadIdx.x >> 6] = cd; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double s = ((sm[0][0] + sm[0][1]) + sm[0][2]) + sm[0][3], c2 = ((sm[1][0] + sm[1][1]) + sm[1][2]) + sm[1][3];
+        const float m = (float)(s / (double)per), cv = (float)c2;
+        mse[(int64_t)i * T + j] = mse[(int64_t)j * T + i] = m;
+        cosd[(int64_t)i * T + j] = cosd[(int64_t)j * T + i] = cv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < T) mse[(int64_t)threadIdx.x * T + threadIdx.x] = cosd[(int64_t)threadIdx.x * T + threadIdx.x] = 0.f;
+}
+extern "C" int edadm_tdac_pair_scores(const float* feats, int64_t T, int64_t B, int64_t C, int64_t P, float eps, float* mse,
+                                      float* cosdis, void* stream) {
+    if (!feats || !mse || !cosdis || T < 2 || T > 256 || B <= 0 || C <= 0 || P <= 0) return EDADM_EINVAL;
+    const unsigned pairs = (unsigned)(T * (T - 1) / 2);
+    hipLaunchKernelGGL(k_tdac_pairs, dim3(pairs), dim3(256), 0, (hipStream_t)stream, feats, (int)T, B, C, P, eps, mse, cosdis);
+    return edadm_launch_status();
+}

@@ -222,6 +222,17 @@ def lp_loss_inject(gout, pred, tgt_rows, idx, row0, nrows, inv_denom, gscale):
     return gin
 
 
+def tdac_pair_scores(feature_map, eps=1e-6):
+    """feature_map: list of T device tensors [B, C, ...] -> (mse [T][T], cosine distance sums [T][T]) (edadm_tdac_pair_scores)"""
+    f = torch.stack([t.detach().float().contiguous() for t in feature_map]).contiguous()
+    T, B, C = f.shape[0], f.shape[1], f.shape[2]
+    P = f[0, 0, 0].numel()
+    mse = torch.empty(T, T, dtype=torch.float32, device=f.device)
+    cd = torch.empty(T, T, dtype=torch.float32, device=f.device)
+    lib.call("edadm_tdac_pair_scores", _pf(f), T, B, C, P, float(eps), _pf(mse), _pf(cd), _stream())
+    return mse, cd
+
+
 def adam_step(p, g, m, v, hyper):
     lib.call("edadm_adam_step", _pf(p), _pf(g), _pf(m), _pf(v), p.numel(), _pf(hyper), _stream())
 

@@ -3,7 +3,9 @@ every sampling step by the density (`#{j : mean((F_i-F_j)^2) <= r}`, :45-52) and
 (`sum_j sum(1 - cos(F_i, F_j))`, :58-63) of the mid-block features, turn `w = D^ + lambda V^` into an
 integer number of calibration samples per step summing to N (:66-92), and assemble the calibration set.
 
-SURVEY.md §8f-1 ("next" tier): the O(T^2) scoring uses device tensor ops; no dedicated HIP kernel yet."""
+SURVEY.md §8f-1: on the device the O(T^2) scoring is ONE launch (edadm_tdac_pair_scores, csrc/small.hip: a workgroup per pair reads
+the two maps once -- the reference's loop is 380 pairs x five torch passes); host tensors (the host-logic test of the allocation
+rule, G9) take the reference's own torch statements."""
 import torch
 import torch.nn.functional as F
 
@@ -12,6 +14,17 @@ def tdac_scores(feature_map, dense_r):
     T = len(feature_map)
     dense_num = torch.zeros(T, dtype=torch.int16)
     cos_dis = torch.zeros(T)
+    if feature_map[0].is_cuda and T >= 2:
+        from . import ops
+        mse, cd = ops.tdac_pair_scores(feature_map)
+        mse, cd = mse.cpu(), cd.cpu()
+        for i in range(T):
+            for j in range(T):                       # the reference's order of j: a count, and a sequential fp32 sum
+                if i != j:
+                    if mse[i, j] <= dense_r:
+                        dense_num[i] = dense_num[i] + 1
+                    cos_dis[i] = cos_dis[i] + cd[i, j]
+        return dense_num, cos_dis
     for i in range(T):
         for j in range(T):
             if i != j:

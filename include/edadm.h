@@ -492,6 +492,14 @@ int edadm_softmax_bwd(const float* dp, const float* p, float* dx, int64_t rows, 
 int edadm_softmax_fwd_any(const float* s, float* out, int64_t rows, int64_t cols, void* stream);
 int edadm_transpose_batched_f32(const float* x, float* out, int64_t Z, int64_t R, int64_t C, void* stream);
 
+/* ---- TDAC step scores (scripts/calibration.py:47-69: the O(T^2) density / variety loop over the mid-block features) -------------
+ * feats [T][B][C][P] fp32 (feature map of sampling step t, NCHW with P = H W).  For every pair: mse[i][j] = mean((F_i - F_j)^2)
+ * (the reference tests it against the density radius, :49-52) and cosdis[i][j] = sum over (b, p) of 1 - cos(F_i[b, :, p], F_j[b, :, p])
+ * with each norm clamped at eps (nn.CosineSimilarity(dim=1, eps=1e-6), :57-63).  Both [T][T], symmetric, zero diagonal; one launch,
+ * deterministic.  The host then counts / adds over j in the reference's order (edadm/tdac.py). */
+int edadm_tdac_pair_scores(const float* feats, int64_t T, int64_t B, int64_t C, int64_t P, float eps, float* mse, float* cosdis,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif
