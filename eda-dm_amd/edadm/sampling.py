@@ -162,6 +162,11 @@ class InFlightSampler:
         self.k += 1
         st = self.streams[i]
         st.wait_stream(torch.cuda.current_stream())
+        for t in (x_T, cond, uncond):
+            # the caller may drop its inputs as soon as this returns: tell the allocator they are in use on the batch's stream (else the
+            # block goes back to the caller's stream and can be handed out again while the sampling kernels still read it)
+            if t is not None and t.is_cuda:
+                t.record_stream(st)
         with torch.cuda.stream(st):
             lat = self.loops[i].sample(x_T, cond, uncond)
         return lat, st
