@@ -645,6 +645,12 @@ def main():
                                  "achieved_GBps": (traffic * len(i8) / (gemm_ms * 1e-3) / 1e9) if traffic else None,
                                  "peak_GBps": 8000.0,
                                  "frac": (traffic * len(i8) / (gemm_ms * 1e-3) / 8e12) if traffic else None},
+                         "in_flight": {"batches": args.inflight,
+                                       "note": "`frac` above prices every launch alone; in the timed loop %d batches share the chip, and the int8 GEMM "
+                                               "flops the sampling-only loop sustains over ITS wall time (all kernels of a call included) are" % args.inflight,
+                                       "unet_calls_per_s": ips_unet / world / B * 20,
+                                       "sustained_int8_gemm_tflops": ips_unet / world / B * 20 * gemm_flop / 1e12,
+                                       "frac": ips_unet / world / B * 20 * gemm_flop / 1e12 / I8_PEAK_TFLOPS},
                          "unet_call_ms": unet_ms,
                          "unet_algorithmic_tflops": 2 * B * UNET_GFLOP_PER_ROW / unet_ms},
             "calibration": {"quick_scale_init_of_the_sampling_model": calib},
