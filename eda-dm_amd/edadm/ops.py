@@ -72,12 +72,31 @@ def init_device(device):
         _inited_devices.add(idx)
 
 
+_ws_scope = [None]
+
+
+class workspace_scope:
+    """Launches issued inside the scope take workspaces of their own (key extended by `tag`): a HIP graph captured inside keeps
+    buffers no other graph or eager launch shares, whatever streams they were captured / are replayed on (torch hands out streams
+    from a pool of 32 per device round-robin, so two streams created far apart can be the same one).  edadm.sampling.GraphedUNet
+    captures inside a scope of its own: several of them can be replayed concurrently (InFlightSampler)."""
+
+    def __init__(self, tag):
+        self.tag = tag
+
+    def __enter__(self):
+        self.prev, _ws_scope[0] = _ws_scope[0], self.tag
+
+    def __exit__(self, *a):
+        _ws_scope[0] = self.prev
+
+
 def workspace(device, floats=None):
     init_device(device)
     n = int(lib.load().edadm_reduce_ws_floats()) if floats is None else int(floats)
-    # one buffer per (device, stream): launches on different streams may run concurrently (a decoder on a side stream next to
-    # the sampling graph), and a graph captured on its capture stream keeps the buffer of that stream to itself
-    key = (device.index, "r" if floats is None else "x", torch.cuda.current_stream(device).cuda_stream)
+    # one buffer per (device, stream[, scope]): launches on different streams may run concurrently (a decoder on a side stream next
+    # to the sampling graph), and a graph captured on its capture stream keeps the buffer of that stream to itself
+    key = (device.index, "r" if floats is None else "x", torch.cuda.current_stream(device).cuda_stream, _ws_scope[0])
     w = _ws.get(key)
     if w is None or w.numel() < n:
         if w is not None:

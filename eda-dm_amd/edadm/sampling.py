@@ -20,10 +20,10 @@ class GraphedUNet:
         its index -- copies its row of that table instead of recomputing 2 + 2 x 22 tiny launches."""
         # cfg_pair: the caller always passes x = [img, img] (a classifier-free-guidance pair): the context-independent
         # prefix of the network runs once for both halves (Engine.cfg_pair)
-        # capture_stream: the stream the three graphs are captured on.  The library's reduction workspaces are per (device,
-        # stream) and a captured graph keeps its capture stream's: two GraphedUNets that are REPLAYED concurrently (two sample
-        # batches in flight, InFlightSampler below) must therefore be captured on different streams (torch's default is one shared
-        # capture stream for every graph of the process)
+        # capture_stream: the stream the three graphs are captured on (torch's default is one shared capture stream for every graph
+        # of the process).  The library's reduction workspaces are per (device, stream, scope), and the captures below run inside a
+        # workspace scope of this object: the graphs of two GraphedUNets never share a workspace, so they can be REPLAYED
+        # concurrently (several sample batches in flight, InFlightSampler below) whatever streams were involved
         gkw = {} if capture_stream is None else {"stream": capture_stream}
         self.engine = engine
         self.x, self.t = x.clone(), t.clone()
@@ -50,20 +50,20 @@ class GraphedUNet:
         self.ctx_graph, self.ctx_r = None, None
         if getattr(engine, "ctx_r", None) is not None:
             self.ctx_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.ctx_graph, **gkw):
+            with torch.cuda.graph(self.ctx_graph, **gkw), ops.workspace_scope(id(self)):
                 self.ctx_r = engine.context_branches(self.ctx)
         engine.ctx_r = self.ctx_r
         emb_r = None
         if ts_all is not None and tabs is not None:
             self.emb_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.emb_graph, **gkw):
+            with torch.cuda.graph(self.emb_graph, **gkw), ops.workspace_scope(id(self)):
                 self.emb_tab, layout = engine.emb_tables(ts_all, len(timesteps))
             self.emb_stage = torch.empty_like(self.emb_tab[0])
             emb_r = {k: self.emb_stage[off:off + rows * n].view(rows, n) for k, (off, n) in layout.items()}
         engine.emb_r = emb_r
         self.graph = torch.cuda.CUDAGraph()
         try:
-            with torch.cuda.graph(self.graph, **gkw):
+            with torch.cuda.graph(self.graph, **gkw), ops.workspace_scope(id(self)):
                 self.out = engine(self.x, self.t, self.ctx)
         finally:
             engine.ctx_r = None                       # eager calls of the engine keep evaluating both per call
