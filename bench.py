@@ -403,6 +403,14 @@ def calibration_cpu_baseline():
                      "`per_unit_ms`) after 32 batches of scale initialisation and 2 x 32 cached forward batches per unit")
 
 
+def emit(line):
+    """Rank 0's ONE stdout line: the compact form (bench_line.py, <= 6 KB); the detailed dict goes to bench_detail.json."""
+    import bench_line
+    bench_line.write_detail(line, ROOT)
+    sys.stdout.write(bench_line.dumps(line) + "\n")
+    sys.stdout.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -486,7 +494,7 @@ def main():
     cond = torch.randn(B, 1, 512, generator=gen, device=dev)
     uncond = torch.randn(1, 1, 512, generator=gen, device=dev).expand(B, 1, 512).contiguous()
 
-    def timed(decoder):
+    def timed(decoder, flight=flight):
         """W untimed + exactly K timed steps between barrier + synchronize on both sides; max over ranks"""
         run_steps(loop, decoder, side, noise, cond, uncond, 0, args.warmup, dev, flight)
         if args.warmup == 0 and decoder is not None:
@@ -509,6 +517,9 @@ def main():
 
     elapsed = timed(dec)                      # the headline: sampled AND decoded
     elapsed_unet = timed(None)                # the quantised UNet sampling alone
+    # the same K steps with ONE batch in flight (the serial loop of the reference's script): what the kernels alone deliver
+    elapsed_one = timed(dec, flight=None) if flight is not None else elapsed
+    elapsed_unet_one = timed(None, flight=None) if flight is not None else elapsed_unet
     ops.device_status()                       # a deferred in-kernel failure (persistent-GEMM hand-off timeout) raises here
 
     # roofline pass: HIP events around every int8 MFMA GEMM launch of one eager UNet call as the sampling loop issues it
@@ -606,14 +617,17 @@ def main():
         achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12
         ips, ips_unet = images / elapsed, images / elapsed_unet
         line = {
-            "metric": "images/sec W4A8 LDM-4 ImageNet 256x256: 20 DDIM steps x CFG 3.0 on the int8 executor AND VQ-f4 decode to pixels "
-                      "(what the reference's loop delivers per batch); full calibration wall-clock under `calibration`",
+            "metric": "images/sec W4A8 LDM-4 ImageNet 256x256 (sampled + VQ-f4 decoded); calibration wall-clock in `calibration`",
+            "metric_definition": "20 DDIM steps x CFG 3.0 on the int8 executor AND VQ-f4 decode to pixels (what the reference's loop "
+                                 "delivers per batch); full calibration wall-clock under `calibration`",
             "value": ips, "unit": "images/sec", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "int8 (i8 MFMA, i32 accumulate; fp32 epilogues); decoder fp32-grade (f16 x3 MFMA)",
+            "scaling": "weak", "vs_baseline": None, "dtype": "int8",
+            "dtype_note": "i8 MFMA, i32 accumulate, fp32 epilogues; first-stage decoder fp32-grade (f16 x3 MFMA)",
             "data": "synthetic",
-            "config": {"workload": "ImageNet LDM-4 256x256 W4A8: 50-image batches x 20 DDIM steps x CFG (100 UNet rows/call), "
-                                   "400.9M-param cin256-v2 UNet, random-init weights, latents+context resident in HBM, each batch decoded by "
+            "config": {"workload": "configs[3]: ImageNet LDM-4 256x256 W4A8, 50-image batches x 20 DDIM steps x CFG 3.0 (100 UNet rows/call), "
+                                   "400.9M-param UNet + VQ-f4 decode, random-init weights, inputs resident in HBM",
+                       "workload_note": "each batch decoded by "
                                    "the VQ-f4 first stage (55.3M params, fp32) -- issued on a second stream, but NOT hidden: both want the same CUs and "
                                    "the decode is ~20 %% of a step (`first_stage_decode`); %d independent batches are in flight on %d streams "
                                    "(edadm.sampling.InFlightSampler: a second batch's launches fill the idle slots between the ~500 "
@@ -626,6 +640,9 @@ def main():
                        "images_per_step": B, "ddim_steps": 20, "cfg_scale": 3.0, "parallelism": "dp%d (independent batches, no collective)" % world},
             "sampling_only": {"metric": "images/sec of the quantised UNet sampling path alone (latents, not decoded)", "value": ips_unet,
                               "ms_per_step": 1e3 * elapsed_unet / args.steps, "steps": args.steps, "warmup": args.warmup},
+            "one_batch_in_flight": {"value": images / elapsed_one, "sampling_only": images / elapsed_unet_one,
+                                    "ms_per_step": 1e3 * elapsed_one / args.steps,
+                                    "note": "the same K steps issued serially on one stream (no InFlightSampler): kernels alone"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": I8_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / I8_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "frac_definition": "dominant kernel GROUP: executed flops of every int8 GEMM launch of one UNet call / their summed "
@@ -639,8 +656,8 @@ def main():
                          "algorithmic_bytes_note": "per GEMM call, like `traffic`: int8 activation tensor + integer weights + output in "
                                                    "its stored type + fp32 residual, each element once (a convolution's input counted "
                                                    "once, not 9x); traffic / algorithmic_bytes = re-read factor",
-                         "kernel": "int8 GEMM (edadm_qgemm_i8/_q and edadm_qconv3_i8_direct: k_conv3_direct, k_gemm_nt, k_gemm_p, k_gemm_nt8): %d launches per UNet call of a DDIM step, %.1f GFLOP, %.2f ms summed"
-                                   % (len(i8), gemm_flop / 1e9, gemm_ms),
+                         "kernel": "int8 GEMM group, %d launches per UNet call, %.1f GFLOP, %.2f ms (cold)" % (len(i8), gemm_flop / 1e9, gemm_ms),
+                         "kernel_note": "edadm_qgemm_i8/_q and edadm_qconv3_i8_direct: k_conv3_direct, k_gemm_nt, k_gemm_p, k_gemm_nt8",
                          "hbm": {"note": "same launches against the HBM roof: PMC bytes per launch x launches / summed time",
                                  "achieved_GBps": (traffic * len(i8) / (gemm_ms * 1e-3) / 1e9) if traffic else None,
                                  "peak_GBps": 8000.0,
@@ -726,7 +743,7 @@ def main():
         def _torn_down(signum, frame):
             if rank == 0:
                 line["calibration"]["error"] = "a rank failed inside the %d-rank calibration job (its traceback is on stderr); torn down" % world
-                print(json.dumps(line), flush=True)
+                emit(line)
             os._exit(14)
         signal.signal(signal.SIGTERM, _torn_down)
     if args.calib != "none" and (world == 1 or args.calib == "full"):
@@ -783,11 +800,11 @@ def main():
                 sys.stderr.flush()
                 if rank == 0:
                     line["calibration"].update(calib_out)
-                    print(json.dumps(line), flush=True)
+                    emit(line)
                 os._exit(13)                                   # no collective after a failure: the launcher ends the other ranks
     if rank == 0:
         line["calibration"].update(calib_out)
-        print(json.dumps(line))
+        emit(line)
     if world > 1:
         dist.destroy_process_group()
 
