@@ -235,11 +235,12 @@ __global__ void __launch_bounds__(256) k_tdac_pairs(const float* __restrict__ F,
         mse[(int64_t)i * T + j] = mse[(int64_t)j * T + i] = m;
         cosd[(int64_t)i * T + j] = cosd[(int64_t)j * T + i] = cv;
     }
-    if (blockIdx.x == 0 && threadIdx.x < T) mse[(int64_t)threadIdx.x * T + threadIdx.x] = cosd[(int64_t)threadIdx.x * T + threadIdx.x] = 0.f;
+    if (blockIdx.x == 0)                                        // the diagonal: any T (Church samples 500 steps by default)
+        for (int64_t d = threadIdx.x; d < T; d += 256) mse[d * T + d] = cosd[d * T + d] = 0.f;
 }
 extern "C" int edadm_tdac_pair_scores(const float* feats, int64_t T, int64_t B, int64_t C, int64_t P, float eps, float* mse,
                                       float* cosdis, void* stream) {
-    if (!feats || !mse || !cosdis || T < 2 || T > 256 || B <= 0 || C <= 0 || P <= 0) return EDADM_EINVAL;
+    if (!feats || !mse || !cosdis || T < 2 || T > 32768 || B <= 0 || C <= 0 || P <= 0) return EDADM_EINVAL;
     const unsigned pairs = (unsigned)(T * (T - 1) / 2);
     hipLaunchKernelGGL(k_tdac_pairs, dim3(pairs), dim3(256), 0, (hipStream_t)stream, feats, (int)T, B, C, P, eps, mse, cosdis);
     return edadm_launch_status();

@@ -6,6 +6,7 @@ integer number of calibration samples per step summing to N (:66-92), and assemb
 SURVEY.md §8f-1: on the device the O(T^2) scoring is ONE launch (edadm_tdac_pair_scores, csrc/small.hip: a workgroup per pair reads
 the two maps once -- the reference's loop is 380 pairs x five torch passes); host tensors (the host-logic test of the allocation
 rule, G9) take the reference's own torch statements."""
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -17,13 +18,14 @@ def tdac_scores(feature_map, dense_r):
     if feature_map[0].is_cuda and T >= 2:
         from . import ops
         mse, cd = ops.tdac_pair_scores(feature_map)
-        mse, cd = mse.cpu(), cd.cpu()
-        for i in range(T):
-            for j in range(T):                       # the reference's order of j: a count, and a sequential fp32 sum
-                if i != j:
-                    if mse[i, j] <= dense_r:
-                        dense_num[i] = dense_num[i] + 1
-                    cos_dis[i] = cos_dis[i] + cd[i, j]
+        mse, cd = mse.cpu(), cd.cpu().numpy()
+        # the reference's order of j: a count, and a sequential fp32 sum over j != i.  Both [T][T] tables come back with a zero
+        # diagonal: `x + 0.0f == x`, so the running fp32 sum along a whole row (numpy's cumsum accumulates left to right in the
+        # array's type) is the reference's sum over j != i, bit for bit; the count leaves the diagonal out explicitly
+        near = mse <= dense_r
+        near.fill_diagonal_(False)
+        dense_num = near.sum(dim=1).to(torch.int16)
+        cos_dis = torch.from_numpy(np.cumsum(cd, axis=1, dtype=np.float32)[:, -1].copy())
         return dense_num, cos_dis
     for i in range(T):
         for j in range(T):

@@ -64,3 +64,42 @@ def test_tdac_pair_scores_match_the_reference_statements(shape, T):
         t_num = (w / w.sum() * 256).round().to(torch.int64)
         assert int(a[3].sum()) == 256
         assert int((a[3] - t_num).abs().max()) <= 1            # before the +-1 fix-up of the rounding error (calibration.py:72-90)
+
+
+def test_tdac_pair_scores_beyond_256_steps():
+    """LSUN-Church samples 500 DDIM steps by default (scripts/sample_diffusion_ldm_church.py:35): one feature map per step, T = 500.
+    The launch has no limit on T (the diagonal is written by a strided loop); reference statements evaluated on host copies."""
+    from edadm import ops
+    from edadm.tdac import tdac_scores, tdac_allocate
+    T, shape = 500, (2, 8, 2, 2)
+    g = torch.Generator().manual_seed(500)
+    base = torch.randn(shape, generator=g)
+    fm_cpu = [base * (1.0 + 0.002 * t) + 0.01 * t * torch.randn(shape, generator=g) for t in range(T)]
+    fm = [f.cuda() for f in fm_cpu]
+    mse, cdm = ops.tdac_pair_scores(fm)
+    mse, cdm = mse.cpu(), cdm.cpu()
+    assert mse.shape == (T, T) and float(mse.diagonal().abs().max()) == 0.0 and float(cdm.diagonal().abs().max()) == 0.0
+    assert torch.equal(mse, mse.T) and torch.equal(cdm, cdm.T)
+    st = torch.stack(fm_cpu).double()
+    rows = [0, 1, 255, 256, 257, 499]
+    for i in rows:
+        d = ((st[i][None] - st) ** 2).flatten(1).mean(1).float()
+        d[i] = 0.0
+        assert torch.allclose(mse[i], d, rtol=2e-6, atol=0), i
+        cs = torch.stack([torch.sum(1 - F.cosine_similarity(fm_cpu[i], fm_cpu[j], dim=1, eps=1e-6)) for j in range(T)])
+        cs[i] = 0.0
+        assert torch.allclose(cdm[i], cs, rtol=2e-5, atol=2e-5), i
+    r = float(mse[0, 40])
+    dn, cd = tdac_scores(fm, r * 1.0000001)
+    near = mse <= r * 1.0000001
+    near.fill_diagonal_(False)
+    assert torch.equal(dn.long(), near.sum(1))
+    # the sequential fp32 sum over j != i in the reference's order
+    for i in rows:
+        s = torch.zeros(())
+        for j in range(T):
+            if j != i:
+                s = s + cdm[i, j]
+        assert float(s) == float(cd[i]), i
+    a = tdac_allocate(fm, 1.2, 1024, r)
+    assert int(a[3].sum()) == 1024 and a[3].numel() == T
