@@ -494,8 +494,15 @@ def main():
     cond = torch.randn(B, 1, 512, generator=gen, device=dev)
     uncond = torch.randn(1, 1, 512, generator=gen, device=dev).expand(B, 1, 512).contiguous()
 
-    def timed(decoder, flight=flight):
-        """W untimed + exactly K timed steps between barrier + synchronize on both sides; max over ranks"""
+    def flight_now():
+        return flight
+
+    def timed(decoder, serial=False):
+        """W untimed + exactly K timed steps between barrier + synchronize on both sides; max over ranks.  serial: one batch in
+        flight (the loop of the first in-flight slot on the current stream) instead of the InFlightSampler.  (`flight` is read from
+        the enclosing scope at call time: a default argument would keep the sampler, its graphs and static buffers alive through the
+        calibration job below.)"""
+        flight = None if serial else flight_now()
         run_steps(loop, decoder, side, noise, cond, uncond, 0, args.warmup, dev, flight)
         if args.warmup == 0 and decoder is not None:
             with torch.cuda.stream(side):
@@ -518,8 +525,8 @@ def main():
     elapsed = timed(dec)                      # the headline: sampled AND decoded
     elapsed_unet = timed(None)                # the quantised UNet sampling alone
     # the same K steps with ONE batch in flight (the serial loop of the reference's script): what the kernels alone deliver
-    elapsed_one = timed(dec, flight=None) if flight is not None else elapsed
-    elapsed_unet_one = timed(None, flight=None) if flight is not None else elapsed_unet
+    elapsed_one = timed(dec, serial=True) if flight is not None else elapsed
+    elapsed_unet_one = timed(None, serial=True) if flight is not None else elapsed_unet
     ops.device_status()                       # a deferred in-kernel failure (persistent-GEMM hand-off timeout) raises here
 
     # roofline pass: HIP events around every int8 MFMA GEMM launch of one eager UNet call as the sampling loop issues it

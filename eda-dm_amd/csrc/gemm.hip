@@ -23,6 +23,7 @@
 #include "../../include/edadm.h"
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
+#include <string.h>
 // Launch heuristics are compile-time constants in the product; the diagnostic build (`make diag` / `make stamps`,
 // -DEDADM_DIAG, loaded only by tools/ through EDADM_LIB_PATH) reads them from the environment to sweep kernel structures.
 #ifdef EDADM_DIAG
@@ -710,7 +711,7 @@ extern "C" int EDADM_PAD_INIT_NAME(EDADM_GEMM_DT)() {
     return hipGetLastError() == hipSuccess ? 0 : EDADM_EIO;
 }
 // Diagnostics (tools/unet_prof.py, tools/pmc_traffic.py): which kernel structures the LAST entry-point call of this thread
-// launched, in order -- 1 k_gemm_nt, 2 k_gemm_nt8, 3 k_gemm_p, 4 k_gemm_ntq, 5 k_conv3_direct, 6 k_gemm_split2, 7 k_gemm_geglu.  Host-side bookkeeping of
+// launched, in order -- 1 k_gemm_nt, 2 k_gemm_nt8, 3 k_gemm_p, 4 k_gemm_ntq, 5 k_conv3_direct, 6 k_gemm_split2, 7 k_gemm_br.  Host-side bookkeeping of
 // a few integers per launch (a graph replay runs none of it).
 static thread_local int g_launch_tags[8];
 static thread_local int g_launch_ntags = 0;
@@ -1874,6 +1875,219 @@ extern "C" void edadm_dbg_read(unsigned long long* dst) {
 }
 #endif
 
+#if EDADM_GEMM_DT == 0
+// ---- k_gemm_br: grouped, WEIGHT-RESIDENT persistent kernel for the short-K, quantised-output dense layers (the GEGLU
+// projections 384 -> 3072 and 576 -> 4608, and the q / k / v projections of a self-attention as ONE launch).
+// What bounded k_gemm_p on these layers: a 256 x 192 tile takes in (256 + 192) K bytes for 4.6 k MFMA cycles
+// at K = 384 -- more than the ~25 B/clk a CU gets from its L2 -- and its eight MFMA waves walk tile by tile in lockstep (every wave
+// reads every ring slot), so the GEGLU / quantising epilogue (2-3 x the MFMA time of such a tile, all VALU) never overlaps the next
+// tile's matrix work.  Here:
+//   * a workgroup owns ONE 192-column block of ONE problem and keeps that block's weights [192][K] RESIDENT in LDS (72 KB at
+//     K = 384, 108 KB at 576) for all its row tiles: the intake per 128 x 192 outputs is the 128 x K activation rows alone
+//     (2 B per output at K = 384 instead of 3.5);
+//   * two CONSUMER GROUPS of four MFMA waves (one wave of each group per SIMD) take alternate 128-row tiles: while a group runs its
+//     epilogue on the vector ALU its SIMD partners of the other group run the next tile's MFMAs -- the matrix pipe and the VALU of
+//     a SIMD work at the same time, on different tiles;
+//   * four loader waves stream the activation rows by LDS-DMA (global_load_lds_dwordx4, hand-counted vmcnt, DEPTH K-steps in
+//     flight) into a ring of 8 KB slots; per slot a FULL word (4 loader waves) and a FREE word (the 4 waves of the consuming
+//     group), no workgroup barrier after the prologue.
+// Arithmetic and epilogue are k_gemm_ntq's / k_gemm_p's (operands swapped, gemm_epilogue_qdirect): the same codes bit for bit.
+struct BrProblem {
+    const uint8_t* A;
+    const uint8_t* W;
+    const float* scale;
+    const float* bias;
+    void* out;
+    const float* oqp;
+    int64_t lda, ldw, ldo, rpb, N;
+    int out_mode, cb0;                     // cb0: index of the problem's first column block in the launch
+};
+struct BrArgs {
+    BrProblem p[4];
+    int count, ncb, wpc, mt;               // problems, column blocks in all, workgroups per column block, 128-row tiles
+};
+
+template <int TN, int NK>
+__global__ void __launch_bounds__(768)
+k_gemm_br(const BrArgs a) {
+    constexpr int BN = 64 * TN, GM = 128;
+    constexpr int BBYTES = BN * NK * 64;                   // the resident weight block, NK panels of [BN][64 B]
+    constexpr int ASLOT = GM * 64;                         // one K-step of a group's 128 activation rows
+    constexpr int ECN = 2 * BN + 4;
+    constexpr int SA_ROOM = (160 * 1024 - BBYTES - ECN * 4 - 256) / ASLOT;
+    constexpr int SA = SA_ROOM > 12 ? 12 : SA_ROOM;        // ring slots
+    constexpr int DEPTH = 4;                               // K-steps a loader wave keeps in flight
+    static_assert(SA >= DEPTH + 2, "ring too short for the loader's depth");
+    constexpr int SMEM_BYTES = BBYTES + SA * ASLOT + ECN * 4 + (2 * SA + 2) * 4;
+    __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM_BYTES];
+    uint8_t* Bres = smem;
+    uint8_t* Aring = smem + BBYTES;
+    float* ec = reinterpret_cast<float*>(smem + BBYTES + SA * ASLOT);
+    int* full_w = reinterpret_cast<int*>(smem + BBYTES + SA * ASLOT + ECN * 4);
+    int* free_w = full_w + SA;
+    int* ready_w = free_w + SA;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // workgroups of one XCD are neighbours in `logical` (xcd_tile's bijection); within an XCD the column blocks of one row range
+    // are neighbours: the activation rows they all read cross into that XCD's L2 once
+    const unsigned nwg = gridDim.x, wg = blockIdx.x;
+    unsigned logical = wg;
+    if (nwg >= 16) {
+        const unsigned k = wg & 7, j = wg >> 3, q = nwg >> 3, r = nwg & 7;
+        logical = k * q + (k < r ? k : r) + j;
+    }
+    const int cb = (int)(logical % (unsigned)a.ncb), wi = (int)(logical / (unsigned)a.ncb);
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (i < a.count && cb >= a.p[i].cb0) pi = i;
+    const BrProblem& P = a.p[pi];
+    const int64_t n0 = (int64_t)(cb - P.cb0) * BN;
+    const int u0 = (int)((int64_t)a.mt * wi / a.wpc), u1 = (int)((int64_t)a.mt * (wi + 1) / a.wpc);
+    const int nu = u1 - u0;
+    const int G = nu * NK;                                  // K-steps this workgroup streams
+    if (tid < 2 * SA + 2) full_w[tid] = 0;
+    __syncthreads();
+    bool dead = false;
+    auto wait_at_least = [&](int* word, int target) {
+        if (dead) return;
+        for (int spins = 0;; ++spins) {
+            const int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+            if (v >= target) return;
+            if (spins > (1 << 22)) {
+                dead = true;
+                if (lane == 0) atomicOr(&g_error_word, 2u);
+                return;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
+    auto signal = [&](int* word) {
+        if (lane == 0) __hip_atomic_fetch_add(word, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
+
+    if (wave >= 8) {
+        // ------------------------------------------------------------------ loader waves
+        const int lw = wave - 8, ltid = tid - 512;
+        // a 1-KiB piece is 16 rows x 64 bytes, lane-linear in LDS: lane l lands at row l / 4, physical chunk l % 4, and fetches the
+        // logical chunk (l % 4) ^ ((row >> 2) & 3) -- the swizzle of the fragment reads, applied to the source
+        const int prow = lane >> 2;
+        const int sc = (lane & 3) ^ ((lane >> 4) & 3);
+        // epilogue constants of the column block (fixed for the workgroup's life)
+        for (int idx = ltid; idx < 2 * BN; idx += 256) {
+            const int c = idx < BN ? idx : idx - BN;
+            ec[idx] = idx < BN ? P.scale[n0 + c] : (P.bias ? P.bias[n0 + c] : 0.f);
+        }
+        if (ltid < 3) ec[2 * BN + ltid] = P.oqp[ltid];
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        // the weight block: NK x (BN / 16) pieces, dealt round-robin to the four loader waves
+        {
+            const uint8_t* wrow = P.W + (n0 + prow) * P.ldw + sc * 16;
+            for (int pc = lw; pc < NK * (BN / 16); pc += 4) {
+                const int kk = pc / (BN / 16), rb = pc - kk * (BN / 16);
+                glds16(wrow + (int64_t)rb * 16 * P.ldw + kk * 64, lds0 + (uint32_t)(kk * (BN * 64) + rb * 1024));
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        signal(ready_w);
+        // the activation stream: step gs = (unit gs / NK, K-step gs % NK) -> ring slot gs % SA; this wave's two pieces are rows
+        // [32 lw, 32 lw + 32) of the unit's 128
+        const uint8_t* arow = P.A + (int64_t)(lw * 32 + prow) * P.lda + sc * 16;
+        int unit = 0, kk = 0, slot = 0, use = 0;           // of the next step to issue; use = gs / SA
+        int s_slot = 0;                                     // slot of the next step to publish
+        auto issue = [&]() {
+            if (use > 0) wait_at_least(free_w + slot, 4 * use);
+            const uint8_t* src = arow + (int64_t)(u0 + unit) * GM * P.lda + kk * 64;
+            const uint32_t dst = lds0 + (uint32_t)(BBYTES + slot * ASLOT + lw * 2048);
+            glds16(src, dst);
+            glds16(src + 16 * P.lda, dst + 1024);
+            if (++kk == NK) { kk = 0; ++unit; }
+            if (++slot == SA) { slot = 0; ++use; }
+        };
+        auto publish = [&]() {
+            signal(full_w + s_slot);
+            if (++s_slot == SA) s_slot = 0;
+        };
+        int gi = 0;
+        for (; gi < G && gi < DEPTH - 1; ++gi) issue();
+        for (; gi < G; ++gi) {
+            issue();
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (DEPTH - 1)) : "memory");   // the oldest step in flight has landed
+            publish();
+        }
+        // drain: the last min(G, DEPTH - 1) steps
+        const int tail = G < DEPTH - 1 ? G : DEPTH - 1;
+        if (tail >= 3) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); publish(); }
+        if (tail >= 2) { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); publish(); }
+        if (tail >= 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); publish(); }
+        static_assert(DEPTH == 4, "the drain above is written for three steps in flight");
+        return;
+    }
+
+    // ---------------------------------------------------------------------- MFMA waves: group = wave / 4
+    const int grp = wave >> 2, wq = wave & 3;
+    const int wm = wq >> 1, wn = wq & 1;
+    const int fr = lane & 31, fh = lane >> 5;
+    v16i acc[2][TN];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+    };
+    zero_acc();
+    wait_at_least(ready_w, 4);                              // weights and epilogue constants are in LDS
+    uint4 fa0[2], fb0[TN], fa1[2], fb1[TN];
+    auto rd = [&](const uint8_t* As, const uint8_t* Bs, int ks, uint4 (&fa)[2], uint4 (&fb)[TN]) {
+        const int c = 2 * ks + fh;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = wm * 64 + i * 32 + fr;
+            fa[i] = *reinterpret_cast<const uint4*>(As + (r * 4 + (c ^ ((r >> 2) & 3))) * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int r = wn * (TN * 32) + j * 32 + fr;
+            fb[j] = *reinterpret_cast<const uint4*>(Bs + (r * 4 + (c ^ ((r >> 2) & 3))) * 16);
+        }
+    };
+    auto mm = [&](uint4 (&fa)[2], uint4 (&fb)[TN]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) mma_step<0>(fb[j], fa[i], acc[i][j]);      // swapped: a lane owns an output row
+    };
+    for (int li = grp; li < nu; li += 2) {
+        int gs = li * NK;
+        int slot = gs % SA, use = gs / SA;
+        wait_at_least(full_w + slot, 4 * (use + 1));
+        rd(Aring + slot * ASLOT, Bres, 0, fa0, fb0);
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+            const uint8_t* As = Aring + slot * ASLOT;
+            rd(As, Bres + kk * (BN * 64), 1, fa1, fb1);
+            mm(fa0, fb0);
+            const int pslot = slot;
+            if (kk + 1 < NK) {
+                if (++slot == SA) { slot = 0; ++use; }
+                wait_at_least(full_w + slot, 4 * (use + 1));
+                rd(Aring + slot * ASLOT, Bres + (kk + 1) * (BN * 64), 0, fa0, fb0);
+            }
+            mm(fa1, fb1);
+            signal(free_w + pslot);                         // release: this step's fragments are in registers
+        }
+        const int64_t m0 = (int64_t)(u0 + li) * GM;
+        gemm_epilogue_qdirect<0, 2, TN, BN, 0, 1>(acc, ec, lane, m0 + wm * 64, n0 + wn * (TN * 32), wn * (TN * 32), P.out, P.ldo,
+                                                  P.out_mode, nullptr, 0, P.rpb, P.N);
+        zero_acc();
+    }
+}
+#endif
+
 template <int DT>
 static int launch_gemm(const void* A, int64_t lda_b, int64_t sA, const void* Bm, int64_t ldb_b, int64_t sB,
                        int64_t M, int64_t N, int64_t Kb, const ConvGeom& g, const float* scale, const float* bias,
@@ -2803,6 +3017,58 @@ extern "C" int edadm_qgemm_i8_q(const int8_t* A, int64_t lda, const int8_t* Wt, 
     if (rowadd && rows_per_batch < 16) return EDADM_EINVAL;
     return launch_gemm<0>(A, lda, 0, Wt, ldw, 0, M, N, K, g, scale, bias, rowadd, rows_per_batch, residual, ldr,
                              (float*)out, ldo, 0, 1, 1.0f, (hipStream_t)stream, 1, 0, 0, 0, out_mode, oqp);
+}
+#endif
+
+#if EDADM_GEMM_DT == 0
+// ---- grouped quantised-output dense layers on the weight-resident kernel (k_gemm_br): `count` (<= 4) problems of the same M and
+// K in ONE launch -- the q / k / v projections of a self-attention (ldm/modules/attention.py:168-176; three QuantModules with their
+// own input and output quantisers, quant_layer.py:406-437), or one GEGLU projection (attention.py:37-45).
+extern "C" int edadm_qgemm_i8_grouped_q_ok(int64_t M, int64_t N, int64_t K) {
+    return M > 0 && M % 128 == 0 && N > 0 && N % 192 == 0 && (K == 384 || K == 576) && (M / 128) * (N / 192) >= 448;
+}
+extern "C" int edadm_qgemm_i8_grouped_q(const edadm_gemm_problem* probs, int count, int64_t M, int64_t K, void* stream) {
+    if (!probs || count < 1 || count > 4 || M <= 0 || M % 128 || (K != 384 && K != 576)) return EDADM_EINVAL;
+    BrArgs a;
+    memset(&a, 0, sizeof(a));
+    int ncb = 0;
+    for (int i = 0; i < count; ++i) {
+        const edadm_gemm_problem& q = probs[i];
+        if (!q.A || !q.W || !q.scale || !q.out || !q.oqp || q.N <= 0 || q.N % 192 || q.lda < K || (q.lda & 15) || q.ldw < K ||
+            (q.ldw & 15) || ((uintptr_t)q.A & 15) || ((uintptr_t)q.W & 15) || q.out_mode < 1 || q.out_mode > 4)
+            return EDADM_EINVAL;
+        // the register-direct epilogue's store widths (k_gemm_ntq's conditions)
+        if (q.out_mode == 4) {
+            if (q.rows_per_batch <= 0 || (q.rows_per_batch & 31) || M % q.rows_per_batch || q.ldo < q.rows_per_batch ||
+                ((uintptr_t)q.out & 3))
+                return EDADM_EINVAL;
+        } else if (q.out_mode == 3) {
+            if (((uintptr_t)q.out & 7) || (q.ldo & 7) || q.ldo < q.N / 2) return EDADM_EINVAL;
+        } else if (((uintptr_t)q.out & 15) || ((q.ldo * (q.out_mode == 1 ? 2 : 1)) & 15) || q.ldo < q.N) {
+            return EDADM_EINVAL;
+        }
+        BrProblem& b = a.p[i];
+        b.A = (const uint8_t*)q.A; b.W = (const uint8_t*)q.W; b.scale = q.scale; b.bias = q.bias; b.out = q.out; b.oqp = q.oqp;
+        b.lda = q.lda; b.ldw = q.ldw; b.ldo = q.ldo; b.rpb = q.out_mode == 4 ? q.rows_per_batch : M; b.N = q.N;
+        b.out_mode = q.out_mode; b.cb0 = ncb;
+        ncb += (int)(q.N / 192);
+    }
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (ncu < 1) ncu = 1;
+    }
+    const int mt = (int)(M / 128);
+    int wpc = ncu / ncb;
+    if (wpc < 1) wpc = 1;
+    if (wpc > mt) wpc = mt;
+    a.count = count; a.ncb = ncb; a.wpc = wpc; a.mt = mt;
+    launch_tag(7);
+    if (K == 384) hipLaunchKernelGGL((k_gemm_br<3, 6>), dim3((unsigned)(ncb * wpc)), dim3(768), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((k_gemm_br<3, 9>), dim3((unsigned)(ncb * wpc)), dim3(768), 0, (hipStream_t)stream, a);
+    return edadm_launch_status();
 }
 #endif
 

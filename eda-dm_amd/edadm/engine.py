@@ -141,6 +141,7 @@ class Engine:
         self.w4_gemm_max_rows = 2048     # dense 4-bit layers at M <= this read their weights as packed nibbles (K4w); 0: never
         self.attention_i8_scores = True  # one wide head (d = 384): Q K^T on the int8 MFMA (False: the f16 form of K6w; same codes up to boundary cases)
         self.fused_split = True          # split-quantiser skip convolutions as one launch (False: two, the second through the residual port)
+        self.grouped_gemm = True         # q / k / v projections as ONE launch and the short-K GEGLU projections on the weight-resident kernel (False: one edadm_qgemm_i8_q launch each; same codes)
         self.fused_attention = True      # K6f for heads of d <= 160 (False: the three-kernel path with the scores in memory;
                                          # the two differ only in the order of the fp32 row sum, i.e. in rare +-1 probability codes)
         # classifier-free guidance evaluates [x, x] with contexts [uncond, cond]: the two halves are identical until the first
@@ -378,6 +379,35 @@ class Engine:
                               self._alg_bytes(L, a, M, 4.0 * M * L.N, residual, "conv%d" % L.kh if geom is not None else "dense")))
         run()
         return out
+
+    def _gemm_group(self, items, M):
+        """items: [(L, a, out_mode, oqp, rpb)] -- quantised-output dense layers over the same rows (the q / k / v projections of a
+        self-attention; one GEGLU projection).  ONE launch of the weight-resident grouped kernel (edadm_qgemm_i8_grouped_q, K4g) when
+        the shapes allow, else one _gemm call each: the same codes either way."""
+        Ls = [it[0] for it in items]
+        K = Ls[0].segs[0]["K"] if Ls[0].mode == "i8" and len(Ls[0].segs) == 1 else -1
+        ok = (self.grouped_gemm and 1 <= len(items) <= 4 and K > 0
+              and all(L.mode == "i8" and len(L.segs) == 1 and not L.split and L.segs[0]["K"] == K and L.N % 192 == 0 for L in Ls)
+              and all(a.dim() == 2 and a.shape[0] == M and a.shape[1] == K and a.stride(1) == 1 and a.stride(0) % 16 == 0
+                      and a.data_ptr() % 16 == 0 for _, a, _, _, _ in items)
+              and all(mode in (1, 2, 3) or (mode == 4 and rpb and rpb % 32 == 0 and M % rpb == 0) for _, _, mode, _, rpb in items)
+              and ops.qgemm_i8_grouped_q_ok(M, sum(L.N for L in Ls), K))
+        if not ok:
+            return [self._gemm(L, a, M, out_mode=mode, oqp=oqp, rpb=rpb or 1) for L, a, mode, oqp, rpb in items]
+        if self.tap is not None:
+            for L, a, _, _, _ in items:
+                self.tap.setdefault(L.name, []).append(a.detach().clone())
+        probs = [dict(A=a, lda=a.stride(0), W=L.segs[0]["w"], N=L.N, scale=L.segs[0]["scale"], bias=L.bias, out_mode=mode, oqp=oqp,
+                      rows_per_batch=rpb) for L, a, mode, oqp, rpb in items]
+        run = lambda: ops.qgemm_i8_grouped_q(probs, M, K)
+        if self.prof is not None:
+            by = {"kind": "dense", "a": 0.0, "w": 0.0, "out": 0.0, "res": 0.0}
+            for L, a, mode, _, _ in items:
+                one = self._alg_bytes(L, a, M, {1: 2.0, 2: 1.0, 3: 0.5, 4: 2.0}[mode] * M * L.N, None, "dense")
+                for k in ("a", "w", "out"):
+                    by[k] += one[k]
+            self.prof.append(("i8", "+".join(L.name for L in Ls), M, sum(L.N for L in Ls), K, 2.0 * M * sum(L.N for L in Ls) * K, run, by))
+        return run()
 
     @staticmethod
     def _alg_bytes(L, a, M, out_bytes, residual, kind):
@@ -830,9 +860,14 @@ class Engine:
         if (self.fused_attention and self.attention_i8_scores and ops.attention_i8qk_ok(heads_, d_, Nq, Nk)
                 and all(self.L(m).mode == "i8" and len(self.L(m).segs) == 1 for m in (attn.to_q, attn.to_k)) and Lv.mode == "i8"
                 and len(Lv.segs) == 1):
-            q8 = self._gemm(self.L(attn.to_q), x2d_q, B * Nq, out_mode=2, oqp=self._aq(attn.act_quantizer_q)[0])
-            k8 = self._gemm(self.L(attn.to_k), ctx_ops[0], B * Nk, out_mode=2, oqp=self._aq(attn.act_quantizer_k)[0])
-            v = self._gemm(Lv, ctx_ops[1], B * Nk, out_mode=1, oqp=self._aq(attn.act_quantizer_v)[0], rpb=Nk)
+            if Nq == Nk:                                      # self-attention: the three projections read rows of the same count
+                q8, k8, v = self._gemm_group([(self.L(attn.to_q), x2d_q, 2, self._aq(attn.act_quantizer_q)[0], 0),
+                                              (self.L(attn.to_k), ctx_ops[0], 2, self._aq(attn.act_quantizer_k)[0], 0),
+                                              (Lv, ctx_ops[1], 1, self._aq(attn.act_quantizer_v)[0], Nk)], B * Nq)
+            else:
+                q8 = self._gemm(self.L(attn.to_q), x2d_q, B * Nq, out_mode=2, oqp=self._aq(attn.act_quantizer_q)[0])
+                k8 = self._gemm(self.L(attn.to_k), ctx_ops[0], B * Nk, out_mode=2, oqp=self._aq(attn.act_quantizer_k)[0])
+                v = self._gemm(Lv, ctx_ops[1], B * Nk, out_mode=1, oqp=self._aq(attn.act_quantizer_v)[0], rpb=Nk)
             Lo = self.L(attn.to_out[0])
             fuse = Lo.mode == "i8" and not Lo.split
             (_, dq), (_, dk), (_, dv), (qpw, dw) = (self._aq(a) for a in (attn.act_quantizer_q, attn.act_quantizer_k, attn.act_quantizer_v,
@@ -841,12 +876,16 @@ class Engine:
             o = ops.attention_fused_i8qk(q8, k8, v, B, heads_, Nq, Nk, d_, dq * dk * attn.scale, zq, qpw, dw * dv,
                                          out_qp=Lo.qp if (fuse and (heads_ * d_) % 4 == 0) else None)
             return self.lin(attn.to_out[0], None if fuse else o, residual=residual, pre=o if fuse else None)
-        q = self._gemm(self.L(attn.to_q), x2d_q, B * Nq, out_mode=1, oqp=self._aq(attn.act_quantizer_q)[0])
-        k = self._gemm(self.L(attn.to_k), ctx_ops[0], B * Nk, out_mode=1, oqp=self._aq(attn.act_quantizer_k)[0])
         fused = self.fused_attention and ops.attention_fused_ok(heads_, self.L(attn.to_q).N // heads_, Nq, Nk)
         vt_ok = (not fused) and Lv.mode == "i8" and len(Lv.segs) == 1 and ops.vt_mode_ok(B * Nk, Lv.N, Nk)
         # the v projection writes the P.V product's B operand directly: f16 codes, transposed per image
-        v = self._gemm(Lv, ctx_ops[1], B * Nk, out_mode=4 if vt_ok else 1, oqp=self._aq(attn.act_quantizer_v)[0], rpb=Nk)
+        qkv = [(self.L(attn.to_q), x2d_q, 1, self._aq(attn.act_quantizer_q)[0], 0),
+               (self.L(attn.to_k), ctx_ops[0], 1, self._aq(attn.act_quantizer_k)[0], 0),
+               (Lv, ctx_ops[1], 4 if vt_ok else 1, self._aq(attn.act_quantizer_v)[0], Nk)]
+        if Nq == Nk:
+            q, k, v = self._gemm_group(qkv, B * Nq)
+        else:
+            q, k, v = (self._gemm(L_, a_, B * (Nq if i_ == 0 else Nk), out_mode=m_, oqp=o_, rpb=r_ or 1) for i_, (L_, a_, m_, o_, r_) in enumerate(qkv))
         heads = attn.heads
         d = q.shape[1] // heads
         Lo = self.L(attn.to_out[0])
@@ -934,7 +973,7 @@ class Engine:
                                       "padded K behind GEGLU: no configuration of the reference produces it (W8 is shipped for "
                                       "the DDPM UNet only)")
         if getattr(L0, "geglu_interleaved", False):
-            g = self._gemm(L0, of, B * N, out_mode=3, oqp=L2.qp)
+            (g,) = self._gemm_group([(L0, of, 3, L2.qp, 0)], B * N)
         else:
             g = ops.geglu_quant_i8(self._gemm(L0, of, B * N), L2.qp)
         if out_qp is not None and L2.mode == "i8" and len(L2.segs) == 1:

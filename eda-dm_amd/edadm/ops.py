@@ -73,6 +73,20 @@ def init_device(device):
 
 
 _ws_scope = [None]
+_scope_tokens = [0]
+
+
+def new_scope_token():
+    """A workspace-scope tag no other object of this process has had (an id() can be recycled once its owner is gone: a new owner
+    would silently inherit buffers of a stale size on the same stream)."""
+    _scope_tokens[0] += 1
+    return "scope%d" % _scope_tokens[0]
+
+
+def release_scope(tag):
+    """Drop the workspaces of a scope whose owner (and its captured graphs, the only launches that knew those addresses) is gone."""
+    for key in [k for k in _ws if k[3] == tag]:
+        del _ws[key]
 
 
 class workspace_scope:
@@ -672,6 +686,43 @@ def qgemm_i8_q(A, Wt, M, N, K, scale, bias, out_mode, oqp, geom=None, lda=None, 
              int(M), int(N), int(K), gptr, _pf(scale), _pf(bias), _pf(rowadd), int(rows_per_batch), _pf(residual),
              int(N), ctypes.c_void_p(out.data_ptr()), int(ncol), int(out_mode), _pf(oqp), _stream())
     return out
+
+
+class _GemmProblem(ctypes.Structure):
+    """struct edadm_gemm_problem (include/edadm.h)"""
+    _fields_ = [("A", ctypes.c_void_p), ("lda", ctypes.c_int64), ("W", ctypes.c_void_p), ("ldw", ctypes.c_int64),
+                ("scale", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("out", ctypes.c_void_p), ("ldo", ctypes.c_int64),
+                ("oqp", ctypes.c_void_p), ("N", ctypes.c_int64), ("rows_per_batch", ctypes.c_int64), ("out_mode", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
+def qgemm_i8_grouped_q_ok(M, N, K):
+    """N: the output columns of all problems of the launch together"""
+    return bool(lib.load().edadm_qgemm_i8_grouped_q_ok(int(M), int(N), int(K)))
+
+
+def qgemm_i8_grouped_q(problems, M, K):
+    """edadm_qgemm_i8_grouped_q: up to four quantised-output dense layers of the same M and K in ONE launch (the q / k / v projections
+    of a self-attention, or one GEGLU projection).  problems: dicts with A (int8 [M][lda]), W (int8 [N][K]), N, scale, bias, out_mode,
+    oqp and rows_per_batch (mode 4).  Returns the outputs in order -- the bits of one qgemm_i8_q call per problem."""
+    arr = (_GemmProblem * len(problems))()
+    outs = []
+    for q, pr in zip(arr, problems):
+        A, N, mode = pr["A"], int(pr["N"]), int(pr["out_mode"])
+        rpb = int(pr.get("rows_per_batch") or 0)
+        if mode == 4:
+            out = torch.empty(M // rpb, N, rpb, dtype=torch.float16, device=A.device)
+            ldo = rpb
+        else:
+            ldo = N // 2 if mode == 3 else N
+            out = torch.empty(M, ldo, dtype=_OUT_DT[mode], device=A.device)
+        outs.append(out)
+        q.A, q.lda, q.W, q.ldw = A.data_ptr(), int(pr.get("lda") or K), pr["W"].data_ptr(), int(pr.get("ldw") or K)
+        q.scale, q.bias = pr["scale"].data_ptr(), (pr["bias"].data_ptr() if pr.get("bias") is not None else None)
+        q.out, q.ldo, q.oqp, q.N, q.rows_per_batch, q.out_mode, q.reserved = out.data_ptr(), ldo, pr["oqp"].data_ptr(), N, rpb, mode, 0
+        assert A.dtype == torch.int8 and pr["W"].dtype == torch.int8 and pr["scale"].dtype == torch.float32 and pr["oqp"].dtype == torch.float32
+    lib.call("edadm_qgemm_i8_grouped_q", ctypes.cast(arr, ctypes.c_void_p), len(problems), int(M), int(K), _stream())
+    return outs
 
 
 def gemm_f16_nt_q(A, lda, strideA, Bm, ldb, strideB, batch, M, N, K, alpha, out, out_mode, oqp, inner=1,

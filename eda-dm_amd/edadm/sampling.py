@@ -2,6 +2,8 @@
 (ldm/models/diffusion/ddim_control.py:167-254 of the reference), with the UNet forward captured
 once into a HIP graph and replayed per step, and the CFG combine + x_{t-1} update as one kernel
 (edadm_ddim_step, K9)."""
+import weakref
+
 import numpy as np
 import torch
 
@@ -25,6 +27,9 @@ class GraphedUNet:
         # workspace scope of this object: the graphs of two GraphedUNets never share a workspace, so they can be REPLAYED
         # concurrently (several sample batches in flight, InFlightSampler below) whatever streams were involved
         gkw = {} if capture_stream is None else {"stream": capture_stream}
+        # the scope's workspaces live exactly as long as this object (and with it the graphs that have their addresses baked in)
+        self._scope = ops.new_scope_token()
+        weakref.finalize(self, ops.release_scope, self._scope)
         self.engine = engine
         self.x, self.t = x.clone(), t.clone()
         self.ctx = None if ctx is None else ctx.clone()
@@ -50,20 +55,20 @@ class GraphedUNet:
         self.ctx_graph, self.ctx_r = None, None
         if getattr(engine, "ctx_r", None) is not None:
             self.ctx_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.ctx_graph, **gkw), ops.workspace_scope(id(self)):
+            with torch.cuda.graph(self.ctx_graph, **gkw), ops.workspace_scope(self._scope):
                 self.ctx_r = engine.context_branches(self.ctx)
         engine.ctx_r = self.ctx_r
         emb_r = None
         if ts_all is not None and tabs is not None:
             self.emb_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.emb_graph, **gkw), ops.workspace_scope(id(self)):
+            with torch.cuda.graph(self.emb_graph, **gkw), ops.workspace_scope(self._scope):
                 self.emb_tab, layout = engine.emb_tables(ts_all, len(timesteps))
             self.emb_stage = torch.empty_like(self.emb_tab[0])
             emb_r = {k: self.emb_stage[off:off + rows * n].view(rows, n) for k, (off, n) in layout.items()}
         engine.emb_r = emb_r
         self.graph = torch.cuda.CUDAGraph()
         try:
-            with torch.cuda.graph(self.graph, **gkw), ops.workspace_scope(id(self)):
+            with torch.cuda.graph(self.graph, **gkw), ops.workspace_scope(self._scope):
                 self.out = engine(self.x, self.t, self.ctx)
         finally:
             engine.ctx_r = None                       # eager calls of the engine keep evaluating both per call

@@ -254,7 +254,7 @@ int edadm_device_status(int clear, void* stream);
 int edadm_init_device(void);
 /* Diagnostics for the measurement tools (tools/unet_prof.py -> tools/pmc_traffic.py): the kernel structures the int8 GEMM /
  * convolution entry points launched on this host thread since the last call, in launch order, as tags (1 k_gemm_nt, 2 k_gemm_nt8,
- * 3 k_gemm_p, 4 k_gemm_ntq, 5 k_conv3_direct, 6 k_gemm_split2, 7 k_gemm_geglu); writes up to 8 of them, returns their number and forgets them.
+ * 3 k_gemm_p, 4 k_gemm_ntq, 5 k_conv3_direct, 6 k_gemm_split2, 7 k_gemm_br); writes up to 8 of them, returns their number and forgets them.
  * Lets a tool attribute each layer's ALGORITHMIC bytes to the kernel that ran it, so the PMC traffic per kernel name has its own
  * denominator.  No reference counterpart. */
 int edadm_diag_launch_kernels(int32_t* tags8);
@@ -296,6 +296,32 @@ int edadm_qgemm_i8_q(const int8_t* A, int64_t lda, const int8_t* Wt, int64_t ldw
                      int64_t K, const int32_t* geom, const float* scale, const float* bias,
                      const float* rowadd, int64_t rows_per_batch, const float* residual, int64_t ldr,
                      void* out, int64_t ldo, int out_mode, const float* oqp, void* stream);
+/* GROUPED form of edadm_qgemm_i8_q: `count` (1..4) dense layers of the same M and K in ONE launch, each with its own int8 operand A
+ * [M][lda], integer weights W [N][ldw], per-column scale / bias, output, output mode (1..4 as above) and consuming quantiser oqp -- the
+ * q / k / v projections of a self-attention (ldm/modules/attention.py:168-176; three QuantModules, quant_layer.py:406-437, whose input
+ * quantisers may differ after reconstruction: three operands, not one), or one GEGLU projection (attention.py:37-45; count = 1).
+ * Kernel k_gemm_br (csrc/gemm.hip): a workgroup keeps a 192-column weight block resident in LDS and streams the activation rows; two
+ * groups of MFMA waves take alternate 128-row tiles so that one group's quantising epilogue overlaps the other's matrix work.  The
+ * codes are those of `count` separate edadm_qgemm_i8_q launches, bit for bit.  Shapes: edadm_qgemm_i8_grouped_q_ok (M % 128 == 0,
+ * every N % 192 == 0, K = 384 or 576, enough tiles to fill the chip); no rowadd, no residual.  `probs` is a HOST array (its fields are
+ * copied into the launch). */
+typedef struct edadm_gemm_problem {
+    const int8_t* A;
+    int64_t lda;
+    const int8_t* W;
+    int64_t ldw;
+    const float* scale;
+    const float* bias;            /* may be NULL */
+    void* out;
+    int64_t ldo;                  /* output elements per row (mode 3: N / 2 bytes; mode 4: row length of the transposed image) */
+    const float* oqp;             /* device float[3] {delta, zero_point, qmax} */
+    int64_t N;
+    int64_t rows_per_batch;       /* mode 4 only */
+    int32_t out_mode;
+    int32_t reserved;
+} edadm_gemm_problem;
+int edadm_qgemm_i8_grouped_q_ok(int64_t M, int64_t N, int64_t K);
+int edadm_qgemm_i8_grouped_q(const edadm_gemm_problem* probs, int count, int64_t M, int64_t K, void* stream);
 /* The same attention (quant_block.py:204-235; openaimodel.py:384-406) for ONE WIDE head with q and k as INT8 operands (code - 128:
  * edadm_qgemm_i8_q out_mode 2) and v as the f16 operand (out_mode 1): the score product runs on the int8 MFMA, exact in int32;
  * zq = zero point of the q quantiser (the (128 - zq) sum_d k8 term is added per key; the key-independent terms cancel in the softmax).

@@ -1554,7 +1554,7 @@ class _G20Host(nn.Module):
                                         context_dim=_g20.TF["context_dim"], gated_ff=True, checkpoint=False)
 
 
-def g20_f16x3_units(threads=None, fname="g20_f16x3_units", input_ulp=False, iters=None):
+def g20_f16x3_units(threads=None, fname="g20_f16x3_units", input_ulp=False, iters=None, fp64=False):
     """G20: qdiff_control.block_reconstruction (qdiff_control/block_recon.py:13-243) on ONE LDM-4-sized ResBlock (192 -> 384 at
     32 x 32) and ONE transformer block (d = 384, 1024 tokens), 32-row minibatches, the shipped ImageNet hyper-parameters and
     0.5 / 0.5 masks -- the size at which the product contracts on its three-product f16 kernels.  Weights, cached unit inputs
@@ -1574,6 +1574,13 @@ def g20_f16x3_units(threads=None, fname="g20_f16x3_units", input_ulp=False, iter
     host = _G20Host().eval()
     sd = formula_state_dict([(k, tuple(v.shape)) for k, v in host.state_dict().items()], _g20.SEED)
     host.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    if fp64:
+        # the EXACT reference: the same fp32 weights, caches, scales, draws and masks, every operation of the reference's graph
+        # evaluated in float64 (its one explicit fp32 cast, GroupNorm32.forward util.py:214-216, lifted for the run)
+        from ldm.modules.diffusionmodules.util import GroupNorm32
+        GroupNorm32.forward = nn.GroupNorm.forward
+        torch.set_default_dtype(torch.float64)
+        host = host.double()
     aq = dict(AQ8)
     aq["prob"] = _g20.PROB
     qnn = QuantModel(host, WQ4, aq, sm_abit=8)
@@ -1622,6 +1629,8 @@ def g20_f16x3_units(threads=None, fname="g20_f16x3_units", input_ulp=False, iter
         unit = getattr(qnn.model, name)
         cq, cf = _g20.caches(name)
         cq, cf = [torch.from_numpy(a) for a in cq], [torch.from_numpy(a) for a in cf]
+        if fp64:
+            cq, cf = [a.double() for a in cq], [a.double() for a in cf]
         if input_ulp:
             # the conditioning probe: every cached input moved by (at most) one unit in the last place, nothing else changed
             cq = [a * np.float32(1 + int(input_ulp) * 2.0 ** -23) for a in cq]
@@ -1648,7 +1657,7 @@ def g20_f16x3_units(threads=None, fname="g20_f16x3_units", input_ulp=False, iter
         for n, m in uaqs:
             if m.leaf_param:
                 m.set_inited(True)
-        if input_ulp:
+        if input_ulp or fp64:
             # the probe moves the INPUTS only: the scales are the unperturbed run's (an MSE search over 100 candidates may pick
             # another candidate for a one-ulp change -- a 1 % step, not a rounding effect)
             base = np.load(os.path.join(HERE, "g20_f16x3_units.npz"))
@@ -1730,6 +1739,10 @@ def g20_f16x3_units(threads=None, fname="g20_f16x3_units", input_ulp=False, iter
     if input_ulp:
         d = {k: v for k, v in d.items() if k.startswith("grad0/")}
         d["input_scale"] = np.float32(1 + int(input_ulp) * 2.0 ** -23)
+    if fp64:
+        torch.set_default_dtype(torch.float32)
+        d = {k: (v.double().numpy() if torch.is_tensor(v) else v) for k, v in d.items() if k.startswith("grad0/")}
+        d["dtype"] = np.array("float64")
     save(fname, d)
 
 
@@ -1756,13 +1769,22 @@ def g20_ulp32_floor():
     g20_f16x3_units(fname="g20_reference_ulp32", input_ulp=32, iters=1)
 
 
+def g20_fp64_truth():
+    """The EXACT value of the iteration-0 gradients: the reference's own graph (qdiff_control/block_recon.py:145-217,
+    qdiff/quant_block.py:204-235) on the same fp32 weights, cached inputs, scales, minibatch draw and masks, every module and cached
+    tensor in float64.  Neither the reference's fp32 CPU run nor the product's MFMA contraction is the truth: both are fp32-grade
+    evaluations of a function whose 8-bit fake-quantisers flip codes at .5 boundaries; this run says how far EACH is from the value
+    they approximate (tests/test_fullsize_gpu.py gates the product at a multiple of the reference's own distance)."""
+    g20_f16x3_units(fname="g20_reference_fp64", iters=1, fp64=True)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     jobs = dict(g1=g1_weight_init, g2=g2_act_init, g3=g3_uaq_forward, g4=g4_adaround, g5=g5_loss,
                 g6=g6_quant_module, g7=g7_blocks, g8=g8_g12_recon, g9=g9_tdac, g10=g10_steps,
                 g13c=g13_cifar_unet, g13i=lambda: g13_ldm_unet("imagenet"), g13h=lambda: g13_ldm_unet("church"), g14=g14_plms, g15=g15_decoder,
                 g17=g17_tdac_imagenet, g7b=g7b_blocks, g13w8=lambda: g13_cifar_unet(8, "g13_cifar_w8", 1301), g13sd=g13_ldm_sd, g16=g16_layer_recon,
-                g8b=g8b_recon_masks, g8c=g8c_recon_caches, g18=g18_church_driver, g19=g19_tdac_others, g1b=g1b_max_init, g20=g20_f16x3_units, g20n=g20_noise_floor, g20u=g20_ulp_floor, g20u32=g20_ulp32_floor)
+                g8b=g8b_recon_masks, g8c=g8c_recon_caches, g18=g18_church_driver, g19=g19_tdac_others, g1b=g1b_max_init, g20=g20_f16x3_units, g20n=g20_noise_floor, g20u=g20_ulp_floor, g20u32=g20_ulp32_floor, g20f64=g20_fp64_truth)
     for k, fn in jobs.items():
         if not only or k in only:
             print("==", k)

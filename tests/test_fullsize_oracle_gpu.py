@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 pytestmark = pytest.mark.gpu
 
-TAGS = {1: "k_gemm_nt", 2: "k_gemm_nt8", 3: "k_gemm_p", 4: "k_gemm_ntq", 5: "k_conv3_direct", 6: "k_gemm_split2", 7: "k_gemm_geglu"}
+TAGS = {1: "k_gemm_nt", 2: "k_gemm_nt8", 3: "k_gemm_p", 4: "k_gemm_ntq", 5: "k_conv3_direct", 6: "k_gemm_split2", 7: "k_gemm_br"}
 REP = 50                                                    # the oracle's guidance pair x 50 = the 100 rows of a DDIM step
 
 
@@ -189,17 +189,18 @@ def test_quantised_output_epilogues_codes_at_production_rows(world):
             d_ = Lq.N // a1.heads
             i8 = (eng.fused_attention and eng.attention_i8_scores and ops.attention_i8qk_ok(a1.heads, d_, N, N))
             qq, qk, qv = (world["oquant"][bname + ".attn1.act_quantizer_" + s] for s in "qkv")
+            # the three projections the way Engine.ldm_cross_attn issues them: ONE grouped launch (k_gemm_br) where the shape
+            # allows (the 32 x 32 and 16 x 16 levels), else one launch each (k_gemm_ntq / k_gemm_nt)
+            qm = 2 if i8 else 1
+            q_, k_, vh = launch(lambda: eng._gemm_group([(Lq, oq, qm, eng._aq(a1.act_quantizer_q)[0], 0),
+                                                         (Lk, ok, qm, eng._aq(a1.act_quantizer_k)[0], 0),
+                                                         (Lv, ov, 1, eng._aq(a1.act_quantizer_v)[0], N)], M))
             if i8:
-                q8 = launch(lambda: eng._gemm(Lq, oq, M, out_mode=2, oqp=eng._aq(a1.act_quantizer_q)[0]))
-                k8 = launch(lambda: eng._gemm(Lk, ok, M, out_mode=2, oqp=eng._aq(a1.act_quantizer_k)[0]))
-                check(bname + ".to_q(i8)", q8.float() + 128.0, _codes(qq, out_q))
-                check(bname + ".to_k(i8)", k8.float() + 128.0, _codes(qk, out_k))
+                check(bname + ".to_q(i8)", q_.float() + 128.0, _codes(qq, out_q))
+                check(bname + ".to_k(i8)", k_.float() + 128.0, _codes(qk, out_k))
             else:
-                qh = launch(lambda: eng._gemm(Lq, oq, M, out_mode=1, oqp=eng._aq(a1.act_quantizer_q)[0]))
-                kh = launch(lambda: eng._gemm(Lk, ok, M, out_mode=1, oqp=eng._aq(a1.act_quantizer_k)[0]))
-                check(bname + ".to_q(f16)", qh.float() + float(qq.zero_point), _codes(qq, out_q))
-                check(bname + ".to_k(f16)", kh.float() + float(qk.zero_point), _codes(qk, out_k))
-            vh = launch(lambda: eng._gemm(Lv, ov, M, out_mode=1, oqp=eng._aq(a1.act_quantizer_v)[0], rpb=N))
+                check(bname + ".to_q(f16)", q_.float() + float(qq.zero_point), _codes(qq, out_q))
+                check(bname + ".to_k(f16)", k_.float() + float(qk.zero_point), _codes(qk, out_k))
             check(bname + ".to_v(f16)", vh.float() + float(qv.zero_point), _codes(qv, out_v))
             # GEGLU: ff.net.0.proj's epilogue emits ff.net.2's operand
             ff0, ff2 = blk.ff.net[0].proj, blk.ff.net[2]
@@ -208,7 +209,7 @@ def test_quantised_output_epilogues_codes_at_production_rows(world):
             x2, out2 = rec[bname + ".ff.net.2"][0]
             assert getattr(L0, "geglu_interleaved", False)
             of = eng._quant(L0, _rep(x0).reshape(-1, C).cuda())
-            gcodes = launch(lambda: eng._gemm(L0, of, M, out_mode=3, oqp=L2.qp))
+            (gcodes,) = launch(lambda: eng._gemm_group([(L0, of, 3, L2.qp, 0)], M))
             o2 = world["olayers"][bname + ".ff.net.2"]
             check(bname + ".geglu", gcodes.float() + 128.0, _codes(o2.act_quantizer, x2))
             # ff.net.2 + residual -> proj_out's operand
@@ -226,8 +227,10 @@ def test_quantised_output_epilogues_codes_at_production_rows(world):
     print("quantised-output epilogues at %d rows: %d codes, %d off by one (%.2e), none by more" % (2 * REP, tot, off1, off1 / max(tot, 1)))
     print("   kernel structures:", seen)
     assert tot > 5e6
-    assert seen.get("k_gemm_ntq", 0) > 0 and (seen.get("k_gemm_p", 0) + seen.get("k_gemm_geglu", 0)) > 0, seen
-    assert calls.get("edadm_qgemm_i8_q", 0) >= 5 * len(_tblock_names(world))
+    # the weight-resident grouped kernel took the q / k / v and GEGLU launches of the 384- and 576-wide levels, the persistent 4-wave
+    # kernel ff.net.2 (+ residual) and the 960-wide level
+    assert seen.get("k_gemm_ntq", 0) > 0 and seen.get("k_gemm_br", 0) >= 10, seen
+    assert calls.get("edadm_qgemm_i8_grouped_q", 0) >= 10 and calls.get("edadm_qgemm_i8_q", 0) >= len(_tblock_names(world))
 
 
 def test_transformer_blocks_on_the_oracle_inputs_at_production_rows(world):

@@ -383,3 +383,68 @@ def test_split_quantiser_layer_in_one_launch_bit_identical_to_two(M, N, K1, K2):
     ref = (A[:64, :K1].double() @ W1.double().t()) * s1.double() + bias.double() + (A[:64, K1:].double() @ W2.double().t()) * s2.double()
     one = ops.qgemm_i8_split2(A, W1, W2, M, N, K1, K2, s1, s2, bias, torch.empty(M, N, device="cuda"))
     assert float((one[:64].double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("M,K,specs", [
+    (65536, 384, [(384, 2), (384, 2), (384, 1)]),            # q / k / v of the 32 x 32 self-attention: int8, int8, f16 codes
+    (25600, 576, [(576, 1), (576, 1), (576, 4)]),            # the 16 x 16 level: f16 codes, v transposed per image
+    (16384, 384, [(3072, 3)]),                               # GEGLU projection 384 -> 3072 (pairs), 256 CUs x uneven row shares
+    (12800, 576, [(4608, 3)]),                               # GEGLU projection 576 -> 4608: 240 of the 256 workgroups
+    (32768, 384, [(384, 1), (192, 2), (576, 4), (192, 3)]),  # four problems of different widths and all four output forms
+    (102400, 384, [(3072, 3)]),                              # the production shape of the 32 x 32 GEGLU projection
+])
+def test_grouped_weight_resident_kernel_bit_identical_to_separate_launches(ops, M, K, specs):
+    """k_gemm_br (csrc/gemm.hip, edadm_qgemm_i8_grouped_q): the problems of one launch -- each with its OWN int8 operand, weights,
+    scales, output form and consuming quantiser (the q / k / v QuantModules of ldm/modules/attention.py:168-176 keep separate input
+    quantisers, quant_layer.py:406-437) -- give the bytes of one edadm_qgemm_i8_q launch each (k_gemm_ntq / k_gemm_p / k_gemm_nt:
+    integer accumulation, the same register-direct epilogue)."""
+    from edadm import lib
+    g = torch.Generator().manual_seed(M // 128 + K + 7 * len(specs))
+    assert ops.qgemm_i8_grouped_q_ok(M, sum(n for n, _ in specs), K)
+    probs, refs = [], []
+    for i, (N, mode) in enumerate(specs):
+        a = torch.randint(-128, 128, (M, K), generator=g, dtype=torch.int8).cuda()
+        w = torch.randint(-8, 9, (N, K), generator=g, dtype=torch.int8).cuda()
+        scale = (torch.rand(N, generator=g) * 2e-3 + 1e-4).cuda()
+        bias = torch.randn(N, generator=g).cuda() if i != 1 else None
+        oqp = ops.qp_tensor([(0.03 + 0.004 * i, 117.0 + i, 255.0)], torch.device("cuda"))
+        rpb = 1024 if mode == 4 else 0
+        probs.append(dict(A=a, W=w, N=N, scale=scale, bias=bias, out_mode=mode, oqp=oqp, rows_per_batch=rpb))
+        refs.append(ops.qgemm_i8_q(a, w, M, N, K, scale, bias, mode, oqp, rows_per_batch=rpb or 1))
+    import ctypes as _ct
+    lib.load().edadm_diag_launch_kernels((_ct.c_int32 * 8)())       # forget the reference launches' tags
+    lib.CALLS = {}
+    try:
+        outs = ops.qgemm_i8_grouped_q(probs, M, K)
+        calls = dict(lib.CALLS)
+    finally:
+        lib.CALLS = None
+    assert calls == {"edadm_qgemm_i8_grouped_q": 1}
+    import ctypes
+    buf = (ctypes.c_int32 * 8)()
+    n = lib.load().edadm_diag_launch_kernels(buf)
+    assert n >= 1 and buf[n - 1] == 7                       # launch tag 7 = k_gemm_br
+    ops.device_status()                                     # a hand-off that never arrived would raise here
+    for o, r in zip(outs, refs):
+        assert o.shape == r.shape and o.dtype == r.dtype and torch.equal(o, r)
+        assert float(o.float().abs().sum()) > 0
+    # the launch again (hand-off words start from zero every launch; nothing carried over)
+    again = ops.qgemm_i8_grouped_q(probs, M, K)
+    assert all(torch.equal(x, y) for x, y in zip(again, refs))
+
+
+def test_grouped_kernel_rejects_what_it_cannot_take(ops):
+    from edadm import lib
+    a = torch.zeros(1024, 384, dtype=torch.int8, device="cuda")
+    w = torch.zeros(192, 384, dtype=torch.int8, device="cuda")
+    s = torch.ones(192, device="cuda")
+    oqp = ops.qp_tensor([(0.03, 117.0, 255.0)], torch.device("cuda"))
+    assert not ops.qgemm_i8_grouped_q_ok(1024, 192, 384)          # too few tiles to fill the chip
+    assert not ops.qgemm_i8_grouped_q_ok(102400, 3072, 960)       # the weight block does not fit LDS
+    assert not ops.qgemm_i8_grouped_q_ok(102400, 3000, 384)
+    with pytest.raises(lib.EdadmError):
+        ops.qgemm_i8_grouped_q([dict(A=a, W=w, N=192, scale=s, bias=None, out_mode=2, oqp=oqp)], 1000, 384)
+    with pytest.raises(lib.EdadmError):
+        ops.qgemm_i8_grouped_q([dict(A=a, W=w, N=192, scale=s, bias=None, out_mode=0, oqp=oqp)], 1024, 384)
+    with pytest.raises(lib.EdadmError):
+        ops.qgemm_i8_grouped_q([dict(A=a, W=w, N=192, scale=s, bias=None, out_mode=2, oqp=oqp)], 1024, 448)

@@ -26,7 +26,7 @@ for _ in range(2):
 torch.cuda.synchronize()
 extra = 0
 if os.environ.get("LAUNCH_LIST"):
-    TAGS = {1: "k_gemm_nt", 2: "k_gemm_nt8", 3: "k_gemm_p", 4: "k_gemm_ntq", 5: "k_conv3_direct", 6: "k_gemm_split2", 7: "k_gemm_geglu"}
+    TAGS = {1: "k_gemm_nt", 2: "k_gemm_nt8", 3: "k_gemm_p", 4: "k_gemm_ntq", 5: "k_conv3_direct", 6: "k_gemm_split2", 7: "k_gemm_br"}
     eng.prof = []
     eng(x, t, c)
     prof, eng.prof = eng.prof, None
