@@ -506,7 +506,14 @@ __device__ __forceinline__ void gemm_epilogue_direct(typename Acc<DT>::type (&ac
 // behind a store) keep 32 KB per CU in flight at two workgroups per CU: ff.net.2 + residual 141.7 -> 139.2 us at 102400 x 384 x
 // 1536, 70.2 -> 66.7 at 25600 x 576 x 2304, 45.3 -> 43.5 at 6400 x 960 x 3840 (tools/gemm_table.py, same codes).  The
 // 168-register persistent kernel keeps RD = 1 (it has no register to spare).
-template <int DT, int TM, int TN, int BN, int RA, int RD = 1>
+// MODES: bit m set = output mode m may occur (a kernel that knows its launch's modes instantiates those bodies only: each body hoists
+// its own address arithmetic out of a persistent kernel's tile loop, and with all four the 168-register kernels spill ~60 registers
+// that are then RELOADED BEHIND the epilogue's stores -- vmcnt retires in order, so every reload waits out a store round trip)
+// WIDE (GEGLU, no residual): the exactness test covers the four pairs of TWO register groups instead of two pairs of one.  Each test is
+// a real branch, i.e. a basic-block boundary the scheduler does not cross: with two pairs per block the ~28 dependent vector
+// instructions of a pair run nearly back to back (a lone wave issues a dependent VALU instruction every ~6 cycles); four pairs per
+// block interleave.  Same codes: a group redone the exact way gives every element the code the fast path proved for it.
+template <int DT, int TM, int TN, int BN, int RA, int RD = 1, int MODES = 0x1e, bool WIDE = false>
 __device__ __forceinline__ void gemm_epilogue_qdirect(typename Acc<DT>::type (&acc)[TM][TN], const float* ec, int lane,
                                                       int64_t row0, int64_t col0, int ecol0, void* __restrict__ outv,
                                                       int64_t ldo, int out_mode, const float* __restrict__ residual = nullptr,
@@ -555,6 +562,32 @@ __device__ __forceinline__ void gemm_epilogue_qdirect(typename Acc<DT>::type (&a
             for (int i = 0; i < TM; ++i) {
                 uint32_t pk[4][2];                          // packed words per register group g (f16: 2 words, else 1)
                 const int64_t ro = rbase + (int64_t)(i * 32) * ldo;
+                if constexpr (MODE == 3 && WIDE) {
+#pragma unroll
+                    for (int g = 0; g < 4; g += 2) {
+                        float va[4], ga[4];
+#pragma unroll
+                        for (int h2 = 0; h2 < 2; ++h2) {
+                            const float4 s4 = s4n, b4 = b4n;
+                            const int qc = (j * TM + i) * 4 + g + h2;
+                            if (qc + 1 < QN) const_pair(qc + 1, s4n, b4n);
+                            float v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) asm volatile("v_cvt_f32_i32 %0, %1" : "=v"(v[e]) : "v"(acc[i][j][4 * (g + h2) + e]));
+                            va[2 * h2] = fmaf(v[0], s4.x, b4.x); ga[2 * h2] = fmaf(v[1], s4.y, b4.y);
+                            va[2 * h2 + 1] = fmaf(v[2], s4.z, b4.z); ga[2 * h2 + 1] = fmaf(v[3], s4.w, b4.w);
+                        }
+                        float r[4];
+                        geglu_codes_n<4>(va, ga, od, oi, oz, r);
+#pragma unroll
+                        for (int h2 = 0; h2 < 2; ++h2) {
+                            uint32_t w = 0;
+                            w = __builtin_amdgcn_cvt_pk_u8_f32(clampf(r[2 * h2], 0.f, oq), 0, w);
+                            w = __builtin_amdgcn_cvt_pk_u8_f32(clampf(r[2 * h2 + 1], 0.f, oq), 1, w);
+                            pk[g + h2][0] = w ^ 0x8080u;
+                        }
+                    }
+                } else
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const float4 s4 = s4n, b4 = b4n;
@@ -656,10 +689,18 @@ __device__ __forceinline__ void gemm_epilogue_qdirect(typename Acc<DT>::type (&a
             }
         }
     };
-    if (out_mode == 1) body(std::integral_constant<int, 1>{});
-    else if (out_mode == 2) body(std::integral_constant<int, 2>{});
-    else if (out_mode == 4) body(std::integral_constant<int, 4>{});
-    else body(std::integral_constant<int, 3>{});
+    constexpr bool single = (MODES & (MODES - 1)) == 0;
+    if constexpr (single) {
+        if constexpr (MODES == 2) body(std::integral_constant<int, 1>{});
+        else if constexpr (MODES == 4) body(std::integral_constant<int, 2>{});
+        else if constexpr (MODES == 8) body(std::integral_constant<int, 3>{});
+        else body(std::integral_constant<int, 4>{});
+    } else {
+        if ((MODES & 2) && out_mode == 1) body(std::integral_constant<int, 1>{});
+        else if ((MODES & 4) && out_mode == 2) body(std::integral_constant<int, 2>{});
+        else if ((MODES & 16) && out_mode == 4) body(std::integral_constant<int, 4>{});
+        else if constexpr ((MODES & 8) != 0) body(std::integral_constant<int, 3>{});
+    }
 }
 
 // Source rows for everything that is not real data (convolution padding, M/N/K tails): row v holds
@@ -1907,7 +1948,7 @@ struct BrArgs {
     int count, ncb, wpc, mt;               // problems, column blocks in all, workgroups per column block, 128-row tiles
 };
 
-template <int TN, int NK>
+template <int TN, int NK, int MODES>              // MODES: bit m set = some problem of the launch has output mode m (those epilogue bodies only)
 __global__ void __launch_bounds__(768)
 k_gemm_br(const BrArgs a) {
     constexpr int BN = 64 * TN, GM = 128;
@@ -1915,17 +1956,27 @@ k_gemm_br(const BrArgs a) {
     constexpr int ASLOT = GM * 64;                         // one K-step of a group's 128 activation rows
     constexpr int ECN = 2 * BN + 4;
     constexpr int SA_ROOM = (160 * 1024 - BBYTES - ECN * 4 - 256) / ASLOT;
-    constexpr int SA = SA_ROOM > 12 ? 12 : SA_ROOM;        // ring slots
-    constexpr int DEPTH = 4;                               // K-steps a loader wave keeps in flight
-    static_assert(SA >= DEPTH + 2, "ring too short for the loader's depth");
-    constexpr int SMEM_BYTES = BBYTES + SA * ASLOT + ECN * 4 + (2 * SA + 2) * 4;
+    // every consumer group has a ring of its OWN (round 6, first form: one FIFO ring for both groups -- a group in its epilogue held
+    // the head of the queue and the other group's next tile could not be fetched past it: 248 us on the 384-deep GEGLU layer, the MFMA
+    // phase of a tile 8.7 k cycles, 5.9 k of them waiting)
+    constexpr int SG = SA_ROOM / 2 > NK ? NK : SA_ROOM / 2;  // slots per group: up to a whole tile ahead
+#ifndef EDADM_BR_DEPTH
+#define EDADM_BR_DEPTH 3
+#endif
+    constexpr int DEPTH = EDADM_BR_DEPTH;                  // K-steps a loader wave keeps in flight
+    static_assert(SG >= 3 && DEPTH >= 1 && DEPTH <= 6, "ring too short");
+    constexpr int SMEM_BYTES = BBYTES + 2 * SG * ASLOT + ECN * 4 + 20 * 4;
     __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM_BYTES];
     uint8_t* Bres = smem;
     uint8_t* Aring = smem + BBYTES;
-    float* ec = reinterpret_cast<float*>(smem + BBYTES + SA * ASLOT);
-    int* full_w = reinterpret_cast<int*>(smem + BBYTES + SA * ASLOT + ECN * 4);
-    int* free_w = full_w + SA;
-    int* ready_w = free_w + SA;
+    float* ec = reinterpret_cast<float*>(smem + BBYTES + 2 * SG * ASLOT);
+    // hand-off: monotonic step counters, one word per WAVE -- pub_w[g][lw] = steps of group g loader wave lw has published,
+    // con_w[g][w] = steps MFMA wave w of group g has consumed; a reader takes the minimum over the four words (one 16-byte LDS read).
+    // (A sum over the four waves is not enough: a loader wave running ahead would vouch for a step a slower one has not landed.)  Both
+    // sides keep the last minimum they read and go back to LDS only when it does not cover what they need.
+    int* pub_w = reinterpret_cast<int*>(smem + BBYTES + 2 * SG * ASLOT + ECN * 4);      // [2][4]
+    int* con_w = pub_w + 8;                                                              // [2][4]
+    int* ready_w = pub_w + 16;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1946,15 +1997,16 @@ k_gemm_br(const BrArgs a) {
     const int64_t n0 = (int64_t)(cb - P.cb0) * BN;
     const int u0 = (int)((int64_t)a.mt * wi / a.wpc), u1 = (int)((int64_t)a.mt * (wi + 1) / a.wpc);
     const int nu = u1 - u0;
-    const int G = nu * NK;                                  // K-steps this workgroup streams
-    if (tid < 2 * SA + 2) full_w[tid] = 0;
+    if (tid < 20) pub_w[tid] = (tid < 8 && (tid & 2)) ? 0x3fffffff : 0;      // two loader waves per group: the other two words never bind
     __syncthreads();
     bool dead = false;
+    auto peek = [&](int* word) {
+        return __builtin_amdgcn_readfirstlane(__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+    };
     auto wait_at_least = [&](int* word, int target) {
         if (dead) return;
         for (int spins = 0;; ++spins) {
-            const int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
-            if (v >= target) return;
+            if (peek(word) >= target) return;
             if (spins > (1 << 22)) {
                 dead = true;
                 if (lane == 0) atomicOr(&g_error_word, 2u);
@@ -1966,11 +2018,26 @@ k_gemm_br(const BrArgs a) {
     auto signal = [&](int* word) {
         if (lane == 0) __hip_atomic_fetch_add(word, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
+    auto publish = [&](int* word, int value) {              // this wave's own counter: a plain release store
+        if (lane == 0) __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
+    auto min4 = [&](int* w4) {                              // minimum of four counters, one 16-byte LDS read
+        v4i v;
+        const uint32_t addr = lds0 + (uint32_t)(reinterpret_cast<uint8_t*>(w4) - smem);
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+        const int m01 = v.x < v.y ? v.x : v.y, m23 = v.z < v.w ? v.z : v.w;
+        return __builtin_amdgcn_readfirstlane(m01 < m23 ? m01 : m23);
+    };
 
     if (wave >= 8) {
         // ------------------------------------------------------------------ loader waves
         const int lw = wave - 8, ltid = tid - 512;
+        // The loader waves are the youngest of their SIMDs, and the two MFMA waves beside each spend most of their time in a
+        // VALU-dense epilogue: at equal priority the loader's handful of vector instructions per step (source addresses, the LDS
+        // words) get the leftover issue slots only and the stream starves.  Highest priority for them costs the others nothing
+        // measurable: ~10 vector instructions per K-step.
+        __builtin_amdgcn_s_setprio(3);
         // a 1-KiB piece is 16 rows x 64 bytes, lane-linear in LDS: lane l lands at row l / 4, physical chunk l % 4, and fetches the
         // logical chunk (l % 4) ^ ((row >> 2) & 3) -- the swizzle of the fragment reads, applied to the source
         const int prow = lane >> 2;
@@ -1992,37 +2059,64 @@ k_gemm_br(const BrArgs a) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         signal(ready_w);
-        // the activation stream: step gs = (unit gs / NK, K-step gs % NK) -> ring slot gs % SA; this wave's two pieces are rows
-        // [32 lw, 32 lw + 32) of the unit's 128
-        const uint8_t* arow = P.A + (int64_t)(lw * 32 + prow) * P.lda + sc * 16;
-        int unit = 0, kk = 0, slot = 0, use = 0;           // of the next step to issue; use = gs / SA
-        int s_slot = 0;                                     // slot of the next step to publish
-        auto issue = [&]() {
-            if (use > 0) wait_at_least(free_w + slot, 4 * use);
-            const uint8_t* src = arow + (int64_t)(u0 + unit) * GM * P.lda + kk * 64;
-            const uint32_t dst = lds0 + (uint32_t)(BBYTES + slot * ASLOT + lw * 2048);
-            glds16(src, dst);
-            glds16(src + 16 * P.lda, dst + 1024);
-            if (++kk == NK) { kk = 0; ++unit; }
-            if (++slot == SA) { slot = 0; ++use; }
-        };
-        auto publish = [&]() {
-            signal(full_w + s_slot);
-            if (++s_slot == SA) s_slot = 0;
-        };
-        int gi = 0;
-        for (; gi < G && gi < DEPTH - 1; ++gi) issue();
-        for (; gi < G; ++gi) {
-            issue();
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (DEPTH - 1)) : "memory");   // the oldest step in flight has landed
-            publish();
+        // The activation stream.  Loader waves 0, 1 serve consumer group 0 and waves 2, 3 group 1 (its tiles are the workgroup's units
+        // g, g + 2, ...): a wave brings rows [64 h, 64 h + 64) of each of its group's K-steps (four 1-KiB pieces) into slot
+        // (step % SG) of that group's ring, keeps DEPTH steps in flight and publishes a step when its pieces have landed (vmcnt retires
+        // in issue order).  When the ring is full it first publishes everything in flight, then waits for the group to free a slot --
+        // a loop with one branch per step (a scheduler that picked among both rings per step cost ~1500 cycles per step in scalar
+        // bookkeeping and starved the MFMA waves).
+        const int g = lw >> 1, h = lw & 1;
+        const int total = ((nu + 1 - g) >> 1) * NK;         // steps of this wave's group
+        // source = wave-uniform pointer (SGPR pair) + a fixed per-lane byte offset: no vector arithmetic per step
+        const int64_t lda = uniform_i64(P.lda);
+        const uint32_t voff = (uint32_t)(prow * (int)lda + sc * 16);
+        const uint8_t* src = P.A + ((int64_t)(u0 + g) * GM + h * 64) * lda;      // first K-step of the group's first tile
+        const int64_t tile_adv = 2 * GM * lda - (int64_t)NK * 64;                 // from past the last K-step of a tile to the next tile
+        const uint32_t ring0 = lds0 + (uint32_t)(BBYTES + g * SG * ASLOT + h * 4096);
+        int* mypub = pub_w + 4 * g + h;                     // two loader waves per group: words 0, 1 (2, 3 stay at "infinity")
+        int seen = 0, slot = 0, kk = 0, fly = 0, done = 0;  // consumed steps known; slot / K-step of the next issue; in flight; published
+#ifdef EDADM_STAMPS
+        unsigned long long l_idle = 0, l_vm = 0, l_steps = 0, l_issue = 0, l_poll = 0;
+        const unsigned long long l_t0 = __builtin_amdgcn_s_memtime();
+#endif
+        for (int step = 0; step < total && !dead; ++step) {
+            if (step - seen >= SG) {
+                // ring full as far as this wave knows: everything in flight lands and is published, then wait for room
+                STAMP(lp0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (fly) { done += fly; fly = 0; publish(mypub, done); }
+                for (int spins = 0; !dead; ++spins) {
+                    seen = min4(con_w + 4 * g);
+                    if (step - seen < SG) break;
+                    if (spins > (1 << 22)) {
+                        dead = true;
+                        if (lane == 0) atomicOr(&g_error_word, 2u);
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+#ifdef EDADM_STAMPS
+                { STAMP(lp1); l_poll += lp1 - lp0; }
+#endif
+            }
+            const uint32_t dst = ring0 + (uint32_t)(slot * ASLOT);
+            glds16_s(src, voff, dst);
+            glds16_s(src + 16 * lda, voff, dst + 1024);
+            glds16_s(src + 32 * lda, voff, dst + 2048);
+            glds16_s(src + 48 * lda, voff, dst + 3072);
+            src += 64;
+            if (++kk == NK) { kk = 0; src += tile_adv; }
+            if (++slot == SG) slot = 0;
+            if (++fly == DEPTH) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (DEPTH - 1)) : "memory");   // the oldest step in flight has landed
+                --fly;
+                publish(mypub, ++done);
+            }
         }
-        // drain: the last min(G, DEPTH - 1) steps
-        const int tail = G < DEPTH - 1 ? G : DEPTH - 1;
-        if (tail >= 3) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); publish(); }
-        if (tail >= 2) { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); publish(); }
-        if (tail >= 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); publish(); }
-        static_assert(DEPTH == 4, "the drain above is written for three steps in flight");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (fly) publish(mypub, done + fly);
+#ifdef EDADM_STAMPS
+        (void)l_idle; (void)l_vm; (void)l_steps; (void)l_issue; (void)l_poll; (void)l_t0;
+#endif
         return;
     }
 
@@ -2061,30 +2155,80 @@ k_gemm_br(const BrArgs a) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) mma_step<0>(fb[j], fa[i], acc[i][j]);      // swapped: a lane owns an output row
     };
-    for (int li = grp; li < nu; li += 2) {
-        int gs = li * NK;
-        int slot = gs % SA, use = gs / SA;
-        wait_at_least(full_w + slot, 4 * (use + 1));
-        rd(Aring + slot * ASLOT, Bres, 0, fa0, fb0);
-#pragma unroll
-        for (int kk = 0; kk < NK; ++kk) {
-            const uint8_t* As = Aring + slot * ASLOT;
-            rd(As, Bres + kk * (BN * 64), 1, fa1, fb1);
-            mm(fa0, fb0);
-            const int pslot = slot;
-            if (kk + 1 < NK) {
-                if (++slot == SA) { slot = 0; ++use; }
-                wait_at_least(full_w + slot, 4 * (use + 1));
-                rd(Aring + slot * ASLOT, Bres + (kk + 1) * (BN * 64), 0, fa0, fb0);
+    uint8_t* ring = Aring + grp * SG * ASLOT;
+    int* pubg = pub_w + 4 * grp;
+    int* cong = con_w + 4 * grp + wq;
+    // A workgroup serves ONE problem, so its output mode never changes: the tile loop is instantiated per mode and chosen once (one
+    // epilogue body per loop -- see MODES at gemm_epilogue_qdirect: with several bodies inside one loop their hoisted invariants spill).
+    auto run = [&](auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+#ifdef EDADM_STAMPS
+        unsigned long long m_wait = 0, m_comp = 0, m_epi = 0, m_n = 0;
+#endif
+        int slot = 0, step = 0;                             // ring slot and running number of the group's next step
+        int have = 0;                                       // steps of this group known to be published (pub_w / 4 as last read)
+        auto need = [&](int upto) {                         // steps [0, upto) published?  LDS is asked only when `have` does not say so
+            if (have >= upto) return;
+#ifdef EDADM_STAMPS
+            STAMP(tw0);
+#endif
+            for (int spins = 0; !dead; ++spins) {
+                have = min4(pubg);
+                if (have >= upto) break;
+                if (spins > (1 << 22)) {
+                    dead = true;
+                    if (lane == 0) atomicOr(&g_error_word, 2u);
+                }
+                __builtin_amdgcn_s_sleep(1);
             }
-            mm(fa1, fb1);
-            signal(free_w + pslot);                         // release: this step's fragments are in registers
+#ifdef EDADM_STAMPS
+            { STAMP(tw1); m_wait += tw1 - tw0; }
+#endif
+        };
+        for (int li = grp; li < nu; li += 2) {
+            STAMP(ts1);
+            // matrix phase above the SIMD partner's epilogue: its fragment addresses and hand-off words are few, and every cycle the
+            // matrix pipe waits for them is lost; the epilogue runs at the base priority
+            __builtin_amdgcn_s_setprio(2);
+            need(step + 1);
+            rd(ring + slot * ASLOT, Bres, 0, fa0, fb0);
+#pragma unroll
+            for (int kk = 0; kk < NK; ++kk) {
+                const uint8_t* As = ring + slot * ASLOT;
+                if (++slot == SG) slot = 0;
+                ++step;
+                rd(As, Bres + kk * (BN * 64), 1, fa1, fb1);
+                mm(fa0, fb0);
+                if (kk + 1 < NK) {
+                    need(step + 1);
+                    rd(ring + slot * ASLOT, Bres + (kk + 1) * (BN * 64), 0, fa0, fb0);
+                }
+                mm(fa1, fb1);
+                publish(cong, step);                        // release: this step's fragments are in registers
+            }
+            // epilogues: the older wave of a SIMD (group 0) wins every arbitration at equal priority and group 1 ran 27 % longer per tile
+            // (16.7 k against 13.1 k cycles, tools/gemm_br_bench.py --stamps); the two take turns at priority 1 instead
+            if (((li >> 1) ^ grp) & 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+            STAMP(ts2);
+            const int64_t m0 = (int64_t)(u0 + li) * GM;
+            gemm_epilogue_qdirect<0, 2, TN, BN, 0, 1, (1 << MODE), true>(acc, ec, lane, m0 + wm * 64, n0 + wn * (TN * 32), wn * (TN * 32),
+                                                                         P.out, P.ldo, MODE, nullptr, 0, P.rpb, P.N);
+            zero_acc();
+#ifdef EDADM_STAMPS
+            { asm volatile("s_nop 0" ::: "memory"); STAMP(ts3); m_comp += ts2 - ts1; m_epi += ts3 - ts2; ++m_n; }
+#endif
         }
-        const int64_t m0 = (int64_t)(u0 + li) * GM;
-        gemm_epilogue_qdirect<0, 2, TN, BN, 0, 1>(acc, ec, lane, m0 + wm * 64, n0 + wn * (TN * 32), wn * (TN * 32), P.out, P.ldo,
-                                                  P.out_mode, nullptr, 0, P.rpb, P.N);
-        zero_acc();
-    }
+#ifdef EDADM_STAMPS
+        if (wave == 0) { STAMP_ADD(0, m_wait); STAMP_ADD(1, m_comp); STAMP_ADD(2, m_epi); STAMP_ADD(3, m_n); }
+        if (wave == 4) { STAMP_ADD(4, m_wait); STAMP_ADD(5, m_comp); STAMP_ADD(6, m_epi); STAMP_ADD(7, m_n); }
+#endif
+    };
+    const int om = __builtin_amdgcn_readfirstlane(P.out_mode);
+    if ((MODES & 2) && om == 1) run(std::integral_constant<int, 1>{});
+    else if ((MODES & 4) && om == 2) run(std::integral_constant<int, 2>{});
+    else if ((MODES & 16) && om == 4) run(std::integral_constant<int, 4>{});
+    else if constexpr ((MODES & 8) != 0) run(std::integral_constant<int, 3>{});
 }
 #endif
 
@@ -3066,8 +3210,22 @@ extern "C" int edadm_qgemm_i8_grouped_q(const edadm_gemm_problem* probs, int cou
     if (wpc > mt) wpc = mt;
     a.count = count; a.ncb = ncb; a.wpc = wpc; a.mt = mt;
     launch_tag(7);
-    if (K == 384) hipLaunchKernelGGL((k_gemm_br<3, 6>), dim3((unsigned)(ncb * wpc)), dim3(768), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((k_gemm_br<3, 9>), dim3((unsigned)(ncb * wpc)), dim3(768), 0, (hipStream_t)stream, a);
+    int modes = 0;
+    for (int i = 0; i < count; ++i) modes |= 1 << probs[i].out_mode;
+    const dim3 grid((unsigned)(ncb * wpc));
+    // the mode sets of the engine's launches get kernels with exactly their epilogue bodies; anything else the general one
+#define EDADM_BR_CASE(NK_, MODES_)                                                                     \
+    if (K == 64 * NK_ && modes == MODES_) {                                                            \
+        hipLaunchKernelGGL((k_gemm_br<3, NK_, MODES_>), grid, dim3(768), 0, (hipStream_t)stream, a);   \
+        return edadm_launch_status();                                                                  \
+    }
+    EDADM_BR_CASE(6, 8)  EDADM_BR_CASE(9, 8)          // GEGLU
+    EDADM_BR_CASE(6, 6)  EDADM_BR_CASE(9, 6)          // q, k int8 codes, v f16 codes (int8-score attention)
+    EDADM_BR_CASE(6, 2)  EDADM_BR_CASE(9, 2)          // f16 codes
+    EDADM_BR_CASE(6, 18) EDADM_BR_CASE(9, 18)         // f16 codes, v transposed per image
+#undef EDADM_BR_CASE
+    if (K == 384) hipLaunchKernelGGL((k_gemm_br<3, 6, 0x1e>), grid, dim3(768), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((k_gemm_br<3, 9, 0x1e>), grid, dim3(768), 0, (hipStream_t)stream, a);
     return edadm_launch_status();
 }
 #endif

@@ -444,7 +444,8 @@ def test_grouped_kernel_rejects_what_it_cannot_take(ops):
     assert not ops.qgemm_i8_grouped_q_ok(102400, 3000, 384)
     with pytest.raises(lib.EdadmError):
         ops.qgemm_i8_grouped_q([dict(A=a, W=w, N=192, scale=s, bias=None, out_mode=2, oqp=oqp)], 1000, 384)
+    bad = dict(A=a, W=w, N=192, scale=s, bias=None, out_mode=2, oqp=oqp, lda=380)      # rows not 16-byte aligned
     with pytest.raises(lib.EdadmError):
-        ops.qgemm_i8_grouped_q([dict(A=a, W=w, N=192, scale=s, bias=None, out_mode=0, oqp=oqp)], 1024, 384)
+        ops.qgemm_i8_grouped_q([bad], 1024, 384)
     with pytest.raises(lib.EdadmError):
         ops.qgemm_i8_grouped_q([dict(A=a, W=w, N=192, scale=s, bias=None, out_mode=2, oqp=oqp)], 1024, 448)

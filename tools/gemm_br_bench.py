@@ -24,6 +24,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--json", default=None)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--stamps", action="store_true", help="EDADM_LIB_PATH points at the stamps build: print k_gemm_br's in-kernel stamps")
     args = ap.parse_args()
     from edadm import ops
     dev = torch.device("cuda", 0)
@@ -53,9 +54,10 @@ def main():
         for i, (N, mode) in enumerate(specs):
             a = torch.randint(-128, 128, (M, K), generator=g, dtype=torch.int8).to(dev)
             w = torch.randint(-8, 9, (N, K), generator=g, dtype=torch.int8).to(dev)
-            scale = (torch.rand(N, generator=g) * 2e-3 + 1e-4).to(dev)
-            bias = torch.randn(N, generator=g).to(dev)
-            oqp = ops.qp_tensor([(0.03, 117.0, 255.0)], dev)
+            # scaled like a real layer: pre-activations of unit size, a step size that leaves the exact-division branch rare
+            scale = (1.5e-4 * (0.5 + torch.rand(N, generator=g))).to(dev)
+            bias = (0.1 * torch.randn(N, generator=g)).to(dev)
+            oqp = ops.qp_tensor([(0.02, 128.0, 255.0)], dev)
             probs.append(dict(A=a, W=w, N=N, scale=scale, bias=bias, out_mode=mode, oqp=oqp, rows_per_batch=256 if mode == 4 else 0))
         sep = lambda: [ops.qgemm_i8_q(p["A"], p["W"], M, p["N"], K, p["scale"], p["bias"], p["out_mode"], p["oqp"],
                                       rows_per_batch=p["rows_per_batch"] or 1) for p in probs]
@@ -67,6 +69,19 @@ def main():
              "separate_us_cold": timed(sep, True), "grouped_us_cold": timed(grp, True)}
         r["grouped_TOPs_warm"] = flop / r["grouped_us_warm"] / 1e6
         r["mfma_roof_us"] = flop / 5033e12 * 1e6
+        if args.stamps:
+            import ctypes
+            from edadm import lib
+            L = lib.load()
+            buf = (ctypes.c_ulonglong * 8)()
+            grp(); torch.cuda.synchronize(); L.edadm_dbg_read(buf)
+            grp(); torch.cuda.synchronize(); L.edadm_dbg_read(buf)
+            n0, n1 = max(buf[3], 1), max(buf[7], 1)
+            r["stamps"] = {"group0_wave0": {"tiles": int(buf[3]), "waiting": buf[0] / n0, "mfma_phase": buf[1] / n0, "epilogue": buf[2] / n0},
+                           "group1_wave4": {"tiles": int(buf[7]), "waiting": buf[4] / n1, "mfma_phase": buf[5] / n1, "epilogue": buf[6] / n1}}
+            print("   stamps (cycles per tile; waits are inside the MFMA phase): group 0 wave 0: waiting %.0f, MFMA phase %.0f, epilogue %.0f (%d tiles) | "
+                  "group 1 wave 4: waiting %.0f, MFMA phase %.0f, epilogue %.0f (%d tiles)"
+                  % (buf[0] / n0, buf[1] / n0, buf[2] / n0, buf[3], buf[4] / n1, buf[5] / n1, buf[6] / n1, buf[7]), flush=True)
         rows.append(r)
         print("%-26s M %6d K %3d  separate %7.1f / %7.1f us   grouped %7.1f / %7.1f us (warm / cold)  %.0f TOP/s  roof %.0f us  same bits: %s"
               % (name, M, K, r["separate_us_warm"], r["separate_us_cold"], r["grouped_us_warm"], r["grouped_us_cold"],
