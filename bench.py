@@ -575,7 +575,7 @@ def main():
     torch.cuda.synchronize()
     unet_ms = ev0.elapsed_time(ev1)
 
-    # HBM bytes per launch of the dominant kernel group from the committed rocprofv3 --pmc passes (tools/prof_round.sh step 2).  The
+    # HBM bytes per launch of the dominant kernel group from the committed rocprofv3 --pmc passes (tools/prof_round6.sh step 2).  The
     # file names the sources it was measured on (sha256 of csrc/gemm.hip); a file of another build is NOT used: traffic = null
     traffic, traffic_src = None, None
     import hashlib
@@ -785,11 +785,11 @@ def main():
                 calib_out["multi_rank"] = {
                     "ranks": world,
                     "sharded_stages": "TDAC trajectory batches (one gather of the calibration latents), activation caching of every unit "
-                                      "(one gather per cached slab), and the reconstruction iterations of the units with >= 1024 positions "
-                                      "per row (64 x 64 and 32 x 32 levels: the 32-row minibatch split over the ranks, partial gradient slabs "
+                                      "(one gather per cached slab), and the reconstruction iterations of EVERY unit -- block or single layer -- with >= 1024 "
+                                      "positions per row (64 x 64 and 32 x 32 levels: the 32-row minibatch split over the ranks, partial gradient slabs "
                                       "all-gathered and added in rank order, SURVEY 8e(2))",
                     "replicated_stages": "scale initialisation (the activation ranges are an EMA over the batch sequence), the iterations of the "
-                                         "16 x 16 / 8 x 8 / single-layer units (launch-latency bound), per-unit set-up",
+                                         "units below 1024 positions per row (16 x 16 / 8 x 8 levels, time-embedding layers: launch-latency bound), per-unit set-up",
                     "sharded_s_this_run": sharded, "of_which_data_parallel_loop_s": dp_loop, "replicated_s_this_run": rest,
                     # what N ranks can gain at best with this split: the stages of THIS run, sharded ones divided by N / this N
                     "ceiling": {str(n): (rest + sharded * world) / (rest + sharded * world / n) for n in (1, 2, 4, 8)},

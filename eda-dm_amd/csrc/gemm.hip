@@ -1836,7 +1836,11 @@ k_gemm_p(const uint8_t* __restrict__ A, int64_t lda_b, const uint8_t* __restrict
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
     };
     zero_acc();
-    auto run = [&](auto swp) {
+    // mode_tag: the launch's output mode as a compile-time constant -- ONE quantising epilogue body inside the tile loop (with the four
+    // of a run-time dispatch the loop's hoisted invariants spill ~44 registers, reloaded behind the epilogue's stores: see MODES at
+    // gemm_epilogue_qdirect)
+    auto run = [&](auto swp, auto mode_tag) {
+        constexpr int QMODE = decltype(mode_tag)::value;
         int kk = 0, T = 0;
 #ifdef EDADM_STAMPS
         unsigned long long m_bar = 0, m_comp = 0, m_epi = 0;
@@ -1883,8 +1887,9 @@ k_gemm_p(const uint8_t* __restrict__ A, int64_t lda_b, const uint8_t* __restrict
                 const int64_t m0 = (int64_t)mt * BM, n0 = (int64_t)nt * BN;
                 const float* ec = ec_all + (T % 3) * ECN;
                 if constexpr (decltype(swp)::value) {
-                    gemm_epilogue_qdirect<DT, TM, TN, BN, RA>(acc, ec, lane, m0 + wm * 64, n0 + wn * (TN * 32), wn * (TN * 32), out,
-                                                              ldo, out_mode, residual, ldr, rows_per_batch, N);
+                    gemm_epilogue_qdirect<DT, TM, TN, BN, RA, 1, (QMODE ? (1 << QMODE) : 0x1e)>(acc, ec, lane, m0 + wm * 64, n0 + wn * (TN * 32),
+                                                                                                wn * (TN * 32), out, ldo, out_mode, residual, ldr,
+                                                                                                rows_per_batch, N);
                 } else {
                     EpiRegs<TN> er;
                     load_epi_regs<TN, BN>(er, ec, lane, m0, m0 + wm * 64, wn * (TN * 32), rows_per_batch);
@@ -1903,8 +1908,11 @@ k_gemm_p(const uint8_t* __restrict__ A, int64_t lda_b, const uint8_t* __restrict
         if (wave == 0) { STAMP_ADD(0, m_bar); STAMP_ADD(1, m_comp); STAMP_ADD(2, m_epi); STAMP_ADD(3, 1); }
 #endif
     };
-    if (out_mode != 0) run(std::true_type{});
-    else run(std::false_type{});
+    if (out_mode == 0) run(std::false_type{}, std::integral_constant<int, 0>{});
+    else if (out_mode == 1) run(std::true_type{}, std::integral_constant<int, 1>{});
+    else if (out_mode == 2) run(std::true_type{}, std::integral_constant<int, 2>{});
+    else if (out_mode == 3) run(std::true_type{}, std::integral_constant<int, 3>{});
+    else run(std::true_type{}, std::integral_constant<int, 4>{});
 }
 
 #if defined(EDADM_STAMPS) && EDADM_GEMM_DT == 0

@@ -131,6 +131,11 @@ class Engine:
         for name, m in self.net.named_modules():
             if isinstance(m, QuantModule):
                 self.layers[id(m)] = FrozenLayer(m, name)
+            if type(m).__name__ == "QKVAttention":
+                # openaimodel.py:413-444: no shipped configuration uses it and the reference's hooks do not quantise it; the executor
+                # has no graph for the q | k | v-before-heads order and must not run it on stock operators behind the caller's back
+                raise NotImplementedError("use_new_attention_order (QKVAttention at %s): the int8 executor implements the legacy "
+                                          "attention order only" % name)
         self._attn_cache = {}
         # Fusions / shortcuts of the executor.  Each gives the same bits as its plain form (tests flip these attributes to show
         # it); they are attributes, not environment switches: the product has ONE configuration.

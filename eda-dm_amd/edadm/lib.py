@@ -67,12 +67,22 @@ def load():
 # tests / tools: a dict here counts the entry points that run (name -> calls), e.g. to assert which contraction kernels a
 # reconstruction unit actually took
 CALLS = None
+# diagnostic (tools/prof_elementwise.sh): EDADM_TRACE_BYTES=<path> installs edadm/trace_bytes.py's hook here -- algorithmic bytes per
+# entry point, joined with rocprofv3 counters of the same process by tools/elementwise_hbm.py
+TRACE_HOOK = None
 
 
 def call(name, *args):
     """Invoke an int-returning entry point; non-zero status raises."""
     if CALLS is not None:
         CALLS[name] = CALLS.get(name, 0) + 1
+    if TRACE_HOOK is not None:
+        TRACE_HOOK(name, args)
     rc = getattr(load(), name)(*args)
     if rc != 0:
         raise EdadmError("%s failed with status %d" % (name, rc))
+
+
+if os.environ.get("EDADM_TRACE_BYTES"):
+    from . import trace_bytes as _tb
+    _tb.install(os.environ["EDADM_TRACE_BYTES"])

@@ -373,6 +373,12 @@ class QKVAttentionLegacy(nn.Module):
 
 
 class QKVAttention(nn.Module):
+    """The new attention order (q | k | v split BEFORE the heads, openaimodel.py:413-444).  No shipped configuration sets
+    `use_new_attention_order`, the reference's quantisation hooks wrap QKVAttentionLegacy only (quant_block.py:119-162), and the int8
+    executor has no graph for it -- so the products run on the library's kernels (T.bmm_nt / T.softmax, the same operators the legacy
+    class uses, differentiable for the reconstruction loop) and the frozen engine refuses the module (edadm/engine.py) rather than
+    falling back to stock torch operators silently."""
+
     def __init__(self, n_heads):
         super().__init__()
         self.n_heads = n_heads
@@ -382,10 +388,10 @@ class QKVAttention(nn.Module):
         ch = width // (3 * self.n_heads)
         q, k, v = qkv.chunk(3, dim=1)
         scale = 1 / math.sqrt(math.sqrt(ch))
-        w = torch.einsum("bct,bcs->bts", (q * scale).view(bs * self.n_heads, ch, length),
-                         (k * scale).view(bs * self.n_heads, ch, length))
-        w = torch.softmax(w.float(), dim=-1).type(w.dtype)
-        return torch.einsum("bts,bcs->bct", w, v.reshape(bs * self.n_heads, ch, length)).reshape(bs, -1, length)
+        q = (q * scale).reshape(bs * self.n_heads, ch, length)
+        k = (k * scale).reshape(bs * self.n_heads, ch, length)
+        w = T.softmax(T.bmm_nt(T.transpose12(q), T.transpose12(k)))              # einsum("bct,bcs->bts")
+        return T.bmm_nt(v.reshape(bs * self.n_heads, ch, length), w).reshape(bs, -1, length)   # einsum("bts,bcs->bct")
 
 
 class AttentionBlock(nn.Module):

@@ -1741,7 +1741,9 @@ def g20_f16x3_units(threads=None, fname="g20_f16x3_units", input_ulp=False, iter
         d["input_scale"] = np.float32(1 + int(input_ulp) * 2.0 ** -23)
     if fp64:
         torch.set_default_dtype(torch.float32)
-        d = {k: (v.double().numpy() if torch.is_tensor(v) else v) for k, v in d.items() if k.startswith("grad0/")}
+        keep = ("grad0/",) if fp64 is True else ("grad0/", "final/res/", "final/tf/", "first/")
+        d = {k: (v.double().numpy() if torch.is_tensor(v) else v) for k, v in d.items()
+             if k.startswith(keep) and not k.startswith("final/qp")}
         d["dtype"] = np.array("float64")
     save(fname, d)
 
@@ -1778,13 +1780,20 @@ def g20_fp64_truth():
     g20_f16x3_units(fname="g20_reference_fp64", iters=1, fp64=True)
 
 
+def g20_fp64_full():
+    """... and the whole 12-iteration run in float64 (same draws, masks, scales): every alpha's first-step direction and final hard
+    rounding as exact arithmetic gives them.  The reference's fp32 run and the product are both compared with THIS in index space
+    (tests/test_fullsize_gpu.py): the count by which the reference's own fp32 run misses the exact roundings is the yardstick."""
+    g20_f16x3_units(fname="g20_reference_fp64_full", fp64="full")
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     jobs = dict(g1=g1_weight_init, g2=g2_act_init, g3=g3_uaq_forward, g4=g4_adaround, g5=g5_loss,
                 g6=g6_quant_module, g7=g7_blocks, g8=g8_g12_recon, g9=g9_tdac, g10=g10_steps,
                 g13c=g13_cifar_unet, g13i=lambda: g13_ldm_unet("imagenet"), g13h=lambda: g13_ldm_unet("church"), g14=g14_plms, g15=g15_decoder,
                 g17=g17_tdac_imagenet, g7b=g7b_blocks, g13w8=lambda: g13_cifar_unet(8, "g13_cifar_w8", 1301), g13sd=g13_ldm_sd, g16=g16_layer_recon,
-                g8b=g8b_recon_masks, g8c=g8c_recon_caches, g18=g18_church_driver, g19=g19_tdac_others, g1b=g1b_max_init, g20=g20_f16x3_units, g20n=g20_noise_floor, g20u=g20_ulp_floor, g20u32=g20_ulp32_floor, g20f64=g20_fp64_truth)
+                g8b=g8b_recon_masks, g8c=g8c_recon_caches, g18=g18_church_driver, g19=g19_tdac_others, g1b=g1b_max_init, g20=g20_f16x3_units, g20n=g20_noise_floor, g20u=g20_ulp_floor, g20u32=g20_ulp32_floor, g20f64=g20_fp64_truth, g20f64full=g20_fp64_full)
     for k, fn in jobs.items():
         if not only or k in only:
             print("==", k)

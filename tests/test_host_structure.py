@@ -172,3 +172,15 @@ def test_attention_step_sizes_trained_by_the_right_walk(golden):
     qc = _wrap(golden("g13_cifar_unet"), "cifar")
     ab = [m for m in qc.modules() if isinstance(m, QuantAttnBlock)]
     assert len(_attention_quantizers(ab[0], control=True)) == 4 and len(_attention_quantizers(ab[0], control=False)) == 4
+
+
+def test_new_attention_order_is_refused_by_the_executor_and_uses_library_operators():
+    """openaimodel.py:413-444 (`use_new_attention_order`): not shipped, not quantised by the reference's hooks.  The module's products go
+    through the library's operators (edadm.train_ops), never torch.einsum / torch.softmax, and the frozen engine refuses the network."""
+    import inspect
+    from edadm.nets import ldm_unet
+    src = inspect.getsource(ldm_unet.QKVAttention)
+    assert "torch.einsum" not in src and "torch.softmax" not in src and "T.bmm_nt" in src and "T.softmax" in src
+    from edadm import engine
+    eng_src = inspect.getsource(engine)
+    assert 'type(m).__name__ == "QKVAttention"' in eng_src and "NotImplementedError" in eng_src
