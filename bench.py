@@ -267,6 +267,43 @@ def full_calibration(dev):
     return r
 
 
+def rank_rows_ceiling(full, st, dp_loop, rest, world):
+    """The multi-rank ceiling with the data-parallel iterations priced at what a rank's SMALLER minibatch costs, not at 1 / N of the
+    32-row iteration: profiles/*_rank_rows.json (tools/rank_rows.py, committed) holds the measured ms per iteration of the data-parallel
+    unit classes at 32 / 16 / 8 / 4 rows on ONE GPU; each eligible unit of THIS run is scaled by the ratio of its class (by positions per
+    row, transformer block or not).  The per-iteration gather is priced, not measured (no multi-GPU node): <= 12 MB per rank over one
+    xGMI link at 153 GB/s + 45 us of latency and graph A / gather / graph B hand-off."""
+    if world != 1:
+        return {}
+    try:
+        names = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_rank_rows.json"))
+        with open(os.path.join(ROOT, "profiles", names[-1])) as fh:
+            rr = json.load(fh)["classes"]
+    except Exception:
+        return {}
+    import edadm.recon as er
+    iters = full.get("iters_per_unit", 1000)
+    out = {}
+    for n in (1, 2, 4, 8):
+        rows = str(32 // n)
+        t_dp = 0.0
+        n_dp_iters = 0
+        for u in full.get("per_unit_ms", []):
+            if not u["data_parallel_eligible"]:
+                continue
+            pos = u["positions_per_row"]
+            cls = ("tf@1024" if "transformer_blocks" in u["unit"] else ("res@4096" if pos >= 4096 else "res@1024"))
+            ratio = rr.get(cls, rr["res@1024"])["ratio_to_32_rows"][rows]
+            t_dp += u["ms_per_iteration"] * 1e-3 * (iters - 1) * ratio
+            n_dp_iters += iters if n > 1 else 0
+        gather = n_dp_iters * (12e6 / 153e9 + 45e-6)
+        wall = rest + (st["tdac_s"] + st["caching_s"]) / n + t_dp + gather
+        out[str(n)] = full["wall_s"] / wall
+    return {"ceiling_measured_rows": out,
+            "ceiling_measured_rows_source": "profiles/%s: per-rank iteration cost measured at 32 / N rows on one GPU; gather priced at one xGMI "
+                                            "link (12 MB / 153 GB/s + 45 us); still no N > 1 hardware number" % names[-1]}
+
+
 def time_h1_contraction(dev):
     """H1's dominant contraction on its own: the 3x3 192->192 convolution of the 64x64 level at the reconstruction batch
     (32 rows), forward, on both contraction paths, timed with events on the launch stream.  fp32-equivalent rate =
@@ -767,7 +804,26 @@ def main():
                 torch.cuda.empty_cache()
                 if world > 1:
                     dist.barrier()
-                full = full_calibration(dev)
+                try:
+                    full = full_calibration(dev)
+                except torch.OutOfMemoryError as oom:
+                    # the job peaks near 210 of the 288 GB and the allocator's fragmentation decides whether the last 2.5 GB slab fits:
+                    # ONE retry (single rank only: the ranks of a sharded job must agree) from an empty cache with the cache budgets at
+                    # 60 % -- more FP sweeps, the same result; the line says so
+                    if world > 1:
+                        raise
+                    sys.stderr.write("calibration: out of memory (%s); retrying once with the cache budgets at 60 %%\n" % str(oom)[:200])
+                    import qdiff.data_utils as du
+                    import edadm.recon as er
+                    gc.collect()
+                    torch.cuda.empty_cache()
+                    keep = du.FP_TRACE_GB, du.Q_MEMO_GB, er.FP_FEAT_GB
+                    du.FP_TRACE_GB, du.Q_MEMO_GB, er.FP_FEAT_GB = 0.6 * keep[0], 0.6 * keep[1], 0.6 * keep[2]
+                    try:
+                        full = full_calibration(dev)
+                    finally:
+                        du.FP_TRACE_GB, du.Q_MEMO_GB, er.FP_FEAT_GB = keep
+                    full["retried_after_oom_with_budgets_at"] = 0.6
                 if world > 1:
                     dist.barrier()
                     tt = torch.tensor([full["wall_s"]] + [full["stages"][k] for k in ("tdac_s", "scale_init_s", "caching_s", "loop_s")],
@@ -793,6 +849,7 @@ def main():
                     "sharded_s_this_run": sharded, "of_which_data_parallel_loop_s": dp_loop, "replicated_s_this_run": rest,
                     # what N ranks can gain at best with this split: the stages of THIS run, sharded ones divided by N / this N
                     "ceiling": {str(n): (rest + sharded * world) / (rest + sharded * world / n) for n in (1, 2, 4, 8)},
+                    **rank_rows_ceiling(full, st, dp_loop, rest, world),
                     "ceiling_note": "speed-up over one rank if the sharded stages scaled perfectly, from the per-stage / per-unit seconds "
                                     "measured in THIS run (collectives and the smaller per-rank kernels' efficiency not priced: an upper "
                                     "bound); no multi-GPU node was available to this build -- the N-rank path is exercised by the "

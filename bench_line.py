@@ -75,7 +75,7 @@ def compact(line):
         out["cpu_baseline"] = _pick(cb, _CPU)
     cal = line.get("calibration")
     if cal:
-        c = _pick(cal, ("value_s", "units", "calib_samples", "iters_per_unit", "peak_hbm_gb", "graphed_units", "error"))
+        c = _pick(cal, ("value_s", "units", "calib_samples", "iters_per_unit", "peak_hbm_gb", "graphed_units", "retried_after_oom_with_budgets_at", "error"))
         if cal.get("stages"):
             c["stages"] = {k: _num(v) for k, v in cal["stages"].items()}
         h1 = cal.get("h1_roofline")

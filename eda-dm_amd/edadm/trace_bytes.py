@@ -32,8 +32,16 @@ FORMULAS = {
     "edadm_adaround_bwd": lambda a: 16 * _v(a[6]) * _v(a[7]),
     # K5 (GroupNorm + SiLU / LayerNorm + the consumers' quantisers)
     "edadm_groupnorm_stats": lambda a: 4 * _v(a[3]) * _v(a[4]) * _v(a[5]),
+    "edadm_groupnorm_stats_cat": lambda a: 4 * _v(a[6]) * _v(a[7]) * (_v(a[1]) + _v(a[3]) * _has(a[2])),
+    # *_rep: x2 holds B2 images read periodically -- each of its bytes counted once
+    "edadm_groupnorm_stats_cat_rep": lambda a: 4 * _v(a[7]) * (_v(a[6]) * _v(a[1]) + (_v(a[10]) or _v(a[6])) * _v(a[3]) * _has(a[2])),
+    # (edadm_groupnorm_final_cat*: reduce the producers' partial sums -- kilobytes; their launches are listed with the statistics group)
     "edadm_groupnorm_apply": lambda a: _v(a[5]) * _v(a[6]) * _v(a[7]) * (4 + 4 * _has(a[10]) + _has(a[11]) + _has(a[12]) + _has(a[13])),
     "edadm_groupnorm_apply_cat": lambda a: _v(a[8]) * _v(a[9]) * (_v(a[1]) + _v(a[3])) * (4 + 4 * _has(a[12]) + _has(a[13]) + _has(a[14]) + _has(a[15])),
+    # ... _raw: one more int8 output (the un-normalised input quantised for the skip convolution); x2 may hold B2 < B images
+    "edadm_groupnorm_apply_cat_raw": lambda a: _v(a[8]) * _v(a[9]) * (_v(a[1]) + _v(a[3])) * (4 + 4 * _has(a[12]) + _has(a[13]) + _has(a[14]) + _has(a[15]) + _has(a[18])),
+    "edadm_quant_i8_cat": lambda a: 5 * _v(a[5]) * (_v(a[1]) + _v(a[3]) * _has(a[2])),
+    "edadm_quant_i8_cat_rep": lambda a: 5 * _v(a[5]) * (_v(a[1]) + _v(a[3]) * _has(a[2])),
     "edadm_layernorm_quant": lambda a: _v(a[3]) * _v(a[4]) * (4 + 4 * _has(a[6]) + _has(a[7]) + _has(a[8]) + _has(a[9])),
     "edadm_layernorm_quant_radd": lambda a: _v(a[8]) * (4 * _v(a[1]) + _v(a[7]) * (4 * _has(a[4]) + _has(a[10]) + _has(a[11]) + _has(a[12]))),
     "edadm_quant_i8": lambda a: 5 * _v(a[2]) * _v(a[3]),
@@ -58,7 +66,9 @@ FORMULAS = {
     # K11's re-formatting passes (operand expansion of the three-product contraction)
     "edadm_absmax_parts": lambda a: 4 * _v(a[1]),
     "edadm_split_f16": lambda a: 8 * _v(a[1]) * _v(a[2]) * _v(a[3]),
-    "edadm_transpose_split_f16": lambda a: 8 * _v(a[1]) * _v(a[2]) * _v(a[3]),
+    # in [R][C] fp32 -> [C][R] as f16 (hi, lo) pairs; with a convolution geometry the [R][C] matrix is the im2col of an NHWC tensor gathered on
+    # the fly (3x3 in every such layer of the path): the tensor is read once, the nine-fold matrix written
+    "edadm_transpose_split_f16": lambda a: (4 * _v(a[1]) * _v(a[2]) // 9 + 4 * _v(a[1]) * _v(a[2])) if _has(a[5]) else 8 * _v(a[1]) * _v(a[2]),
 }
 
 TOTALS = {}

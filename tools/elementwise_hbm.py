@@ -19,10 +19,12 @@ GROUPS = [
     ("K1", "fake-quant backward + d delta partial sums", ["edadm_fake_quant_bwd"], [r"\bk_fq_bwd\b"]),
     ("K2", "AdaRound soft/hard weights forward (adaptive_rounding.py:49-61)", ["edadm_adaround_fwd"], [r"\bk_ar_fwd\b"]),
     ("K2", "AdaRound d alpha", ["edadm_adaround_bwd"], [r"\bk_ar_bwd\b"]),
-    ("K5", "GroupNorm statistics (sampling)", ["edadm_groupnorm_stats"], [r"\bk_gn_partial\b", r"\bk_gn_final\b"]),
-    ("K5", "GroupNorm apply + SiLU + int8 operands (sampling)", ["edadm_groupnorm_apply", "edadm_groupnorm_apply_cat"], [r"\bk_gn_apply16\b", r"\bk_gn_apply\b"]),
+    ("K5", "GroupNorm statistics (sampling): reduces the producers' epilogue partials, no pass over x", ["edadm_groupnorm_stats", "edadm_groupnorm_stats_cat", "edadm_groupnorm_stats_cat_rep"],
+     [r"\bk_gn_partial\b", r"\bk_gn_final\b"]),
+    ("K5", "GroupNorm apply + SiLU + int8 operands (sampling)", ["edadm_groupnorm_apply", "edadm_groupnorm_apply_cat", "edadm_groupnorm_apply_cat_raw"],
+     [r"\bk_gn_apply16\b", r"\bk_gn_apply\b"]),
     ("K5", "LayerNorm + int8 operands (sampling)", ["edadm_layernorm_quant", "edadm_layernorm_quant_radd"], [r"\bk_ln_quant_v4\b", r"\bk_ln_quant\b"]),
-    ("K5", "stand-alone activation quantiser", ["edadm_quant_i8"], [r"\bk_quant_i8\b"]),
+    ("K5", "stand-alone activation quantiser", ["edadm_quant_i8", "edadm_quant_i8_cat", "edadm_quant_i8_cat_rep"], [r"\bk_quant_i8\b"]),
     ("K7", "lp loss forward", ["edadm_lp_loss_fwd"], [r"\bk_lp_fwd\b"]),
     ("K7", "lp loss backward / per-module gradient injection", ["edadm_lp_loss_bwd", "edadm_lp_loss_inject"], [r"\bk_lp_bwd\b", r"\bk_lp_inject\b"]),
     ("K8", "Adam + cosine step (block_recon.py:199-206)", ["edadm_adam_step"], [r"\bk_adam\b"]),
