@@ -1,5 +1,6 @@
 """README.md = docs/README.template.md with its @@KEY@@ fields filled from a bench line (the driver-format JSON that `python bench.py`
-prints): the numbers in the README are regenerated, not hand-edited.      python tools/readme_numbers.py profiles/r05z_bench_line.json"""
+writes next to its printed line, bench_detail.json): the numbers in the README are regenerated, not hand-edited.
+    python tools/readme_numbers.py profiles/r06z_bench_detail.json"""
 import json
 import os
 import sys
@@ -17,6 +18,8 @@ f = {
     "CEIL": "%.2f / %.2f / %.2f x" % (ce["2"], ce["4"], ce["8"]), "CPU": "%.4f" % d["cpu_baseline"]["value"],
     "CPUIT": "%.2f" % c["cpu_baseline"]["value"], "CIFAR": "%.0f" % cfg["cifar"]["images_per_sec"],
     "CHURCH": "%.1f" % cfg["church"]["images_per_sec_at_500_steps"], "SD": "%.2f" % cfg["sd"]["images_per_sec"],
+    "ONE": "%.1f" % d["one_batch_in_flight"]["value"], "ONE_S": "%.1f" % d["one_batch_in_flight"]["sampling_only"],
+    "CEILM": "%.2f / %.2f / %.2f x" % tuple(c["multi_rank"].get("ceiling_measured_rows", ce)[k] for k in ("2", "4", "8")),
 }
 text = open(os.path.join(ROOT, "docs", "README.template.md")).read()
 for k, v in f.items():
