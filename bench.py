@@ -782,6 +782,13 @@ def main():
         # A rank that fails inside the job skips the collectives the others are blocked in.  It cannot tell them, so it leaves with a
         # non-zero status (below) and the launcher tears the group down; rank 0 answers the launcher's SIGTERM by printing the line
         # it has -- sampling numbers plus calibration.error -- and leaves non-zero too: no rank exits 0 after a failed job.
+        # ... and, because a rank blocked inside a collective or a stream synchronisation never reaches a Python-level signal handler before
+        # the launcher escalates to SIGKILL, rank 0 prints the line it has NOW (sampling numbers, no calibration yet): whatever happens
+        # to the job below, the driver finds a parseable last line; a job that completes prints the full line after it.
+        if rank == 0:
+            line["calibration"]["status"] = "multi-rank job started; this line was printed before it"
+            emit(line)
+            line["calibration"].pop("status", None)
         import signal
 
         def _torn_down(signum, frame):

@@ -2238,6 +2238,164 @@ k_gemm_br(const BrArgs a) {
     else if ((MODES & 16) && om == 4) run(std::integral_constant<int, 4>{});
     else if constexpr ((MODES & 8) != 0) run(std::integral_constant<int, 3>{});
 }
+
+// ---- k_gemm_bw: the weight-resident kernel with TWELVE INDEPENDENT MFMA waves and no loader waves (round 6, after k_gemm_br's
+// measurements: its bound is the rate at which ONE wave issues the ~28 vector instructions per output pair of its epilogue, two waves
+// per SIMD cannot hide that, and the 168-register budget left no room for a third consumer group beside dedicated loaders).  Here
+// every wave owns a 32-row x 192-column strip of outputs (TM = 1, TN = 6: the same 96 accumulator registers, the same 72 MFMAs per
+// strip), fetches ITS OWN 32 activation rows by LDS-DMA into a private ring of SG 2-KiB slots and consumes them itself: the only
+// hand-off is the wave's own vmcnt -- no FULL / FREE words, no polls, no partner.  Three waves per SIMD at different points of
+// their strips keep the matrix pipe and the vector ALU of the SIMD busy with each other's phases; strips are dealt dynamically from
+// an LDS counter.  The weight block and the epilogue are k_gemm_br's; the codes are identical bit for bit.
+template <int NK, int MODES>
+__global__ void __launch_bounds__(768)
+k_gemm_bw(const BrArgs a) {
+    constexpr int TN = 6, BN = 192, SR = 32, NW = 12;
+    constexpr int BBYTES = BN * NK * 64;
+    constexpr int ASLOT = SR * 64;                          // one K-step of a wave's 32 activation rows
+    constexpr int ECN = 2 * BN + 4;
+    constexpr int SG_ROOM = (160 * 1024 - BBYTES - ECN * 4 - 64) / (NW * ASLOT);
+    constexpr int SG = SG_ROOM > 3 ? 3 : SG_ROOM;           // ring slots per wave (vmcnt switch below: at most 2 younger steps)
+    static_assert(SG >= 2, "no room for the activation rings");
+    constexpr int SMEM_BYTES = BBYTES + NW * SG * ASLOT + ECN * 4 + 16;
+    __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM_BYTES];
+    uint8_t* Bres = smem;
+    float* ec = reinterpret_cast<float*>(smem + BBYTES + NW * SG * ASLOT);
+    int* next_w = reinterpret_cast<int*>(smem + BBYTES + NW * SG * ASLOT + ECN * 4);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned nwg = gridDim.x, wg = blockIdx.x;
+    unsigned logical = wg;
+    if (nwg >= 16) {
+        const unsigned k = wg & 7, j = wg >> 3, q = nwg >> 3, r = nwg & 7;
+        logical = k * q + (k < r ? k : r) + j;
+    }
+    const int cb = (int)(logical % (unsigned)a.ncb), wi = (int)(logical / (unsigned)a.ncb);
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (i < a.count && cb >= a.p[i].cb0) pi = i;
+    const BrProblem& P = a.p[pi];
+    const int64_t n0 = (int64_t)(cb - P.cb0) * BN;
+    const int ms = a.mt * 4;                                // 32-row strips of the launch (a.mt counts 128-row tiles)
+    const int s0 = (int)((int64_t)ms * wi / a.wpc), s1 = (int)((int64_t)ms * (wi + 1) / a.wpc);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
+    const int prow = lane >> 2;
+    const int sc = (lane & 3) ^ ((lane >> 4) & 3);
+    // prologue, all twelve waves: epilogue constants, the weight block, the strip counter
+    for (int idx = tid; idx < 2 * BN; idx += 768) {
+        const int c = idx < BN ? idx : idx - BN;
+        ec[idx] = idx < BN ? P.scale[n0 + c] : (P.bias ? P.bias[n0 + c] : 0.f);
+    }
+    if (tid < 3) ec[2 * BN + tid] = P.oqp[tid];
+    if (tid == 0) next_w[0] = s0 + NW;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    {
+        const uint8_t* wrow = P.W + (n0 + prow) * P.ldw + sc * 16;
+        for (int pc = wave; pc < NK * (BN / 16); pc += NW) {
+            const int kk = pc / (BN / 16), rb = pc - kk * (BN / 16);
+            glds16(wrow + (int64_t)rb * 16 * P.ldw + kk * 64, lds0 + (uint32_t)(kk * (BN * 64) + rb * 1024));
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                        // the only workgroup barrier of the kernel
+
+    const int fr = lane & 31, fh = lane >> 5;
+    const int64_t lda = uniform_i64(P.lda);
+    const uint32_t voff = (uint32_t)(prow * (int)lda + sc * 16);
+    const uint32_t ring0 = lds0 + (uint32_t)(BBYTES + wave * SG * ASLOT);
+    const uint8_t* ring = smem + BBYTES + wave * SG * ASLOT;
+    v16i acc[1][TN];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][j][r] = 0;
+    };
+    zero_acc();
+    int issued = 0, waited = 0;                             // K-steps this wave has requested / consumed, over all its strips
+    int slot_i = 0;                                         // ring slot of the next request
+    auto request = [&](int strip, int kk) {                 // rows [32 strip, +32) of the launch, K-step kk -> slot_i
+        const uint8_t* src = P.A + (int64_t)strip * SR * lda + kk * 64;
+        const uint32_t dst = ring0 + (uint32_t)(slot_i * ASLOT);
+        glds16_s(src, voff, dst);
+        glds16_s(src + 16 * lda, voff, dst + 1024);
+        ++issued;
+        if (++slot_i == SG) slot_i = 0;
+    };
+    auto landed = [&]() {                                   // the oldest requested step is in LDS (vmcnt retires in issue order; stores
+        const int younger = issued - waited - 1;            // of an epilogue in between only make the wait longer, never shorter)
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ++waited;
+    };
+    auto ticket = [&]() {
+        int t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add(next_w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return __builtin_amdgcn_readfirstlane(t);
+    };
+    auto run = [&](auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        int cur = s0 + wave;
+        if (cur >= s1) return;
+        int slot_r = 0;                                     // ring slot of the next step to read
+#pragma unroll
+        for (int kk = 0; kk < SG && kk < NK; ++kk) request(cur, kk);
+        while (true) {
+            int nxt = -1;
+#pragma unroll
+            for (int kk = 0; kk < NK; ++kk) {
+                landed();
+                const uint8_t* As = ring + slot_r * ASLOT;
+                const uint8_t* Bs = Bres + kk * (BN * 64);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int c = 2 * ks + fh;
+                    const uint4 fa = *reinterpret_cast<const uint4*>(As + (fr * 4 + (c ^ ((fr >> 2) & 3))) * 16);
+                    // the six weight fragments in two halves of three: 12 fragment registers live instead of 24 (the kernel sits at the
+                    // 168-register limit of three waves per SIMD)
+#pragma unroll
+                    for (int jh = 0; jh < TN; jh += 3) {
+                        uint4 fb[3];
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            const int r = (jh + j) * 32 + fr;
+                            fb[j] = *reinterpret_cast<const uint4*>(Bs + (r * 4 + (c ^ ((r >> 2) & 3))) * 16);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) mma_step<0>(fb[j], fa, acc[0][jh + j]);     // swapped: a lane owns an output row
+                        asm volatile("" ::: "memory");
+                    }
+                }
+                if (++slot_r == SG) slot_r = 0;
+                // the slot just read is free once its fragments are in registers (the MFMAs above needed them): refill it with the
+                // step SG ahead -- of this strip, or of the next one (its ticket is drawn here, SG steps before this strip ends)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (kk + SG < NK) {
+                    request(cur, kk + SG);
+                } else {
+                    if (kk + SG == NK) {
+                        nxt = ticket();
+                        if (nxt >= s1) nxt = -1;
+                    }
+                    if (nxt >= 0) request(nxt, kk + SG - NK);
+                }
+            }
+            gemm_epilogue_qdirect<0, 1, TN, BN, 0, 1, (1 << MODE), true>(acc, ec, lane, (int64_t)cur * SR, n0, 0, P.out, P.ldo, MODE, nullptr, 0,
+                                                                         P.rpb, P.N);
+            zero_acc();
+            if (nxt < 0) break;
+            cur = nxt;
+        }
+    };
+    const int om = __builtin_amdgcn_readfirstlane(P.out_mode);
+    if ((MODES & 2) && om == 1) run(std::integral_constant<int, 1>{});
+    else if ((MODES & 4) && om == 2) run(std::integral_constant<int, 2>{});
+    else if ((MODES & 16) && om == 4) run(std::integral_constant<int, 4>{});
+    else if constexpr ((MODES & 8) != 0) run(std::integral_constant<int, 3>{});
+}
 #endif
 
 template <int DT>
@@ -3227,6 +3385,20 @@ extern "C" int edadm_qgemm_i8_grouped_q(const edadm_gemm_problem* probs, int cou
         hipLaunchKernelGGL((k_gemm_br<3, NK_, MODES_>), grid, dim3(768), 0, (hipStream_t)stream, a);   \
         return edadm_launch_status();                                                                  \
     }
+    // The GEGLU projection at K = 384 takes the twelve-independent-wave form (k_gemm_bw: 224 against 245 us on 102400 x 3072 x 384,
+    // tools/gemm_br_bench.py); the q / k / v launches measured level on the two (112 against 105-110) and stay on k_gemm_br, as does
+    // K = 576 (its 108 KB weight block leaves two ring slots per wave)
+#ifndef EDADM_BW_DEFAULT
+#define EDADM_BW_DEFAULT 1
+#endif
+    static const int64_t use_bw = EDADM_TUNE_I("EDADM_GEMM_BW", EDADM_BW_DEFAULT);
+#define EDADM_BW_CASE(NK_, MODES_)                                                                     \
+    if (use_bw && K == 64 * NK_ && modes == MODES_) {                                                  \
+        hipLaunchKernelGGL((k_gemm_bw<NK_, MODES_>), grid, dim3(768), 0, (hipStream_t)stream, a);      \
+        return edadm_launch_status();                                                                  \
+    }
+    EDADM_BW_CASE(6, 8)
+#undef EDADM_BW_CASE
     EDADM_BR_CASE(6, 8)  EDADM_BR_CASE(9, 8)          // GEGLU
     EDADM_BR_CASE(6, 6)  EDADM_BR_CASE(9, 6)          // q, k int8 codes, v f16 codes (int8-score attention)
     EDADM_BR_CASE(6, 2)  EDADM_BR_CASE(9, 2)          // f16 codes

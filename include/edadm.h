@@ -300,8 +300,9 @@ int edadm_qgemm_i8_q(const int8_t* A, int64_t lda, const int8_t* Wt, int64_t ldw
  * [M][lda], integer weights W [N][ldw], per-column scale / bias, output, output mode (1..4 as above) and consuming quantiser oqp -- the
  * q / k / v projections of a self-attention (ldm/modules/attention.py:168-176; three QuantModules, quant_layer.py:406-437, whose input
  * quantisers may differ after reconstruction: three operands, not one), or one GEGLU projection (attention.py:37-45; count = 1).
- * Kernel k_gemm_br (csrc/gemm.hip): a workgroup keeps a 192-column weight block resident in LDS and streams the activation rows; two
- * groups of MFMA waves take alternate 128-row tiles so that one group's quantising epilogue overlaps the other's matrix work.  The
+ * Kernels k_gemm_br / k_gemm_bw (csrc/gemm.hip): a workgroup keeps a 192-column weight block resident in LDS and streams the
+ * activation rows; several MFMA waves per SIMD work on different row tiles so that one wave's quantising epilogue overlaps another's
+ * matrix work (br: two groups of four waves + loader waves; bw: twelve independent waves that fetch their own rows).  The
  * codes are those of `count` separate edadm_qgemm_i8_q launches, bit for bit.  Shapes: edadm_qgemm_i8_grouped_q_ok (M % 128 == 0,
  * every N % 192 == 0, K = 384 or 576, enough tiles to fill the chip); no rowadd, no residual.  `probs` is a HOST array (its fields are
  * copied into the launch). */

@@ -11,7 +11,7 @@ import csv, glob, hashlib, json, os, re, sys
 # kernel structure (tag of edadm_diag_launch_kernels) -> pattern of its int8 instantiations in a kernel trace
 PATTERNS = {
     "k_gemm_nt": r"\bk_gemm_nt<0,", "k_gemm_nt8": r"\bk_gemm_nt8<0,", "k_gemm_p": r"\bk_gemm_p<0,", "k_gemm_ntq": r"\bk_gemm_ntq<",
-    "k_conv3_direct": r"\bk_conv3_direct<0,", "k_gemm_split2": r"\bk_gemm_split2<", "k_gemm_br": r"\bk_gemm_br<",
+    "k_conv3_direct": r"\bk_conv3_direct<0,", "k_gemm_split2": r"\bk_gemm_split2<", "k_gemm_br": r"\bk_gemm_b[rw]<",
 }
 # the same templates on other operand types (f16 attention products, fp32 / three-product f16 calibration graph): not int8 layers
 # ... and the packed-nibble kernel of the few-row layers (launch-list type "w4": weights are its traffic, a group of its own)
