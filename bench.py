@@ -457,8 +457,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=3,
                     help="independent 50-image sample batches in flight per GPU (edadm.sampling.InFlightSampler: batch k on stream k mod n; "
-                         "measured 1 / 2 / 3 / 4 in flight: 94.9 / 105.2-107.4 / 108.0-109.0 / 107.4 decoded, 116.7 / 136.2 / 133.0-136.9 / 135.5 "
-                         "sampling-only images/s)")
+                         "measured 1 / 2 / 3 / 4 / 5 in flight, round 6: 97.5 / 108.4 / 110.3-111.9 / 110.6 / 108.3 decoded, 120.5 / 141.9 / 140.8-141.3 / "
+                         "140.3 / 138.5 sampling-only images/s)")
     ap.add_argument("--calib", choices=["full", "bounded", "none"], default=None,
                     help="full (default at N = 1): the whole calibration job at the shipped size, measured (~8 min); with N > 1 every rank runs "
                          "it (TDAC and activation caching sharded) and the line carries the max-over-ranks wall-clock -- not the default there, "
