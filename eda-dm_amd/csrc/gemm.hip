@@ -43,6 +43,9 @@
 #ifndef EDADM_GEMM_STAGES
 #define EDADM_GEMM_STAGES 3
 #endif
+#ifndef EDADM_BW_DEFAULT
+#define EDADM_BW_DEFAULT 1
+#endif
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
@@ -2247,15 +2250,17 @@ k_gemm_br(const BrArgs a) {
 // hand-off is the wave's own vmcnt -- no FULL / FREE words, no polls, no partner.  Three waves per SIMD at different points of
 // their strips keep the matrix pipe and the vector ALU of the SIMD busy with each other's phases; strips are dealt dynamically from
 // an LDS counter.  The weight block and the epilogue are k_gemm_br's; the codes are identical bit for bit.
-template <int NK, int MODES>
-__global__ void __launch_bounds__(768)
+// TN: 32-column blocks of a strip -- 6 (192 columns: the weight block of k_gemm_br) or 4 (128 columns: 64 accumulator registers, no spill at the
+// 168-register limit, and a smaller weight block that leaves room for a fourth ring slot)
+template <int NK, int MODES, int TN, int NW = 12>      // NW: waves per workgroup (12: three per SIMD, 168 registers; 16: four, 128)
+__global__ void __launch_bounds__(64 * NW)
 k_gemm_bw(const BrArgs a) {
-    constexpr int TN = 6, BN = 192, SR = 32, NW = 12;
+    constexpr int BN = 32 * TN, SR = 32;
     constexpr int BBYTES = BN * NK * 64;
     constexpr int ASLOT = SR * 64;                          // one K-step of a wave's 32 activation rows
     constexpr int ECN = 2 * BN + 4;
     constexpr int SG_ROOM = (160 * 1024 - BBYTES - ECN * 4 - 64) / (NW * ASLOT);
-    constexpr int SG = SG_ROOM > 3 ? 3 : SG_ROOM;           // ring slots per wave (vmcnt switch below: at most 2 younger steps)
+    constexpr int SG = SG_ROOM > 4 ? 4 : SG_ROOM;           // ring slots per wave (vmcnt switch below: at most 3 younger steps)
     static_assert(SG >= 2, "no room for the activation rings");
     constexpr int SMEM_BYTES = BBYTES + NW * SG * ASLOT + ECN * 4 + 16;
     __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM_BYTES];
@@ -2284,7 +2289,7 @@ k_gemm_bw(const BrArgs a) {
     const int prow = lane >> 2;
     const int sc = (lane & 3) ^ ((lane >> 4) & 3);
     // prologue, all twelve waves: epilogue constants, the weight block, the strip counter
-    for (int idx = tid; idx < 2 * BN; idx += 768) {
+    for (int idx = tid; idx < 2 * BN; idx += 64 * NW) {
         const int c = idx < BN ? idx : idx - BN;
         ec[idx] = idx < BN ? P.scale[n0 + c] : (P.bias ? P.bias[n0 + c] : 0.f);
     }
@@ -2326,7 +2331,8 @@ k_gemm_bw(const BrArgs a) {
     };
     auto landed = [&]() {                                   // the oldest requested step is in LDS (vmcnt retires in issue order; stores
         const int younger = issued - waited - 1;            // of an epilogue in between only make the wait longer, never shorter)
-        if (younger >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (younger >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (younger == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else if (younger == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ++waited;
@@ -2354,18 +2360,19 @@ k_gemm_bw(const BrArgs a) {
                 for (int ks = 0; ks < 2; ++ks) {
                     const int c = 2 * ks + fh;
                     const uint4 fa = *reinterpret_cast<const uint4*>(As + (fr * 4 + (c ^ ((fr >> 2) & 3))) * 16);
-                    // the six weight fragments in two halves of three: 12 fragment registers live instead of 24 (the kernel sits at the
+                    // the weight fragments in two halves: half the fragment registers live (the kernel sits at the
                     // 168-register limit of three waves per SIMD)
+                    constexpr int HN = TN / 2;
 #pragma unroll
-                    for (int jh = 0; jh < TN; jh += 3) {
-                        uint4 fb[3];
+                    for (int jh = 0; jh < TN; jh += HN) {
+                        uint4 fb[HN];
 #pragma unroll
-                        for (int j = 0; j < 3; ++j) {
+                        for (int j = 0; j < HN; ++j) {
                             const int r = (jh + j) * 32 + fr;
                             fb[j] = *reinterpret_cast<const uint4*>(Bs + (r * 4 + (c ^ ((r >> 2) & 3))) * 16);
                         }
 #pragma unroll
-                        for (int j = 0; j < 3; ++j) mma_step<0>(fb[j], fa, acc[0][jh + j]);     // swapped: a lane owns an output row
+                        for (int j = 0; j < HN; ++j) mma_step<0>(fb[j], fa, acc[0][jh + j]);    // swapped: a lane owns an output row
                         asm volatile("" ::: "memory");
                     }
                 }
@@ -3341,6 +3348,16 @@ extern "C" int edadm_qgemm_i8_grouped_q(const edadm_gemm_problem* probs, int cou
     if (!probs || count < 1 || count > 4 || M <= 0 || M % 128 || (K != 384 && K != 576)) return EDADM_EINVAL;
     BrArgs a;
     memset(&a, 0, sizeof(a));
+    // the GEGLU projections (every problem in output mode 3) take k_gemm_bw on 128-column weight blocks; everything else 192 columns
+#ifndef EDADM_BW_TN
+#define EDADM_BW_TN 4
+#endif
+    static const int64_t use_bw = EDADM_TUNE_I("EDADM_GEMM_BW", EDADM_BW_DEFAULT);
+    static const int64_t bw_tn = EDADM_TUNE_I("EDADM_BW_TN", EDADM_BW_TN);
+    bool all3 = true;
+    for (int i = 0; i < count; ++i) all3 = all3 && probs[i].out_mode == 3 && probs[i].N % 128 == 0;
+    const bool bw = use_bw && all3;
+    const int bn = (bw && bw_tn == 4) ? 128 : 192;
     int ncb = 0;
     for (int i = 0; i < count; ++i) {
         const edadm_gemm_problem& q = probs[i];
@@ -3361,7 +3378,7 @@ extern "C" int edadm_qgemm_i8_grouped_q(const edadm_gemm_problem* probs, int cou
         b.A = (const uint8_t*)q.A; b.W = (const uint8_t*)q.W; b.scale = q.scale; b.bias = q.bias; b.out = q.out; b.oqp = q.oqp;
         b.lda = q.lda; b.ldw = q.ldw; b.ldo = q.ldo; b.rpb = q.out_mode == 4 ? q.rows_per_batch : M; b.N = q.N;
         b.out_mode = q.out_mode; b.cb0 = ncb;
-        ncb += (int)(q.N / 192);
+        ncb += (int)(q.N / bn);
     }
     static int ncu = 0;
     if (!ncu) {
@@ -3385,20 +3402,21 @@ extern "C" int edadm_qgemm_i8_grouped_q(const edadm_gemm_problem* probs, int cou
         hipLaunchKernelGGL((k_gemm_br<3, NK_, MODES_>), grid, dim3(768), 0, (hipStream_t)stream, a);   \
         return edadm_launch_status();                                                                  \
     }
-    // The GEGLU projection at K = 384 takes the twelve-independent-wave form (k_gemm_bw: 224 against 245 us on 102400 x 3072 x 384,
-    // tools/gemm_br_bench.py); the q / k / v launches measured level on the two (112 against 105-110) and stay on k_gemm_br, as does
-    // K = 576 (its 108 KB weight block leaves two ring slots per wave)
-#ifndef EDADM_BW_DEFAULT
-#define EDADM_BW_DEFAULT 1
+    // The GEGLU projections take the twelve-independent-wave form (k_gemm_bw; tools/gemm_br_bench.py: 102400 x 3072 x 384 in 224 us on
+    // 192-column blocks against 245 on k_gemm_br); the q / k / v launches measured level on the two and stay on k_gemm_br
+    if (bw) {
+#ifndef EDADM_BW_NW
+#define EDADM_BW_NW 12
 #endif
-    static const int64_t use_bw = EDADM_TUNE_I("EDADM_GEMM_BW", EDADM_BW_DEFAULT);
-#define EDADM_BW_CASE(NK_, MODES_)                                                                     \
-    if (use_bw && K == 64 * NK_ && modes == MODES_) {                                                  \
-        hipLaunchKernelGGL((k_gemm_bw<NK_, MODES_>), grid, dim3(768), 0, (hipStream_t)stream, a);      \
-        return edadm_launch_status();                                                                  \
+        static const int64_t bw_nw = EDADM_TUNE_I("EDADM_BW_NW", EDADM_BW_NW);
+        if (K == 384 && bn == 128 && bw_nw == 16) hipLaunchKernelGGL((k_gemm_bw<6, 8, 4, 16>), grid, dim3(1024), 0, (hipStream_t)stream, a);
+        else if (K == 576 && bn == 128 && bw_nw == 16) hipLaunchKernelGGL((k_gemm_bw<9, 8, 4, 16>), grid, dim3(1024), 0, (hipStream_t)stream, a);
+        else if (K == 384 && bn == 128) hipLaunchKernelGGL((k_gemm_bw<6, 8, 4>), grid, dim3(768), 0, (hipStream_t)stream, a);
+        else if (K == 576 && bn == 128) hipLaunchKernelGGL((k_gemm_bw<9, 8, 4>), grid, dim3(768), 0, (hipStream_t)stream, a);
+        else if (K == 384) hipLaunchKernelGGL((k_gemm_bw<6, 8, 6>), grid, dim3(768), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((k_gemm_br<3, 9, 8>), grid, dim3(768), 0, (hipStream_t)stream, a);
+        return edadm_launch_status();
     }
-    EDADM_BW_CASE(6, 8)
-#undef EDADM_BW_CASE
     EDADM_BR_CASE(6, 8)  EDADM_BR_CASE(9, 8)          // GEGLU
     EDADM_BR_CASE(6, 6)  EDADM_BR_CASE(9, 6)          // q, k int8 codes, v f16 codes (int8-score attention)
     EDADM_BR_CASE(6, 2)  EDADM_BR_CASE(9, 2)          // f16 codes
